@@ -1,0 +1,194 @@
+/* lipvq_math.h -- canonical fp32 arithmetic of the LipVQ-VAE action tokenizer.
+ *
+ * ONE definition of every transcendental and of the distance reduction, shared
+ * verbatim by the gfx950 device code (hipcc) and by the CPU oracle (gcc).  It
+ * uses only +, -, *, /, fmaf, comparisons and integer bit casts, so that both
+ * compilers (built with -ffp-contract=off; IEEE division; denormals kept)
+ * produce bit-identical results.  That is what lets the GPU path be compared
+ * with the oracle with `==`, not with a tolerance, at any batch size.
+ *
+ * What each function restates (reference: /root/reference/robomimic/models/
+ * vq_vae/backbone_lfqvae_v5.py, "v5" below):
+ *   lq_gelu       nn.GELU() default = exact erf form        (v5:56,58,64,66)
+ *   lq_sigmoid    torch.sigmoid                             (v5:24)
+ *   lq_softplus   F.softplus, beta 1, threshold 20          (v5:10)
+ *   lq_sqdist8    torch.norm(..., dim=-1) BEFORE the sqrt   (v5:43-45)
+ * torch's CPU kernels use vendor libm/Sleef for erf/exp; these polynomials
+ * agree with them to a few ulp (tests/test_oracle_math.py), which is inside
+ * the 1e-5 budget of the north star.  The distance reduction, in contrast, is
+ * reproduced EXACTLY: torch's vectorised L2-norm reduction on x86 (AVX2 and
+ * AVX512 builds alike) keeps 8 partial sums acc[j] += d[8i+j]^2 with fused
+ * multiply-add, then adds the 8 lanes left to right and takes the square root
+ * (established empirically: oracle/probe_torch_norm.py, 0 mismatches in 3e5
+ * distances for D in {32,64,128,208}).  Coefficients: oracle/fit_coeffs.py.
+ */
+#ifndef LIPVQ_MATH_H_
+#define LIPVQ_MATH_H_
+
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define LQ_HD __host__ __device__ __forceinline__
+#else
+#include <math.h>
+#define LQ_HD static inline __attribute__((always_inline))
+#endif
+
+LQ_HD uint32_t lq_f2u(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
+LQ_HD float lq_u2f(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
+LQ_HD float lq_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+LQ_HD float lq_abs(float x) { return lq_u2f(lq_f2u(x) & 0x7fffffffu); }
+
+/* 2^n for n in [-126, 127] */
+LQ_HD float lq_pow2i(int n) { return lq_u2f((uint32_t)(n + 127) << 23); }
+
+/* exp(x): n = rint(x/ln2) by the 1.5*2^23 trick, r = x - n ln2 (two-term
+ * Cody-Waite), exp(r) = 1 + r + r^2 q(r), scaled by 2^n in two exact steps so
+ * that results in the denormal range are rounded once. */
+LQ_HD float lq_expf(float x) {
+    if (!(x == x)) return x;
+    if (x > 88.72283f) x = 88.72283f;       /* exp -> 3.4028e38, no inf */
+    if (x < -104.0f) return 0.0f;            /* below half the smallest denormal */
+    const float magic = 12582912.0f;         /* 1.5 * 2^23 */
+    float n = lq_fma(x, 1.44269504088896341f, magic) - magic;
+    float r = lq_fma(n, -0.693145751953125f, x);          /* ln2 high: 0x3f317200 */
+    r = lq_fma(n, -1.42860682030941723e-6f, r);           /* ln2 low */
+    float q = 0.00019907570094801486f;
+    q = lq_fma(q, r, 0.0013933652080595493f);
+    q = lq_fma(q, r, 0.00833328627049923f);
+    q = lq_fma(q, r, 0.04166646674275398f);
+    q = lq_fma(q, r, 0.1666666716337204f);
+    q = lq_fma(q, r, 0.5f);
+    float p = lq_fma(r * r, q, r) + 1.0f;
+    int ni = (int)n;
+    int h = ni / 2;
+    return (p * lq_pow2i(h)) * lq_pow2i(ni - h);
+}
+
+/* erf(x): |x| < 1: x * s(x^2);  1 <= |x| < 4: 1 - exp(-p(|x|));  else +-1. */
+LQ_HD float lq_erff(float x) {
+    if (!(x == x)) return x;
+    float a = lq_abs(x);
+    float r;
+    if (a < 1.0f) {
+        float t = a * a;
+        float s = 7.889109110692516e-5f;
+        s = lq_fma(s, t, -0.0008020838140510023f);
+        s = lq_fma(s, t, 0.005189535208046436f);
+        s = lq_fma(s, t, -0.026854444295167923f);
+        s = lq_fma(s, t, 0.11283600330352783f);
+        s = lq_fma(s, t, -0.3761262595653534f);
+        s = lq_fma(s, t, 1.1283791065216064f);
+        r = a * s;
+    } else if (a < 4.0f) {
+        float p = -1.4354437780639273e-6f;
+        p = lq_fma(p, a, 4.2518615373410285e-5f);
+        p = lq_fma(p, a, -0.0005705535295419395f);
+        p = lq_fma(p, a, 0.004652169067412615f);
+        p = lq_fma(p, a, -0.02615582011640072f);
+        p = lq_fma(p, a, 0.10967476665973663f);
+        p = lq_fma(p, a, 0.6322006583213806f);
+        p = lq_fma(p, a, 1.1300415992736816f);
+        p = lq_fma(p, a, -0.0002783838426694274f);
+        r = 1.0f - lq_expf(-p);
+    } else {
+        r = 1.0f;
+    }
+    return lq_u2f(lq_f2u(r) | (lq_f2u(x) & 0x80000000u));
+}
+
+/* nn.GELU() (approximate='none'): 0.5 x (1 + erf(x / sqrt 2)) */
+LQ_HD float lq_gelu(float x) {
+    return (0.5f * x) * (1.0f + lq_erff(x * 0.70710678118654752440f));
+}
+
+/* d/dx gelu(x) = Phi(x) + x phi(x) */
+LQ_HD float lq_gelu_grad(float x) {
+    float cdf = 0.5f * (1.0f + lq_erff(x * 0.70710678118654752440f));
+    float pdf = 0.39894228040143267794f * lq_expf(-0.5f * (x * x));
+    return lq_fma(x, pdf, cdf);
+}
+
+LQ_HD float lq_sigmoid(float x) { return 1.0f / (1.0f + lq_expf(-x)); }
+
+/* log(u) for finite u >= 1 (only use: softplus). */
+LQ_HD float lq_logf_ge1(float u) {
+    uint32_t b = lq_f2u(u);
+    int e = (int)(b >> 23) - 127;
+    float m = lq_u2f((b & 0x007fffffu) | 0x3f800000u);   /* [1,2) */
+    if (m > 1.41421356237309504880f) { m = 0.5f * m; e += 1; }
+    float s = (m - 1.0f) / (m + 1.0f);
+    float z = s * s;
+    float r = 0.19365468621253967f;
+    r = lq_fma(r, z, 0.2219124436378479f);
+    r = lq_fma(r, z, 0.28571757674217224f);
+    r = lq_fma(r, z, 0.3999999761581421f);
+    r = lq_fma(r, z, 0.6666666865348816f);
+    float lm = lq_fma(s * z, r, 2.0f * s);
+    float fe = (float)e;
+    return lq_fma(fe, 0.693145751953125f, lq_fma(fe, 1.42860682030941723e-6f, lm));
+}
+
+/* F.softplus(x) with beta = 1, threshold = 20: x if x > 20 else log1p(exp(x)) */
+LQ_HD float lq_softplus(float x) {
+    if (!(x <= 20.0f)) return x;
+    float t = lq_expf(x);
+    float u = 1.0f + t;
+    if (u == 1.0f) return t;
+    return lq_logf_ge1(u) + (t - (u - 1.0f)) / u;    /* log1p correction term */
+}
+
+/* Squared L2 distance in torch's CPU reduction order (see header comment).
+ * z, c: D contiguous floats.  D % 8 != 0: the tail is folded left to right
+ * with fmaf (torch's scalar tail is build dependent; every BASELINE shape and
+ * the real D = 208 are multiples of 8, so that branch is never taken there). */
+LQ_HD float lq_sqdist8(const float* z, const float* c, int D) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+    int i = 0;
+    for (; i + 8 <= D; i += 8) {
+        float d0 = z[i + 0] - c[i + 0], d1 = z[i + 1] - c[i + 1];
+        float d2 = z[i + 2] - c[i + 2], d3 = z[i + 3] - c[i + 3];
+        float d4 = z[i + 4] - c[i + 4], d5 = z[i + 5] - c[i + 5];
+        float d6 = z[i + 6] - c[i + 6], d7 = z[i + 7] - c[i + 7];
+        a0 = lq_fma(d0, d0, a0); a1 = lq_fma(d1, d1, a1);
+        a2 = lq_fma(d2, d2, a2); a3 = lq_fma(d3, d3, a3);
+        a4 = lq_fma(d4, d4, a4); a5 = lq_fma(d5, d5, a5);
+        a6 = lq_fma(d6, d6, a6); a7 = lq_fma(d7, d7, a7);
+    }
+    float s = ((((((a0 + a1) + a2) + a3) + a4) + a5) + a6) + a7;
+    for (; i < D; ++i) { float d = z[i] - c[i]; s = lq_fma(d, d, s); }
+    return s;
+}
+
+/* Squared L2 distance of the plain VQVAE variant,
+ * `(z_e.unsqueeze(1) - E).pow(2).sum(-1)` (reference: robomimic/models/vq_vae/
+ * backbone.py:57-60): every d*d is rounded first (pow materialises a tensor),
+ * then torch's CPU sum keeps 4 accumulators of 8 lanes over 32-wide chunks,
+ * folds left-over 8-vectors into accumulator 0, adds the accumulators and then
+ * the lanes left to right (oracle/probe_torch_norm.py; exact for D % 8 == 0). */
+LQ_HD float lq_sqdist32(const float* z, const float* c, int D) {
+    float acc[4][8];
+    for (int a = 0; a < 4; ++a)
+        for (int j = 0; j < 8; ++j) acc[a][j] = 0.f;
+    int i = 0;
+    for (; i + 32 <= D; i += 32)
+        for (int a = 0; a < 4; ++a)
+            for (int j = 0; j < 8; ++j) {
+                float d = z[i + 8 * a + j] - c[i + 8 * a + j];
+                acc[a][j] = acc[a][j] + d * d;
+            }
+    for (; i + 8 <= D; i += 8)
+        for (int j = 0; j < 8; ++j) {
+            float d = z[i + j] - c[i + j];
+            acc[0][j] = acc[0][j] + d * d;
+        }
+    float s = 0.f;
+    for (int j = 0; j < 8; ++j) {
+        float v = ((acc[0][j] + acc[1][j]) + acc[2][j]) + acc[3][j];
+        s = (j == 0) ? v : s + v;
+    }
+    for (; i < D; ++i) { float d = z[i] - c[i]; s = s + d * d; }
+    return s;
+}
+
+#endif /* LIPVQ_MATH_H_ */

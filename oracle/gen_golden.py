@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE ITSELF in the build container.
+
+The reference modules (robomimic/models/vq_vae/backbone_lfqvae_v5.py and backbone.py) import
+only torch, so they load from /root/reference by file path.  Nothing of the reference is
+copied: a fixture holds arrays only (seeds/shapes, reference outputs, gradients, post-AdamW
+parameters).  Parameters are NOT stored when they can be re-drawn from the seed with
+oracle.lipvq_oracle.make_params (numpy PCG64 + the canonical C oracle, identical on every
+machine); their sha256 is stored so a drifted generator is detected, not silently accepted.
+
+Also asserts, while generating, that oracle.lipvq_oracle.torch_* (the torch-CPU restatement
+bench.py times) is bit-identical to the reference module.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [--ref /root/reference]
+"""
+from __future__ import annotations
+
+import argparse
+import importlib.util
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from oracle import lipvq_oracle as O  # noqa: E402
+
+GOLD = ROOT / "tests" / "golden"
+
+
+def load_ref(ref_root: Path, rel: str, name: str):
+    spec = importlib.util.spec_from_file_location(name, ref_root / rel)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def top2(dist: torch.Tensor):
+    v, _ = torch.topk(dist, 2, dim=-1, largest=False)
+    return v[:, 0].numpy().copy(), v[:, 1].numpy().copy()
+
+
+def ref_llfq_distances(model, z_e):
+    """Distances exactly as LFQQuantizer.forward forms them (v5:39-45), row-chunked."""
+    cb = model.quantizer.codebook
+    out = []
+    for s in range(0, z_e.shape[0], 64):
+        z = z_e[s:s + 64]
+        m = torch.clamp((2 * torch.sign(z) + 1).unsqueeze(1), max=1)
+        out.append(torch.norm(m * (z.unsqueeze(1) - cb.unsqueeze(0)), dim=-1))
+    return torch.cat(out)
+
+
+def meta_of(**kw):
+    kw = dict(kw)
+    kw["torch_version"] = torch.__version__
+    kw["cpu_capability"] = torch.backends.cpu.get_cpu_capability()
+    return np.array(repr(sorted(kw.items())))
+
+
+def run_llfq(ref, name, seed, N, A, D, K, regime="trained", full=False, clamp=False, oracle=None,
+             chunk=None):
+    torch.manual_seed(0)
+    p = O.make_params(seed, A, D, K, regime=regime, variant="llfq", oracle=oracle)
+    x_np = O.make_inputs(seed, N, A, clamp=clamp)
+    model = ref.LLFQVAE_V4(A, D, num_codes=K)
+    model.load_state_dict(O.to_torch(p), strict=True)
+    model = model.float()
+    x = torch.from_numpy(x_np.copy())
+    out = dict(meta=meta_of(name=name, seed=seed, N=N, A=A, D=D, K=K, regime=regime, clamp=clamp,
+                            variant="llfq", full=full),
+               seed=seed, N=N, A=A, D=D, K=K, params_sha256=np.array(O.params_digest(p)))
+    tp = O.to_torch(p)
+    if chunk is None:
+        if full:
+            opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)  # icl.py:887-889
+            opt.zero_grad()
+        z_latent, loss = model(x)
+        # the torch restatement must be the reference, bit for bit
+        zl2, loss2, ex = O.torch_llfq_forward(tp, x)
+        assert torch.equal(z_latent, zl2) and torch.equal(loss, loss2), name
+        with torch.no_grad():
+            h = model.encoder(x)
+            z_e = model.to_latent(h)
+            z_q, idx = model.quantizer(z_e)
+            x_rec = model.to_output(model.decoder(z_q))
+            dist = ref_llfq_distances(model, z_e)
+            d1, d2 = top2(dist)
+            assert torch.equal(z_q, z_latent)
+            assert torch.equal(ex["indices"], idx) and torch.equal(ex["z_e"], z_e)
+            recon = torch.nn.functional.mse_loss(x_rec, x)
+            commit = torch.nn.functional.mse_loss(z_q, z_e)
+        out.update(z_e=z_e.numpy(), indices=idx.numpy().astype(np.int32), x_recon=x_rec.numpy(),
+                   d_best=d1, d_second=d2, recon_loss=np.float32(recon.item()),
+                   commitment_loss=np.float32(commit.item()), loss=np.float32(loss.item()),
+                   z_latent_sum=np.float64(z_latent.double().sum().item()))
+        if full:
+            loss.backward()
+            for k, v in model.named_parameters():
+                out["grad/" + k] = v.grad.numpy().copy()
+            opt.step()
+            for k, v in model.state_dict().items():
+                out["post/" + k] = v.numpy().copy()
+    else:
+        # big shapes: tokenise in row chunks like bench.py's CPU leg does
+        idx, z_lat = O.torch_llfq_tokenize(tp, x, chunk=chunk)
+        with torch.no_grad():
+            z_e = torch.cat([model.to_latent(model.encoder(x[s:s + chunk]))
+                             for s in range(0, N, chunk)])
+            idx_ref = torch.cat([model.quantizer(z_e[s:s + chunk])[1] for s in range(0, N, chunk)])
+            d1s, d2s = [], []
+            for s in range(0, N, chunk):
+                a, b = top2(ref_llfq_distances(model, z_e[s:s + chunk]))
+                d1s.append(a), d2s.append(b)
+        assert torch.equal(idx, idx_ref), name
+        out.update(z_e=z_e.numpy(), indices=idx.numpy().astype(np.int32),
+                   d_best=np.concatenate(d1s), d_second=np.concatenate(d2s),
+                   z_latent_sum=np.float64(z_lat.double().sum().item()))
+    np.savez_compressed(GOLD / f"{name}.npz", **out)
+    used = len(np.unique(out["indices"]))
+    print(f"{name}: N={N} A={A} D={D} K={K} codes used={used}  min rel top-2 gap="
+          f"{np.min((out['d_second'] - out['d_best']) / np.maximum(out['d_second'], 1e-30)):.3e}")
+
+
+def run_vq(ref, name, seed, N, A, D, K, regime="trained", oracle=None):
+    p = O.make_params(seed, A, D, K, regime=regime, variant="vq", oracle=oracle)
+    x_np = O.make_inputs(seed, N, A)
+    model = ref.VQVAE(A, D, num_embeddings=K)
+    model.load_state_dict(O.to_torch(p), strict=True)
+    x = torch.from_numpy(x_np.copy())
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    opt.zero_grad()
+    z_latent, loss = model(x)
+    zl2, loss2, ex = O.torch_vq_forward(O.to_torch(p), x)
+    assert torch.equal(z_latent, zl2) and torch.equal(loss, loss2), name
+    with torch.no_grad():
+        z_e = model.encoder(x)
+        dist = (z_e.unsqueeze(1) - model.embedding.weight).pow(2).sum(-1)
+        idx = torch.argmin(dist, dim=1)
+        d1, d2 = top2(dist)
+        x_rec = ex["x_recon"]
+    out = dict(meta=meta_of(name=name, seed=seed, N=N, A=A, D=D, K=K, regime=regime, variant="vq"),
+               seed=seed, N=N, A=A, D=D, K=K, params_sha256=np.array(O.params_digest(p)),
+               z_e=z_e.numpy(), indices=idx.numpy().astype(np.int32), z_latent=z_latent.numpy(),
+               x_recon=x_rec.detach().numpy(), d_best=d1, d_second=d2,
+               recon_loss=np.float32(ex["recon_loss"].item()),
+               quantization_loss=np.float32(ex["quantization_loss"].item()),
+               loss=np.float32(loss.item()))
+    loss.backward()
+    for k, v in model.named_parameters():
+        out["grad/" + k] = v.grad.numpy().copy()
+    opt.step()
+    for k, v in model.state_dict().items():
+        out["post/" + k] = v.numpy().copy()
+    np.savez_compressed(GOLD / f"{name}.npz", **out)
+    print(f"{name}: N={N} A={A} D={D} K={K} codes used={len(np.unique(out['indices']))}")
+
+
+def run_nearest_edge(ref, name, D=64, K=96, N=160):
+    """Hand-built quantizer inputs: exact ties (duplicate codes), rows equal to a code, a pair of
+    squared distances that differ but share one fp32 square root, zeros, negative entries."""
+    rng = np.random.Generator(np.random.PCG64(4242))
+    cb = rng.uniform(0, 1, (K, D)).astype(np.float32)
+    cb[40] = cb[7]                      # exact duplicate: lower index must win
+    cb[41] = cb[7]
+    z = rng.uniform(0, 1, (N, D)).astype(np.float32)
+    z[0] = cb[7]                        # distance exactly 0 to codes 7, 40, 41
+    z[1] = cb[40] + np.float32(1e-3)
+    z[2] = 0.0
+    z[3] = -z[3]                        # negative latent: exercises the sign mask (v5:39-40)
+    z[4, ::2] = 0.0                     # sign(0) = 0 entries
+    # rows 5..: midpoints of code pairs -> near ties in both orders
+    for r in range(5, 69):
+        a, b = rng.integers(0, K, 2)
+        z[r] = (cb[a] * np.float32(0.5) + cb[b] * np.float32(0.5))
+    # sqrt-merge: two codes at squared distances s and nextafter(s) from one row
+    z[70] = 0.0
+    cb[50] = 0.0
+    cb[51] = 0.0
+    cb[51, 0] = np.float32(0.75)                       # s = 0.5625
+    cb[50, 0] = np.nextafter(np.float32(0.75), np.float32(1))   # slightly larger square, lower index
+    q = ref.LFQQuantizer(K, D)
+    with torch.no_grad():
+        q.codebook.copy_(torch.from_numpy(cb))
+        zt = torch.from_numpy(z)
+        zq, idx = q(zt)
+        m = torch.clamp((2 * torch.sign(zt) + 1).unsqueeze(1), max=1)
+        dist = torch.norm(m * (zt.unsqueeze(1) - q.codebook.unsqueeze(0)), dim=-1)
+    assert idx[0].item() == 7
+    np.savez_compressed(GOLD / f"{name}.npz", meta=meta_of(name=name, variant="llfq-quantizer"),
+                        z_e=z, codebook=cb, indices=idx.numpy().astype(np.int32), z_q=zq.numpy(),
+                        distances=dist.numpy())
+    print(f"{name}: N={N} K={K} D={D}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    args = ap.parse_args()
+    ref_root = Path(args.ref)
+    v5 = load_ref(ref_root, "robomimic/models/vq_vae/backbone_lfqvae_v5.py", "_ref_v5")
+    vq = load_ref(ref_root, "robomimic/models/vq_vae/backbone.py", "_ref_vq")
+    GOLD.mkdir(parents=True, exist_ok=True)
+    torch.set_num_threads(1)       # what the reference's train() sets (scripts/train.py:57)
+    orc = O.CanonicalOracle()
+    # BASELINE config 1 (CPU plumbing case), full fwd + bwd + AdamW
+    run_llfq(v5, "llfq_cfg1_trained", 101, 1024, 7, 32, 256, full=True, oracle=orc)
+    # the authors' own smoke shape (v5:89-92): B=80, A=12, D=208, K=128
+    run_llfq(v5, "llfq_v5main_trained", 102, 80, 12, 208, 128, full=True, oracle=orc)
+    # the real ICRT step shape (obs_nets.py:2411, K default 1024), forward only
+    run_llfq(v5, "llfq_real_k1024", 103, 80, 12, 208, 1024, oracle=orc)
+    # default (degenerate) init: every row -> one code
+    run_llfq(v5, "llfq_default_init", 104, 256, 7, 32, 256, regime="default", oracle=orc)
+    # clamped actions in [-1,1] (RoboCasa deltas)
+    run_llfq(v5, "llfq_cfg1_clamped", 105, 512, 7, 32, 256, clamp=True, oracle=orc)
+    # slices of BASELINE configs 2 and 3
+    run_llfq(v5, "llfq_cfg2_slice", 106, 2048, 7, 64, 1024, oracle=orc, chunk=256)
+    run_llfq(v5, "llfq_cfg3_slice", 107, 192, 7, 128, 8192, oracle=orc, chunk=32)
+    # ragged sizes (N not a multiple of any tile), tiny N
+    run_llfq(v5, "llfq_ragged_n77", 108, 77, 7, 64, 1024, oracle=orc)
+    run_llfq(v5, "llfq_n1", 109, 1, 7, 32, 256, oracle=orc)
+    # plain VQVAE variant (STE)
+    run_vq(vq, "vq_small_trained", 201, 512, 7, 32, 128, oracle=orc)
+    run_vq(vq, "vq_main_trained", 202, 80, 12, 64, 512, oracle=orc)
+    run_vq(vq, "vq_default_init", 203, 128, 7, 32, 128, regime="default", oracle=orc)
+    run_nearest_edge(v5, "llfq_nearest_edge")
+
+
+if __name__ == "__main__":
+    main()

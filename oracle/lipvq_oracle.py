@@ -1,0 +1,374 @@
+"""CPU oracle for the LipVQ-VAE action-tokenizer path -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module; the product (lipvq-vae_amd/) never does.
+
+Two restatements live here:
+
+1. ``CanonicalOracle`` -- ctypes bindings of oracle/lipvq_oracle.c, the plain-C restatement in
+   *canonical fp32* arithmetic (see that file's header).  The gfx950 kernels are required to
+   equal it bit for bit on every forward tensor; it is multi-threaded (OpenMP) so that the
+   full BASELINE batch (524 288 rows x 1024 codes) is checked in seconds.
+
+2. ``torch_*`` functions -- the same algorithm spelled with the very torch-CPU ops the
+   reference uses (reference: robomimic/models/vq_vae/backbone_lfqvae_v5.py:6-84 and
+   robomimic/models/vq_vae/backbone.py:38-76), operating on a plain ``dict`` of tensors keyed
+   like the reference's ``state_dict``.  It is bit-identical to the reference module run in
+   the same process (tests/golden was produced by the reference itself and
+   tests/test_oracle_golden.py holds this restatement to it) and is what bench.py times as
+   the "reference CPU path" (`cpu_baseline.kind = "port"`), because the reference's files
+   cannot travel to the GPU box.
+
+Parameter regimes: ``make_params`` draws a seeded parameter set.  ``regime="default"`` mimics
+the reference constructors' initial distributions; ``regime="trained"`` is the *trained-like*
+regime of SURVEY.md section 7/8d (ci = 40, b ~ N(0,1), codebook U(0,1) with the first K/2 rows
+replaced by sampled z_e + 0.02 noise), because at default init every row maps to one code and
+parity tests would test nothing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import hashlib
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB_PATH = _HERE / "liblipvq_oracle.so"
+
+ACT_NONE, ACT_GELU, ACT_SIGMOID, ACT_RELU = 0, 1, 2, 3
+DIST_NORM, DIST_SQSUM = 0, 1
+
+LLFQ_KEYS = (
+    "encoder.0.weight", "encoder.0.bias", "encoder.2.weight", "encoder.2.bias",
+    "to_latent.W", "to_latent.b", "to_latent.ci", "quantizer.codebook",
+    "decoder.0.weight", "decoder.0.bias", "decoder.2.weight", "decoder.2.bias",
+    "to_output.weight", "to_output.bias",
+)
+VQ_KEYS = (
+    "encoder.0.weight", "encoder.0.bias", "encoder.2.weight", "encoder.2.bias",
+    "encoder.4.weight", "encoder.4.bias",
+    "decoder.0.weight", "decoder.0.bias", "decoder.2.weight", "decoder.2.bias",
+    "decoder.4.weight", "decoder.4.bias", "embedding.weight",
+)
+
+
+def build(force: bool = False) -> Path:
+    """Compile oracle/lipvq_oracle.c (gcc) if the shared object is missing or stale."""
+    src = _HERE / "lipvq_oracle.c"
+    hdr = _HERE.parent / "lipvq-vae_amd" / "csrc" / "lipvq_math.h"
+    stale = (not _LIB_PATH.exists()) or any(
+        p.exists() and p.stat().st_mtime > _LIB_PATH.stat().st_mtime for p in (src, hdr))
+    if force or stale:
+        subprocess.run(["make", "-C", str(_HERE), "-B" if force else "-s"], check=True)
+    return _LIB_PATH
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a, ty=C.c_float):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ty))
+
+
+class CanonicalOracle:
+    """ctypes view of oracle/liblipvq_oracle.so (numpy in, numpy out)."""
+
+    def __init__(self):
+        self.lib = C.CDLL(str(build()))
+        self.lib.lq_ref_abi_version.restype = C.c_int
+
+    # -- primitives -------------------------------------------------------------------------
+    def lipschitz_scale(self, W, ci):
+        W, ci = _f32(W), _f32(ci)
+        D, H = W.shape
+        scale = np.empty(D, np.float32)
+        Wn = np.empty_like(W)
+        self.lib.lq_ref_lipschitz_scale(_p(W), _p(ci), _p(scale), _p(Wn), C.c_int(D), C.c_int(H))
+        return scale, Wn
+
+    def mlp3(self, x, W0, b0, W1, b1, W2, b2, acts, save_pre=False):
+        x = _f32(x)
+        W0, b0, W1, b1, W2, b2 = map(_f32, (W0, b0, W1, b1, W2, b2))
+        N, K0 = x.shape
+        J0, J1, J2 = W0.shape[0], W1.shape[0], W2.shape[0]
+        assert W0.shape[1] == K0 and W1.shape[1] == J0 and W2.shape[1] == J1
+        y = np.empty((N, J2), np.float32)
+        pre = [np.empty((N, J), np.float32) if save_pre else None for J in (J0, J1, J2)]
+        self.lib.lq_ref_mlp3(_p(x), _p(W0), _p(b0), _p(W1), _p(b1), _p(W2), _p(b2), _p(y),
+                             _p(pre[0]), _p(pre[1]), _p(pre[2]), C.c_int64(N), C.c_int(K0),
+                             C.c_int(J0), C.c_int(J1), C.c_int(J2), C.c_int(acts[0]),
+                             C.c_int(acts[1]), C.c_int(acts[2]))
+        return (y, pre) if save_pre else y
+
+    def nearest(self, z, codebook, dist=DIST_NORM, want_best=False):
+        z, cb = _f32(z), _f32(codebook)
+        N, D = z.shape
+        K = cb.shape[0]
+        assert cb.shape[1] == D
+        idx = np.empty(N, np.int64)
+        zq = np.empty((N, D), np.float32)
+        usage = np.zeros(K, np.int64)
+        best = np.empty(N, np.float32) if want_best else None
+        self.lib.lq_ref_nearest(_p(z), _p(cb), _p(idx, C.c_int64), _p(zq), _p(usage, C.c_int64),
+                                _p(best), C.c_int64(N), C.c_int(K), C.c_int(D), C.c_int(dist))
+        return (idx, zq, usage, best) if want_best else (idx, zq, usage)
+
+    def distances(self, z, codebook, dist=DIST_NORM):
+        z, cb = _f32(z), _f32(codebook)
+        out = np.empty((z.shape[0], cb.shape[0]), np.float32)
+        self.lib.lq_ref_distances(_p(z), _p(cb), _p(out), C.c_int64(z.shape[0]),
+                                  C.c_int(cb.shape[0]), C.c_int(z.shape[1]), C.c_int(dist))
+        return out
+
+    def ste(self, ze, zq):
+        ze, zq = _f32(ze), _f32(zq)
+        out = np.empty_like(ze)
+        self.lib.lq_ref_ste(_p(ze), _p(zq), _p(out), C.c_int64(ze.size))
+        return out
+
+    def mse_pair(self, xr, x, zq, ze):
+        xr, x, zq, ze = map(_f32, (xr, x, zq, ze))
+        out = np.empty(2, np.float32)
+        self.lib.lq_ref_mse_pair(_p(xr), _p(x), C.c_int64(x.size), _p(zq), _p(ze),
+                                 C.c_int64(ze.size), _p(out))
+        return float(out[0]), float(out[1])
+
+    def mlp3_bwd(self, x, W0, W1, W2, pre, gy, acts, want_gx=True):
+        x, W0, W1, W2, gy = map(_f32, (x, W0, W1, W2, gy))
+        pre = [_f32(p) for p in pre]
+        N, K0 = x.shape
+        J0, J1, J2 = W0.shape[0], W1.shape[0], W2.shape[0]
+        g = dict(W0=np.empty_like(W0), b0=np.empty(J0, np.float32), W1=np.empty_like(W1),
+                 b1=np.empty(J1, np.float32), W2=np.empty_like(W2), b2=np.empty(J2, np.float32),
+                 x=np.empty_like(x) if want_gx else None)
+        self.lib.lq_ref_mlp3_bwd(_p(x), _p(W0), _p(W1), _p(W2), _p(pre[0]), _p(pre[1]), _p(pre[2]),
+                                 _p(gy), _p(g["W0"]), _p(g["b0"]), _p(g["W1"]), _p(g["b1"]),
+                                 _p(g["W2"]), _p(g["b2"]), _p(g["x"]), C.c_int64(N), C.c_int(K0),
+                                 C.c_int(J0), C.c_int(J1), C.c_int(J2), C.c_int(acts[0]),
+                                 C.c_int(acts[1]), C.c_int(acts[2]))
+        return g
+
+    def lipschitz_bwd(self, W, ci, gWn):
+        W, ci, gWn = map(_f32, (W, ci, gWn))
+        gW, gci = np.empty_like(W), np.empty_like(ci)
+        self.lib.lq_ref_lipschitz_bwd(_p(W), _p(ci), _p(gWn), _p(gW), _p(gci), C.c_int(W.shape[0]),
+                                      C.c_int(W.shape[1]))
+        return gW, gci
+
+    def scatter_add(self, g, idx, K):
+        g = _f32(g)
+        idx = np.ascontiguousarray(idx, np.int64)
+        out = np.empty((K, g.shape[1]), np.float32)
+        self.lib.lq_ref_scatter_add(_p(g), _p(idx, C.c_int64), _p(out), C.c_int64(g.shape[0]),
+                                    C.c_int(K), C.c_int(g.shape[1]))
+        return out
+
+    def math_probe(self, x, fn):
+        x = _f32(x).reshape(-1)
+        out = np.empty_like(x)
+        self.lib.lq_ref_math_probe(_p(x), _p(out), C.c_int64(x.size), C.c_int(fn))
+        return out
+
+    # -- whole-path forwards (canonical arithmetic) ------------------------------------------
+    def llfq_encode(self, p, x, save_pre=False):
+        """x -> z_e  (v5:71-72)."""
+        _, Wn = self.lipschitz_scale(p["to_latent.W"], p["to_latent.ci"])
+        return self.mlp3(x, p["encoder.0.weight"], p["encoder.0.bias"], p["encoder.2.weight"],
+                         p["encoder.2.bias"], Wn, p["to_latent.b"],
+                         (ACT_GELU, ACT_GELU, ACT_SIGMOID), save_pre=save_pre)
+
+    def llfq_forward(self, p, x):
+        """Everything LLFQVAE_V4.forward computes (v5:70-84), as a dict of numpy arrays."""
+        ze, pre_e = self.llfq_encode(p, x, save_pre=True)
+        idx, zq, usage = self.nearest(ze, p["quantizer.codebook"], DIST_NORM)
+        xr, pre_d = self.mlp3(zq, p["decoder.0.weight"], p["decoder.0.bias"], p["decoder.2.weight"],
+                              p["decoder.2.bias"], p["to_output.weight"], p["to_output.bias"],
+                              (ACT_GELU, ACT_GELU, ACT_NONE), save_pre=True)
+        recon, commit = self.mse_pair(xr, x, zq, ze)
+        loss = np.float32(recon) + np.float32(0.25) * np.float32(commit) + np.float32(0.25) * np.float32(commit)
+        return dict(z_e=ze, indices=idx, z_q=zq, z_latent=zq.copy(), x_recon=xr, usage=usage,
+                    recon_loss=recon, commitment_loss=commit, codebook_loss=commit,
+                    loss=float(loss), pre_enc=pre_e, pre_dec=pre_d)
+
+    def vq_forward(self, p, x, commitment_cost=0.25):
+        """Everything VQVAE.forward computes (vq:38-76)."""
+        R = (ACT_RELU, ACT_RELU, ACT_RELU)
+        ze, pre_e = self.mlp3(x, p["encoder.0.weight"], p["encoder.0.bias"], p["encoder.2.weight"],
+                              p["encoder.2.bias"], p["encoder.4.weight"], p["encoder.4.bias"], R,
+                              save_pre=True)
+        idx, zq, usage = self.nearest(ze, p["embedding.weight"], DIST_SQSUM)
+        zst = self.ste(ze, zq)
+        xr, pre_d = self.mlp3(zst, p["decoder.0.weight"], p["decoder.0.bias"], p["decoder.2.weight"],
+                              p["decoder.2.bias"], p["decoder.4.weight"], p["decoder.4.bias"], R,
+                              save_pre=True)
+        recon, emb = self.mse_pair(xr, x, zq, ze)
+        loss = np.float32(recon) + (np.float32(emb) + np.float32(commitment_cost) * np.float32(emb))
+        return dict(z_e=ze, indices=idx, z_q=zq, z_latent=zst, x_recon=xr, usage=usage,
+                    recon_loss=recon, embedding_loss=emb, loss=float(loss), pre_enc=pre_e,
+                    pre_dec=pre_d)
+
+
+# ---------------------------------------------------------------------------------------------
+# torch-CPU restatement (same op sequence as the reference; bit-identical to it in-process)
+# ---------------------------------------------------------------------------------------------
+
+def torch_llfq_encode(p, x):
+    """x[N,A] -> z_e[N,D]   (v5:54-59 encoder, v5:6-12 normalization, v5:22-24 Lipschitz layer)."""
+    import torch
+    import torch.nn.functional as F
+    h = F.gelu(F.linear(x, p["encoder.0.weight"], p["encoder.0.bias"]))
+    h = F.gelu(F.linear(h, p["encoder.2.weight"], p["encoder.2.bias"]))
+    W, b, ci = p["to_latent.W"], p["to_latent.b"], p["to_latent.ci"]
+    rowsum = torch.sum(torch.abs(W), dim=1, keepdim=True)
+    scale = torch.minimum(torch.tensor(1.0), F.softplus(ci).unsqueeze(1) / rowsum)
+    return torch.sigmoid(torch.matmul(h, (W * scale).T) + b)
+
+
+def torch_llfq_quantize(codebook, z_e):
+    """z_e[N,D] -> (z_q[N,D], idx[N])   (v5:37-48).  Materialises the [N,K,D] difference tensor
+    exactly as the reference does, so the caller must chunk N (see torch_llfq_tokenize)."""
+    import torch
+    mask = torch.clamp((2 * torch.sign(z_e) + 1).unsqueeze(1), max=1)
+    diff = mask * (z_e.unsqueeze(1) - codebook.unsqueeze(0))
+    idx = torch.argmin(torch.norm(diff, dim=-1), dim=-1)
+    return codebook[idx], idx
+
+
+def torch_llfq_forward(p, x):
+    """(z_latent, loss, extras)   (v5:70-84)."""
+    import torch.nn.functional as F
+    z_e = torch_llfq_encode(p, x)
+    z_q, idx = torch_llfq_quantize(p["quantizer.codebook"], z_e)
+    z_latent = z_q.clone().detach()
+    h = F.gelu(F.linear(z_q, p["decoder.0.weight"], p["decoder.0.bias"]))
+    h = F.gelu(F.linear(h, p["decoder.2.weight"], p["decoder.2.bias"]))
+    x_rec = F.linear(h, p["to_output.weight"], p["to_output.bias"])
+    recon = F.mse_loss(x_rec, x)
+    commit = F.mse_loss(z_q.detach(), z_e)
+    cbl = F.mse_loss(z_q, z_e.detach())
+    loss = recon + 0.25 * commit + 0.25 * cbl
+    return z_latent, loss, dict(z_e=z_e, indices=idx, x_recon=x_rec, recon_loss=recon,
+                                commitment_loss=commit, codebook_loss=cbl)
+
+
+def torch_llfq_tokenize(p, x, chunk=256):
+    """encode + quantize over row chunks (the metric's path): returns (indices, z_latent).
+    chunk=256 keeps the reference's [chunk,K,D] temporary at 67 MB for K=1024, D=64."""
+    import torch
+    out_i, out_z = [], []
+    with torch.no_grad():
+        for s in range(0, x.shape[0], chunk):
+            z_e = torch_llfq_encode(p, x[s:s + chunk])
+            z_q, idx = torch_llfq_quantize(p["quantizer.codebook"], z_e)
+            out_i.append(idx)
+            out_z.append(z_q)
+    return torch.cat(out_i), torch.cat(out_z)
+
+
+def torch_vq_forward(p, x, commitment_cost=0.25):
+    """(z_latent, loss, extras) of the plain VQVAE variant   (vq:38-76)."""
+    import torch
+    import torch.nn.functional as F
+    h = x
+    for i in (0, 2, 4):
+        h = F.relu(F.linear(h, p[f"encoder.{i}.weight"], p[f"encoder.{i}.bias"]))
+    z_e = h
+    E = p["embedding.weight"]
+    dist = (z_e.unsqueeze(1) - E).pow(2).sum(-1)
+    idx = torch.argmin(dist, dim=1)
+    z_q = F.embedding(idx, E)
+    q_loss = F.mse_loss(z_q, z_e.detach()) + commitment_cost * F.mse_loss(z_q.detach(), z_e)
+    z_st = z_e + (z_q - z_e).detach()
+    z_latent = z_st.clone().detach()
+    h = z_st
+    for i in (0, 2, 4):
+        h = F.relu(F.linear(h, p[f"decoder.{i}.weight"], p[f"decoder.{i}.bias"]))
+    recon = F.mse_loss(h, x)
+    return z_latent, recon + q_loss, dict(z_e=z_e, indices=idx, x_recon=h, recon_loss=recon,
+                                          quantization_loss=q_loss)
+
+
+# ---------------------------------------------------------------------------------------------
+# seeded synthetic parameters / inputs (numpy PCG64: identical on every machine)
+# ---------------------------------------------------------------------------------------------
+
+def _linear_init(rng, out_f, in_f):
+    # nn.Linear default: U(-1/sqrt(in), 1/sqrt(in)) for weight and bias
+    bound = 1.0 / np.sqrt(in_f)
+    return (rng.uniform(-bound, bound, (out_f, in_f)).astype(np.float32),
+            rng.uniform(-bound, bound, (out_f,)).astype(np.float32))
+
+
+def make_inputs(seed, N, A, clamp=False):
+    rng = np.random.Generator(np.random.PCG64(seed + 7919))
+    x = rng.standard_normal((N, A)).astype(np.float32)
+    return np.clip(x, -1.0, 1.0) if clamp else x
+
+
+def make_params(seed, A, D, K, hidden=128, regime="trained", variant="llfq", oracle=None):
+    """Seeded parameter dict (numpy float32) keyed like the reference state_dict."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    p = {}
+    if variant == "llfq":
+        p["encoder.0.weight"], p["encoder.0.bias"] = _linear_init(rng, 64, A)
+        p["encoder.2.weight"], p["encoder.2.bias"] = _linear_init(rng, hidden, 64)
+        p["to_latent.W"] = rng.standard_normal((D, hidden)).astype(np.float32)      # v5:18
+        p["to_latent.b"] = np.zeros(D, np.float32)                                   # v5:19
+        p["to_latent.ci"] = np.ones(D, np.float32)                                   # v5:20
+        bound = np.sqrt(6.0 / D)                                                     # kaiming_uniform_, v5:35
+        p["quantizer.codebook"] = rng.uniform(-bound, bound, (K, D)).astype(np.float32)
+        p["decoder.0.weight"], p["decoder.0.bias"] = _linear_init(rng, 64, D)
+        p["decoder.2.weight"], p["decoder.2.bias"] = _linear_init(rng, hidden, 64)
+        p["to_output.weight"], p["to_output.bias"] = _linear_init(rng, A, hidden)
+        if regime == "trained":
+            oracle = oracle or CanonicalOracle()
+            p["to_latent.ci"] = np.full(D, 40.0, np.float32)
+            p["to_latent.b"] = rng.standard_normal(D).astype(np.float32)
+            cb = rng.uniform(0.0, 1.0, (K, D)).astype(np.float32)
+            M = max(4 * K, 1024)
+            xs = rng.standard_normal((M, A)).astype(np.float32)
+            ze = oracle.llfq_encode(p, xs)
+            pick = rng.permutation(M)[: K // 2]
+            noise = (0.02 * rng.standard_normal((K // 2, D))).astype(np.float32)
+            cb[: K // 2] = ze[pick] + noise
+            p["quantizer.codebook"] = cb
+    elif variant == "vq":
+        p["encoder.0.weight"], p["encoder.0.bias"] = _linear_init(rng, 64, A)
+        p["encoder.2.weight"], p["encoder.2.bias"] = _linear_init(rng, 128, 64)
+        p["encoder.4.weight"], p["encoder.4.bias"] = _linear_init(rng, D, 128)
+        p["decoder.0.weight"], p["decoder.0.bias"] = _linear_init(rng, 128, D)
+        p["decoder.2.weight"], p["decoder.2.bias"] = _linear_init(rng, 64, 128)
+        p["decoder.4.weight"], p["decoder.4.bias"] = _linear_init(rng, A, 64)
+        p["embedding.weight"] = rng.uniform(-1.0 / K, 1.0 / K, (K, D)).astype(np.float32)  # vq:36
+        if regime == "trained":
+            oracle = oracle or CanonicalOracle()
+            p["encoder.4.bias"] = (0.3 + 0.2 * rng.standard_normal(D)).astype(np.float32)
+            M = max(4 * K, 1024)
+            xs = rng.standard_normal((M, A)).astype(np.float32)
+            R = (ACT_RELU, ACT_RELU, ACT_RELU)
+            ze = oracle.mlp3(xs, p["encoder.0.weight"], p["encoder.0.bias"], p["encoder.2.weight"],
+                             p["encoder.2.bias"], p["encoder.4.weight"], p["encoder.4.bias"], R)
+            pick = rng.permutation(M)[: K // 2]
+            cb = rng.uniform(0.0, 1.0, (K, D)).astype(np.float32)
+            cb[: K // 2] = ze[pick] + (0.02 * rng.standard_normal((K // 2, D))).astype(np.float32)
+            p["embedding.weight"] = cb
+    else:
+        raise ValueError(variant)
+    return p
+
+
+def params_digest(p):
+    h = hashlib.sha256()
+    for k in sorted(p):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(p[k]).tobytes())
+    return h.hexdigest()
+
+
+def to_torch(p):
+    import torch
+    return {k: torch.from_numpy(np.ascontiguousarray(v).copy()) for k, v in p.items()}
