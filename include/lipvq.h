@@ -1,0 +1,93 @@
+/* lipvq.h -- C ABI of the MI355X (gfx950) LipVQ-VAE action-tokenizer library.
+ *
+ * The reference is pure Python/PyTorch: its "FFI" for this path is the set of stock torch ops
+ * that LLFQVAE_V4.forward / VQVAE.forward issue (reference files, relative to /root/reference:
+ *   v5 = robomimic/models/vq_vae/backbone_lfqvae_v5.py,  vq = robomimic/models/vq_vae/backbone.py).
+ * Each entry point below replaces one group of those ops with one hand-written HIP launch and
+ * cites the lines it replaces.  The reference-side binding (a ctypes stub called from a
+ * torch.autograd.Function) is shown in INTEGRATION.md and implemented in
+ * lipvq-vae_amd/_capi.py.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch allocates); the library
+ *     never frees, retains or reallocates it.  Tensors are row-major contiguous fp32 unless a
+ *     parameter says otherwise; indices and usage counts are int64 (torch.long).
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
+ *     Work is only enqueued; no entry point synchronises the device.
+ *   - return value: 0 on success, a negative LIPVQ_E* code otherwise; lipvq_last_error()
+ *     returns a thread-local message.  Nothing throws across the ABI.
+ *   - stateless and re-entrant; one process per GPU.
+ *   - arithmetic: "canonical fp32" (lipvq-vae_amd/csrc/lipvq_math.h): every forward tensor is
+ *     bit-identical to oracle/lipvq_oracle.c on the same inputs.
+ */
+#ifndef LIPVQ_H_
+#define LIPVQ_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LIPVQ_ABI_VERSION 1
+
+enum { LIPVQ_OK = 0, LIPVQ_EINVAL = -1, LIPVQ_EUNSUPPORTED = -2, LIPVQ_EHIP = -3 };
+
+/* activation codes of lipvq_mlp3_* */
+enum { LIPVQ_ACT_NONE = 0, LIPVQ_ACT_GELU = 1, LIPVQ_ACT_SIGMOID = 2, LIPVQ_ACT_RELU = 3 };
+
+/* distance rules of lipvq_nearest_f32 */
+enum {
+    LIPVQ_DIST_NORM = 0,  /* v5:43-46  torch.norm(.., dim=-1) then argmin (compares square roots) */
+    LIPVQ_DIST_SQSUM = 1  /* vq:58-63  (..).pow(2).sum(-1) then argmin */
+};
+
+int lipvq_abi_version(void);
+const char* lipvq_last_error(void);
+
+/* v5:6-12 normalization():  scale[i] = min(1, softplus(ci[i]) / sum_j |W[i][j]|),  Wn = W * scale.
+ * W [D][H], ci [D]; scale [D] and Wn [D][H] are outputs (either may be NULL). */
+int lipvq_lipschitz_scale_f32(const float* W, const float* ci, float* scale, float* Wn, int D, int H,
+                              void* stream);
+
+/* A three-layer perceptron y = act2(L2(act1(L1(act0(L0(x)))))) with nn.Linear weights
+ * W_l [J_l][K_l] -- the shape of every MLP stack on the path:
+ *   v5:54-59 + v5:22-24   encoder + Lipschitz layer   (A -> 64 -> hidden -> D; gelu, gelu, sigmoid; W2 = Wn)
+ *   v5:62-68              decoder + to_output         (D -> 64 -> hidden -> A; gelu, gelu, none)
+ *   vq:17-24 / vq:25-32   ReLU encoder / decoder      (relu x3)
+ * The weights are first re-laid out into MFMA A-operand order by lipvq_mlp3_pack_f32 (once
+ * per parameter update); `packed` needs lipvq_mlp3_packed_floats() floats.
+ * J0 and J1 must be multiples of 32 (<= 256); K0 and J2 are free. */
+size_t lipvq_mlp3_packed_floats(int K0, int J0, int J1, int J2);
+int lipvq_mlp3_pack_f32(const float* W0, const float* b0, const float* W1, const float* b1,
+                        const float* W2, const float* b2, float* packed, int K0, int J0, int J1,
+                        int J2, void* stream);
+/* x [N][K0], or, when gather_idx != NULL, row n of the input is table x[gather_idx[n]] (the
+ * codebook gather of v5:47 fused into the decoder's first layer).  y [N][J2].  pre0/pre1/pre2
+ * (each may be NULL) receive the pre-activations [N][J_l] that the backward pass needs. */
+int lipvq_mlp3_f32(const float* x, const int64_t* gather_idx, const float* packed, float* y,
+                   float* pre0, float* pre1, float* pre2, int64_t N, int K0, int J0, int J1, int J2,
+                   int act0, int act1, int act2, void* stream);
+
+/* v5:37-48 LFQQuantizer.forward / vq:55-66 VQVAE.quantize (distance + argmin + gather):
+ *   idx[n] = first k minimising dist(z[n], codebook[k]);  zq[n] = codebook[idx[n]];
+ *   usage[k] += number of rows mapped to k (usage may be NULL; it is NOT zeroed here).
+ * z [N][D], codebook [K][D], idx [N] int64, zq [N][D] (may be NULL), best [N] (may be NULL)
+ * receives the winning compared value.  Never materialises [N][K] or [N][K][D]. */
+int lipvq_nearest_f32(const float* z, const float* codebook, int64_t* idx, float* zq,
+                      int64_t* usage, float* best, int64_t N, int K, int D, int dist, void* stream);
+
+/* vq:74 straight-through value  out = z_e + (z_q - z_e)  (fp32, as torch rounds it). */
+int lipvq_ste_f32(const float* ze, const float* zq, float* out, int64_t n_elem, void* stream);
+
+/* v5:79-81 / vq:50,69-70  F.mse_loss pair:  out[0] = mean((xr-x)^2) over nx elements,
+ * out[1] = mean((zq-ze)^2) over nz elements.  workspace: lipvq_mse_workspace_bytes() bytes. */
+size_t lipvq_mse_workspace_bytes(void);
+int lipvq_mse_pair_f32(const float* xr, const float* x, int64_t nx, const float* zq, const float* ze,
+                       int64_t nz, float* out2, void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIPVQ_H_ */

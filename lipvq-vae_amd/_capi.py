@@ -1,0 +1,64 @@
+"""ctypes binding of the gfx950 tokenizer library (include/lipvq.h).
+
+This is the stub a maintainer of the reference would add next to
+robomimic/models/vq_vae/backbone_lfqvae_v5.py: it passes raw device
+pointers and the current HIP stream; PyTorch keeps ownership of every buffer.
+
+There is NO fallback: if the shared object is missing the import of the product fails, and a
+non-zero status from the library raises RuntimeError with the library's message.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_LIB_PATH = Path(__file__).resolve().parent / "_lipvq_hip.so"
+
+ACT_NONE, ACT_GELU, ACT_SIGMOID, ACT_RELU = 0, 1, 2, 3
+DIST_NORM, DIST_SQSUM = 0, 1
+ABI_VERSION = 1
+
+_vp, _i, _i64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/lipvq.h one to one (tests/test_abi.py checks it)
+SIGNATURES = {
+    "lipvq_abi_version": (_i, []),
+    "lipvq_last_error": (C.c_char_p, []),
+    "lipvq_lipschitz_scale_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "lipvq_mlp3_packed_floats": (_sz, [_i, _i, _i, _i]),
+    "lipvq_mlp3_pack_f32": (_i, [_vp] * 7 + [_i] * 4 + [_vp]),
+    "lipvq_mlp3_f32": (_i, [_vp] * 7 + [_i64] + [_i] * 7 + [_vp]),
+    "lipvq_nearest_f32": (_i, [_vp] * 6 + [_i64, _i, _i, _i, _vp]),
+    "lipvq_ste_f32": (_i, [_vp, _vp, _vp, _i64, _vp]),
+    "lipvq_mse_workspace_bytes": (_sz, []),
+    "lipvq_mse_pair_f32": (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
+}
+
+
+class LipvqLibraryError(RuntimeError):
+    pass
+
+
+def _load():
+    if not _LIB_PATH.exists():
+        raise ImportError(
+            f"{_LIB_PATH} is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C lipvq-vae_amd/csrc). "
+            "There is no CPU fallback for the tokenizer path.")
+    lib = C.CDLL(str(_LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library drift
+        fn.restype, fn.argtypes = res, args
+    got = lib.lipvq_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"lipvq ABI version {got} != expected {ABI_VERSION}")
+    return lib
+
+
+lib = _load()
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = lib.lipvq_last_error().decode(errors="replace")
+        raise LipvqLibraryError(f"{what} failed with status {status}: {msg}")

@@ -37,6 +37,9 @@
 LQ_HD uint32_t lq_f2u(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
 LQ_HD float lq_u2f(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
 LQ_HD float lq_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+/* IEEE correctly rounded square root: sqrtss on the host; on gfx950 the refined sequence hipcc
+ * emits under -fhip-fp32-correctly-rounded-divide-sqrt (NOT __fsqrt_rn, which is the 1-ulp native op). */
+LQ_HD float lq_sqrt(float x) { return __builtin_sqrtf(x); }
 LQ_HD float lq_abs(float x) { return lq_u2f(lq_f2u(x) & 0x7fffffffu); }
 
 /* 2^n for n in [-126, 127] */

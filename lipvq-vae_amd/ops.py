@@ -1,0 +1,133 @@
+"""Tensor-level wrappers over the C ABI (include/lipvq.h): validation, output allocation and
+stream plumbing only -- all arithmetic happens in the HIP library.
+
+Every function takes CUDA(HIP) fp32 contiguous tensors on one device and enqueues work on
+``torch.cuda.current_stream()``.  A CPU tensor is an error (there is no CPU path in the
+product; the CPU restatement lives in oracle/ and is test infrastructure).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _capi
+from ._capi import (ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, DIST_NORM, DIST_SQSUM, check, lib)
+
+__all__ = ["lipschitz_scale", "mlp3_pack", "mlp3", "nearest", "ste", "mse_pair", "ACT_NONE", "ACT_GELU",
+           "ACT_SIGMOID", "ACT_RELU", "DIST_NORM", "DIST_SQSUM"]
+
+
+def _chk(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: the LipVQ tokenizer path runs on the GPU only (got a {t.device} tensor)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def lipschitz_scale(W: torch.Tensor, ci: torch.Tensor):
+    """(scale[D], Wn[D,H]) of the reference's normalization() (backbone_lfqvae_v5.py:6-12)."""
+    W, ci = _chk(W, "W"), _chk(ci, "ci")
+    D, H = W.shape
+    scale = torch.empty(D, device=W.device, dtype=torch.float32)
+    Wn = torch.empty_like(W)
+    with torch.cuda.device(W.device):
+        check(lib.lipvq_lipschitz_scale_f32(_ptr(W), _ptr(ci), _ptr(scale), _ptr(Wn), D, H, _stream()),
+              "lipvq_lipschitz_scale_f32")
+    return scale, Wn
+
+
+class PackedMlp3:
+    """Weights of one three-layer stack in MFMA A-operand order (see csrc/lipvq_hip.hip)."""
+
+    __slots__ = ("buf", "K0", "J0", "J1", "J2")
+
+    def __init__(self, buf, K0, J0, J1, J2):
+        self.buf, self.K0, self.J0, self.J1, self.J2 = buf, K0, J0, J1, J2
+
+
+def mlp3_pack(W0, b0, W1, b1, W2, b2) -> PackedMlp3:
+    W0, b0, W1, b1, W2, b2 = (_chk(t, n) for t, n in
+                              ((W0, "W0"), (b0, "b0"), (W1, "W1"), (b1, "b1"), (W2, "W2"), (b2, "b2")))
+    J0, K0 = W0.shape
+    J1, J2 = W1.shape[0], W2.shape[0]
+    if W1.shape[1] != J0 or W2.shape[1] != J1 or b0.numel() != J0 or b1.numel() != J1 or b2.numel() != J2:
+        raise ValueError("mlp3_pack: inconsistent layer shapes")
+    n = lib.lipvq_mlp3_packed_floats(K0, J0, J1, J2)
+    buf = torch.empty(n, device=W0.device, dtype=torch.float32)
+    with torch.cuda.device(W0.device):
+        check(lib.lipvq_mlp3_pack_f32(_ptr(W0), _ptr(b0), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(buf),
+                                      K0, J0, J1, J2, _stream()), "lipvq_mlp3_pack_f32")
+    return PackedMlp3(buf, K0, J0, J1, J2)
+
+
+def mlp3(x: torch.Tensor, packed: PackedMlp3, acts, gather_idx: torch.Tensor | None = None,
+         N: int | None = None, save_pre: bool = False):
+    """y[N,J2] (and the three pre-activation tensors when save_pre).  With gather_idx, row n of
+    the input is x[gather_idx[n]] (x is then the table, e.g. the codebook)."""
+    x = _chk(x, "x")
+    if x.dim() != 2 or x.shape[1] != packed.K0:
+        raise ValueError(f"mlp3: x must be [N,{packed.K0}], got {tuple(x.shape)}")
+    if gather_idx is not None:
+        gather_idx = _chk(gather_idx, "gather_idx", torch.int64)
+        N = gather_idx.numel()
+    else:
+        N = x.shape[0]
+    dev = x.device
+    y = torch.empty((N, packed.J2), device=dev, dtype=torch.float32)
+    pre = [torch.empty((N, J), device=dev, dtype=torch.float32) if save_pre else None
+           for J in (packed.J0, packed.J1, packed.J2)]
+    with torch.cuda.device(dev):
+        check(lib.lipvq_mlp3_f32(_ptr(x), _ptr(gather_idx), _ptr(packed.buf), _ptr(y), _ptr(pre[0]),
+                                 _ptr(pre[1]), _ptr(pre[2]), N, packed.K0, packed.J0, packed.J1, packed.J2,
+                                 int(acts[0]), int(acts[1]), int(acts[2]), _stream()), "lipvq_mlp3_f32")
+    return (y, pre) if save_pre else y
+
+
+def nearest(z: torch.Tensor, codebook: torch.Tensor, dist: int = DIST_NORM, usage: torch.Tensor | None = None,
+            want_zq: bool = True, want_best: bool = False):
+    """(idx[N] int64, zq[N,D] or None, best[N] or None); usage[K] int64 is accumulated in place."""
+    z, codebook = _chk(z, "z"), _chk(codebook, "codebook")
+    N, D = z.shape
+    K = codebook.shape[0]
+    if codebook.shape[1] != D:
+        raise ValueError(f"nearest: codebook must be [K,{D}], got {tuple(codebook.shape)}")
+    if usage is not None:
+        usage = _chk(usage, "usage", torch.int64)
+        if usage.numel() != K:
+            raise ValueError("nearest: usage must have K entries")
+    idx = torch.empty(N, device=z.device, dtype=torch.int64)
+    zq = torch.empty_like(z) if want_zq else None
+    best = torch.empty(N, device=z.device, dtype=torch.float32) if want_best else None
+    with torch.cuda.device(z.device):
+        check(lib.lipvq_nearest_f32(_ptr(z), _ptr(codebook), _ptr(idx), _ptr(zq), _ptr(usage), _ptr(best),
+                                    N, K, D, int(dist), _stream()), "lipvq_nearest_f32")
+    return idx, zq, best
+
+
+def ste(ze: torch.Tensor, zq: torch.Tensor) -> torch.Tensor:
+    ze, zq = _chk(ze, "ze"), _chk(zq, "zq")
+    out = torch.empty_like(ze)
+    with torch.cuda.device(ze.device):
+        check(lib.lipvq_ste_f32(_ptr(ze), _ptr(zq), _ptr(out), ze.numel(), _stream()), "lipvq_ste_f32")
+    return out
+
+
+def mse_pair(xr, x, zq, ze) -> torch.Tensor:
+    """tensor([mean((xr-x)^2), mean((zq-ze)^2)]) on the device."""
+    xr, x, zq, ze = _chk(xr, "xr"), _chk(x, "x"), _chk(zq, "zq"), _chk(ze, "ze")
+    out = torch.empty(2, device=x.device, dtype=torch.float32)
+    ws = torch.empty(lib.lipvq_mse_workspace_bytes(), device=x.device, dtype=torch.uint8)
+    with torch.cuda.device(x.device):
+        check(lib.lipvq_mse_pair_f32(_ptr(xr), _ptr(x), x.numel(), _ptr(zq), _ptr(ze), ze.numel(), _ptr(out),
+                                     _ptr(ws), _stream()), "lipvq_mse_pair_f32")
+    return out

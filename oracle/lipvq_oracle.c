@@ -124,7 +124,7 @@ LQ_EXPORT void lq_ref_nearest(const float* z, const float* C, int64_t* idx, floa
         for (int k = 0; k < K; ++k) {
             const float* cr = C + (size_t)k * D;
             float s = (dist == LQ_DIST_NORM) ? lq_sqdist8(zr, cr, D) : lq_sqdist32(zr, cr, D);
-            float v = (dist == LQ_DIST_NORM) ? sqrtf(s) : s;
+            float v = (dist == LQ_DIST_NORM) ? lq_sqrt(s) : s;
             if (v < best) { best = v; bk = k; }
         }
         idx[n] = bk;
@@ -142,7 +142,7 @@ LQ_EXPORT void lq_ref_distances(const float* z, const float* C, float* out, int6
         for (int k = 0; k < K; ++k) {
             float s = (dist == LQ_DIST_NORM) ? lq_sqdist8(z + (size_t)n * D, C + (size_t)k * D, D)
                                              : lq_sqdist32(z + (size_t)n * D, C + (size_t)k * D, D);
-            out[(size_t)n * K + k] = (dist == LQ_DIST_NORM) ? sqrtf(s) : s;
+            out[(size_t)n * K + k] = (dist == LQ_DIST_NORM) ? lq_sqrt(s) : s;
         }
 }
 
