@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py -- actions tokenized / s (encode + quantize) on 1..8 MI355X.
+
+A "step" is one pass of the tokenizer hot path (LLFQVAE_V4.tokenize: encoder MLP -> Lipschitz
+latent layer -> nearest code -> z_latent gather + code-usage histogram) over one synthetic
+batch that is already resident in HBM.  Workload (BASELINE.json configs[1]): B=4096, T=128,
+A=7, codebook K=1024 x D=64, fp32 everywhere (the parity mode: indices are bit-identical to
+the CPU oracle).  With N GPUs every rank tokenizes its own B x T batch (weak scaling, rows are
+independent) and the per-step code-usage histogram [K] int64 is all-reduced over RCCL -- the
+path's only cross-GPU dependency.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      dominant kernel (nearest code search): algorithmic 2*K*D flop per row / the
+                kernel's mean duration measured with HIP events on its own stream, against the
+                157.3 TFLOP/s fp32 peak (vector = fp32-MFMA on gfx950).
+  cpu_baseline  the torch-CPU restatement of the reference (oracle/lipvq_oracle.py,
+                kind="port"), timed on a bounded row sample on this box's host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # name: (B, T, A, D, K)
+    "cfg2": (4096, 128, 7, 64, 1024),
+    "cfg3": (4096, 128, 7, 128, 8192),
+    "cfg1": (64, 16, 7, 32, 256),
+}
+PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 vector = fp32-input MFMA peak
+PEAK_HBM_GBS = 8000.0
+
+
+def trained_like_(model, A, seed=0):
+    """Put a freshly constructed LLFQVAE_V4 into the trained-like regime of SURVEY.md 8d, using
+    the product path itself for the z_e samples (no oracle import on the measured path)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    K, D = model.num_codes, model.latent_dim
+    dev = model.quantizer.codebook.device
+    with torch.no_grad():
+        model.to_latent.ci.fill_(40.0)
+        model.to_latent.b.copy_(torch.randn(D, generator=g).to(dev))
+        cb = torch.rand(K, D, generator=g).to(dev)
+        xs = torch.randn(max(4 * K, 1024), A, generator=g).to(dev)
+        ze = model.encode(xs)
+        pick = torch.randperm(xs.shape[0], generator=g)[: K // 2].to(dev)
+        cb[: K // 2] = ze[pick] + 0.02 * torch.randn(K // 2, D, generator=g).to(dev)
+        model.quantizer.codebook.copy_(cb)
+
+
+def cpu_baseline(model, x_dev, idx_dev, budget_s=12.0):
+    """Time the torch-CPU restatement on a bounded sample of the same batch; check index parity."""
+    from oracle import lipvq_oracle as O
+    p = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    x = x_dev.cpu()
+    threads = torch.get_num_threads()
+    chunk = 256 if model.num_codes * model.latent_dim <= 1024 * 64 else 32
+    # calibrate on a small slice, then size the sample for ~budget_s of CPU work
+    n0 = 4 * chunk
+    t = time.perf_counter()
+    O.torch_llfq_tokenize(p, x[:n0], chunk=chunk)
+    rate0 = n0 / (time.perf_counter() - t)
+    n = int(min(x.shape[0], max(n0, (rate0 * budget_s) // chunk * chunk)))
+    t = time.perf_counter()
+    idx_cpu, _ = O.torch_llfq_tokenize(p, x[:n], chunk=chunk)
+    dt = time.perf_counter() - t
+    mism = int((idx_cpu != idx_dev[:n].cpu()).sum())
+    return {
+        "value": n / dt, "unit": "actions/s", "cores": threads, "kind": "port",
+        "sample": f"first {n} rows of the same batch, torch-CPU restatement, {chunk}-row chunks, {dt:.1f} s",
+        "host_cpus": os.cpu_count(), "index_mismatches_vs_gpu": mism, "rows_compared": n,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+
+    import lipvq_vae_amd  # noqa: F401  (fails loudly if the HIP library is missing)
+    from lipvq_vae_amd import ops
+    from lipvq_vae_amd.tokenizer import LLFQVAE_V4
+
+    B, T, A, D, K = WORKLOADS[args.workload]
+    N = B * T
+    torch.manual_seed(0)
+    model = LLFQVAE_V4(A, D, num_codes=K).to(dev)
+    trained_like_(model, A, seed=0)
+    gx = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    x = torch.randn(B, T, A, generator=gx).to(dev).reshape(N, A)     # flattened as tensor_utils.py:1066-1067 does
+
+    codebook = model.quantizer.codebook.detach()
+    usage = model.code_usage
+    ev_pairs = []
+
+    def step(timed):
+        # == LLFQVAE_V4.tokenize, with HIP events around the dominant kernel on its own stream
+        z_e = model.encode(x)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        idx, zq, _ = ops.nearest(z_e, codebook, ops.DIST_NORM, usage=usage)
+        if timed:
+            e1.record()
+            ev_pairs.append((e0, e1))
+        if dist is not None:
+            dist.all_reduce(usage)          # global code-usage histogram (8 KiB for K=1024)
+        return idx, zq
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        usage.zero_()
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        usage.zero_()
+        idx, zq = step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    near_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / max(1, len(ev_pairs))
+    value = world * N * args.steps / elapsed
+    algo_flop = 2.0 * N * K * D                       # 2*K*D per row for the distance term
+    achieved = algo_flop / (near_ms * 1e-3) / 1e12 if near_ms > 0 else 0.0
+    out = {
+        "metric": "actions tokenized/sec (encode+quantize) at B=4096 T=128 K=1024, 1/2/4/8 GPU",
+        "value": value, "unit": "actions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: B={B} T={T} action_dim={A} codebook K={K} d={D}, "
+                               f"fp32 encoder + fp32 argmin (parity mode), per-GPU batch fixed",
+                   "rows_per_gpu": N, "parallelism": f"batch-sharded x{world}, all-reduce of code usage [K] int64"},
+        "roofline": {"bound": "mfma", "kernel": "nearest_direct_kernel", "achieved": achieved,
+                     "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
+                     "traffic": None, "ms_per_launch": near_ms,
+                     "algorithmic_flop_per_launch": algo_flop},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(model, x, idx)
+        out["gpu_vs_cpu"] = value / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,124 @@
+"""torch.autograd.Function wrappers: the reference's forward()/backward() contract on the HIP path.
+
+Forward value flow (LLFQVAE_V4, reference backbone_lfqvae_v5.py:70-84):
+    x --mlp3(gelu,gelu,sigmoid; W2 = Lipschitz-normalised)--> z_e --nearest--> (idx, z_q)
+    z_q --mlp3(gelu,gelu,none; input gathered from the codebook)--> x_recon
+    loss = mse(x_recon,x) + 0.25*mse(z_q.detach(),z_e) + 0.25*mse(z_q,z_e.detach())
+Gradient routing (no straight-through estimator in this variant):
+    recon     -> to_output, decoder, codebook (through the gather)
+    codebook  -> codebook
+    commit    -> to_latent.{W,b,ci}, encoder
+The two latent mse terms have the same VALUE; the library computes it once.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .ops import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, DIST_NORM, DIST_SQSUM
+
+_ENC_ACTS = (ACT_GELU, ACT_GELU, ACT_SIGMOID)
+_DEC_ACTS = (ACT_GELU, ACT_GELU, ACT_NONE)
+_RELU3 = (ACT_RELU, ACT_RELU, ACT_RELU)
+
+
+class _LLFQFn(torch.autograd.Function):
+    """(z_latent, loss) = f(x, 14 parameters).  z_latent is non-differentiable (v5:74)."""
+
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        enc_packed, scale, Wn = module._packed_encoder()
+        dec_packed = module._packed_decoder()
+        codebook = module.quantizer.codebook.detach()
+        need_grad = any(ctx.needs_input_grad[2:])
+        if need_grad:
+            z_e, pre_e = ops.mlp3(x, enc_packed, _ENC_ACTS, save_pre=True)
+        else:
+            z_e, pre_e = ops.mlp3(x, enc_packed, _ENC_ACTS), None
+        idx, z_q, _ = ops.nearest(z_e, codebook, DIST_NORM, usage=module.code_usage)
+        if need_grad:
+            x_rec, pre_d = ops.mlp3(codebook, dec_packed, _DEC_ACTS, gather_idx=idx, save_pre=True)
+        else:
+            x_rec, pre_d = ops.mlp3(codebook, dec_packed, _DEC_ACTS, gather_idx=idx), None
+        mse = ops.mse_pair(x_rec, x, z_q, z_e)
+        q = mse[1] * 0.25
+        loss = (mse[0] + q) + q          # recon + 0.25*commit + 0.25*codebook, left to right (v5:83)
+        module.last_indices = idx
+        ctx.module = module
+        if need_grad:
+            ctx.save_for_backward(x, z_e, z_q, idx, x_rec, Wn, scale, *pre_e, *pre_d)
+        ctx.mark_non_differentiable(z_q)
+        return z_q, loss
+
+    @staticmethod
+    def backward(ctx, _g_latent, g_loss):
+        from .backward import llfq_backward
+        grads = llfq_backward(ctx.module, ctx.saved_tensors, g_loss)
+        return (None, None) + tuple(grads)
+
+
+def llfq_forward(module, x):
+    params = (*module._enc_params(), module.quantizer.codebook, *module._dec_params())
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        z_latent, loss = _LLFQFn.apply(module, x, *params)
+    else:
+        with torch.no_grad():
+            z_latent, loss = _LLFQFn.forward(_NoCtx(len(params)), module, x, *params)
+    return z_latent, loss
+
+
+class _NoCtx:
+    """Stand-in for the autograd context on the no-grad path (rollouts, tokenisation)."""
+
+    def __init__(self, n):
+        self.needs_input_grad = (False,) * (n + 2)
+
+    def save_for_backward(self, *a):
+        pass
+
+    def mark_non_differentiable(self, *a):
+        pass
+
+
+class _VQFn(torch.autograd.Function):
+    """(z_latent, loss) of the plain VQVAE (reference backbone.py:38-76)."""
+
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        enc_packed = module._packed_encoder()
+        dec_packed = module._packed_decoder()
+        E = module.embedding.weight.detach()
+        need_grad = any(ctx.needs_input_grad[2:])
+        if need_grad:
+            z_e, pre_e = ops.mlp3(x, enc_packed, _RELU3, save_pre=True)
+        else:
+            z_e, pre_e = ops.mlp3(x, enc_packed, _RELU3), None
+        idx, z_q, _ = ops.nearest(z_e, E, DIST_SQSUM, usage=module.code_usage)
+        z_st = ops.ste(z_e, z_q)                                   # vq:74
+        if need_grad:
+            x_rec, pre_d = ops.mlp3(z_st, dec_packed, _RELU3, save_pre=True)
+        else:
+            x_rec, pre_d = ops.mlp3(z_st, dec_packed, _RELU3), None
+        mse = ops.mse_pair(x_rec, x, z_q, z_e)
+        q_loss = mse[1] + module.commitment_cost * mse[1]          # vq:69-71
+        loss = mse[0] + q_loss                                     # vq:50-51
+        module.last_indices = idx
+        ctx.module = module
+        if need_grad:
+            ctx.save_for_backward(x, z_e, z_q, z_st, idx, x_rec, *pre_e, *pre_d)
+        ctx.mark_non_differentiable(z_st)
+        return z_st, loss
+
+    @staticmethod
+    def backward(ctx, _g_latent, g_loss):
+        from .backward import vq_backward
+        grads = vq_backward(ctx.module, ctx.saved_tensors, g_loss)
+        return (None, None) + tuple(grads)
+
+
+def vq_forward(module, x):
+    params = (*module._enc_params(), *module._dec_params(), module.embedding.weight)
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        return _VQFn.apply(module, x, *params)
+    with torch.no_grad():
+        return _VQFn.forward(_NoCtx(len(params)), module, x, *params)

@@ -1,0 +1,214 @@
+"""Drop-in replacements for the reference's action tokenizers, running on the HIP library.
+
+``LLFQVAE_V4``  mirrors robomimic/models/vq_vae/backbone_lfqvae_v5.py:51-84 (the paper's
+                LipVQ-VAE): same constructor signature and defaults, same 14 ``state_dict``
+                keys/shapes/dtypes, same RNG consumption at construction (so the same
+                ``torch.manual_seed`` gives the same initial weights), and
+                ``forward(x[N,A]) -> (z_latent[N,D] without grad, loss 0-dim with grad_fn)``.
+``VQVAE``       mirrors robomimic/models/vq_vae/backbone.py:6-76 (ReLU stacks, squared-L2
+                argmin, commitment 0.25, straight-through estimator).
+
+The ``nn.Linear`` / container sub-modules exist only to own the parameters under the
+reference's names; they are never called.  All arithmetic is issued through
+``lipvq_vae_amd.ops`` (C ABI -> hand-written gfx950 kernels).  Gradients are produced by the
+library's backward kernels through one ``torch.autograd.Function`` per variant, so
+``loss.backward(); AdamW.step()`` in the ICRT loop (robomimic/algo/icl.py:885-889,968-970)
+works unchanged.
+
+Extras that the reference does not have (allowed by SURVEY.md section 8b): ``last_indices``,
+``code_usage`` (int64 [K], accumulated over forwards), ``tokenize()`` (encode + quantize
+only: the BASELINE metric's path) and ``perplexity()``.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, DIST_NORM, DIST_SQSUM
+
+__all__ = ["LLFQVAE_V4", "VQVAE", "LipschitzMLP", "LFQQuantizer"]
+
+
+class _PackCache:
+    """Re-lays weights out for the MFMA kernels only when a parameter changed (an optimizer
+    step bumps ``Tensor._version``; ``.to()``/``load_state_dict`` change data_ptr/version)."""
+
+    def __init__(self):
+        self._key = None
+        self._val = None
+
+    def get(self, tensors, build):
+        key = tuple((t.data_ptr(), t._version, t.device) for t in tensors)
+        if key != self._key:
+            self._val = build()
+            self._key = key
+        return self._val
+
+
+class LipschitzMLP(nn.Module):
+    """Parameter holder of the Lipschitz latent layer (reference v5:15-24): W ~ N(0,1), b = 0, ci = 1."""
+
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.W = nn.Parameter(torch.randn(out_dim, in_dim))
+        self.b = nn.Parameter(torch.zeros(out_dim))
+        self.ci = nn.Parameter(torch.ones(out_dim))
+
+    def normalized_weight(self):
+        """(scale[D], W_norm[D,H]) = normalization(W, ci) of v5:6-12, computed on the GPU."""
+        return ops.lipschitz_scale(self.W.detach(), self.ci.detach())
+
+
+class LFQQuantizer(nn.Module):
+    """Parameter holder of the codebook (reference v5:27-35): randn then kaiming_uniform_."""
+
+    def __init__(self, num_codes, code_dim):
+        super().__init__()
+        self.num_codes = num_codes
+        self.code_dim = code_dim
+        self.codebook = nn.Parameter(torch.randn(num_codes, code_dim))
+        nn.init.kaiming_uniform_(self.codebook)
+
+    def forward(self, z_e):
+        """(z_q, indices) of v5:37-48 for callers that use the quantizer on its own (no grad)."""
+        idx, zq, _ = ops.nearest(z_e.detach(), self.codebook.detach(), DIST_NORM)
+        return zq, idx
+
+
+class _TokenizerBase(nn.Module):
+    def _init_extras(self, K):
+        self.register_buffer("code_usage", torch.zeros(K, dtype=torch.int64), persistent=False)
+        self.last_indices = None
+        self._enc_cache = _PackCache()
+        self._dec_cache = _PackCache()
+
+    def reset_usage(self):
+        self.code_usage.zero_()
+
+    def perplexity(self):
+        """exp(entropy) of the accumulated code-usage histogram."""
+        c = self.code_usage.to(torch.float64)
+        p = c / c.sum().clamp_min(1)
+        nz = p > 0
+        return float(torch.exp(-(p[nz] * p[nz].log()).sum()))
+
+    @staticmethod
+    def _as_rows(x):
+        if x.dim() != 2:
+            raise ValueError(f"expected [N, feature_dim] (the reference flattens [B,T,A] to [B*T,A] "
+                             f"before the tokenizer, tensor_utils.py:1066-1067); got {tuple(x.shape)}")
+        if x.dtype != torch.float32:
+            raise TypeError(f"expected float32 actions, got {x.dtype}")
+        return x.contiguous()
+
+
+class LLFQVAE_V4(_TokenizerBase):
+    def __init__(self, feature_dim, latent_dim, num_codes=1024, hidden_dim=128):
+        super().__init__()
+        if hidden_dim % 32 or not (32 <= hidden_dim <= 96 or hidden_dim == 128):
+            raise ValueError("hidden_dim must be 32, 64, 96 or 128 on the MI355X path")
+        # construction order = the reference's (v5:54-68), so RNG draws line up
+        self.encoder = nn.Sequential(nn.Linear(feature_dim, 64), nn.GELU(), nn.Linear(64, hidden_dim), nn.GELU())
+        self.to_latent = LipschitzMLP(hidden_dim, latent_dim)
+        self.quantizer = LFQQuantizer(num_codes, latent_dim)
+        self.decoder = nn.Sequential(nn.Linear(latent_dim, 64), nn.GELU(), nn.Linear(64, hidden_dim), nn.GELU())
+        self.to_output = nn.Linear(hidden_dim, feature_dim)
+        self.feature_dim, self.latent_dim, self.num_codes, self.hidden_dim = feature_dim, latent_dim, num_codes, hidden_dim
+        self._init_extras(num_codes)
+
+    # -- packed weights ---------------------------------------------------------------------
+    def _enc_params(self):
+        return (self.encoder[0].weight, self.encoder[0].bias, self.encoder[2].weight, self.encoder[2].bias,
+                self.to_latent.W, self.to_latent.b, self.to_latent.ci)
+
+    def _dec_params(self):
+        return (self.decoder[0].weight, self.decoder[0].bias, self.decoder[2].weight, self.decoder[2].bias,
+                self.to_output.weight, self.to_output.bias)
+
+    def _packed_encoder(self):
+        def build():
+            w0, b0, w1, b1, W, b, ci = (t.detach() for t in self._enc_params())
+            scale, Wn = ops.lipschitz_scale(W, ci)
+            return ops.mlp3_pack(w0, b0, w1, b1, Wn, b), scale, Wn
+        return self._enc_cache.get(self._enc_params(), build)
+
+    def _packed_decoder(self):
+        def build():
+            return ops.mlp3_pack(*(t.detach() for t in self._dec_params()))
+        return self._dec_cache.get(self._dec_params(), build)
+
+    # -- the metric's path ------------------------------------------------------------------
+    @torch.no_grad()
+    def encode(self, x):
+        """z_e = to_latent(encoder(x))   (v5:71-72)."""
+        packed, _, _ = self._packed_encoder()
+        return ops.mlp3(self._as_rows(x), packed, (ACT_GELU, ACT_GELU, ACT_SIGMOID))
+
+    @torch.no_grad()
+    def tokenize(self, x, count_usage=True):
+        """encode + quantize: (indices[N] int64, z_latent[N,D])   (v5:71-74)."""
+        z_e = self.encode(x)
+        idx, zq, _ = ops.nearest(z_e, self.quantizer.codebook.detach(), DIST_NORM,
+                                 usage=self.code_usage if count_usage else None)
+        self.last_indices = idx
+        return idx, zq
+
+    @torch.no_grad()
+    def decode(self, indices):
+        """x_recon = to_output(decoder(codebook[indices]))   (v5:75-76)."""
+        return ops.mlp3(self.quantizer.codebook.detach(), self._packed_decoder(), (ACT_GELU, ACT_GELU, ACT_NONE),
+                        gather_idx=indices)
+
+    # -- reference forward ------------------------------------------------------------------
+    def forward(self, x):
+        from .autograd import llfq_forward
+        return llfq_forward(self, self._as_rows(x))
+
+
+class VQVAE(_TokenizerBase):
+    def __init__(self, feature_dim, latent_dim, num_embeddings=128, commitment_cost=0.25):
+        super().__init__()
+        self.feature_dim = feature_dim
+        self.latent_dim = latent_dim
+        self.num_embeddings = num_embeddings
+        self.commitment_cost = commitment_cost
+        self.encoder = nn.Sequential(nn.Linear(feature_dim, 64), nn.ReLU(), nn.Linear(64, 128), nn.ReLU(),
+                                     nn.Linear(128, latent_dim), nn.ReLU())
+        self.decoder = nn.Sequential(nn.Linear(latent_dim, 128), nn.ReLU(), nn.Linear(128, 64), nn.ReLU(),
+                                     nn.Linear(64, feature_dim), nn.ReLU())
+        self.embedding = nn.Embedding(num_embeddings, latent_dim)
+        self.embedding.weight.data.uniform_(-1 / num_embeddings, 1 / num_embeddings)
+        self._init_extras(num_embeddings)
+
+    def _enc_params(self):
+        e = self.encoder
+        return (e[0].weight, e[0].bias, e[2].weight, e[2].bias, e[4].weight, e[4].bias)
+
+    def _dec_params(self):
+        d = self.decoder
+        return (d[0].weight, d[0].bias, d[2].weight, d[2].bias, d[4].weight, d[4].bias)
+
+    def _packed_encoder(self):
+        return self._enc_cache.get(self._enc_params(),
+                                   lambda: ops.mlp3_pack(*(t.detach() for t in self._enc_params())))
+
+    def _packed_decoder(self):
+        return self._dec_cache.get(self._dec_params(),
+                                   lambda: ops.mlp3_pack(*(t.detach() for t in self._dec_params())))
+
+    @torch.no_grad()
+    def encode(self, x):
+        return ops.mlp3(self._as_rows(x), self._packed_encoder(), (ACT_RELU, ACT_RELU, ACT_RELU))
+
+    @torch.no_grad()
+    def tokenize(self, x, count_usage=True):
+        z_e = self.encode(x)
+        idx, zq, _ = ops.nearest(z_e, self.embedding.weight.detach(), DIST_SQSUM,
+                                 usage=self.code_usage if count_usage else None)
+        self.last_indices = idx
+        return idx, ops.ste(z_e, zq)
+
+    def forward(self, x):
+        from .autograd import vq_forward
+        return vq_forward(self, self._as_rows(x))
