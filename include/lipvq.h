@@ -87,6 +87,44 @@ size_t lipvq_mse_workspace_bytes(void);
 int lipvq_mse_pair_f32(const float* xr, const float* x, int64_t nx, const float* zq, const float* ze,
                        int64_t nz, float* out2, void* workspace, void* stream);
 
+
+/* ---- backward (what autograd derives from v5:70-84 / vq:38-76) --------------------------- */
+
+/* Backward-data of lipvq_mlp3_f32.  gy [N][J2] = dL/dy.  pre0/pre1/pre2 are the saved
+ * pre-activations (pre2 may be NULL when act2 is the identity).  packed_bwd holds the transposed
+ * weights (lipvq_mlp3_pack_bwd_f32; lipvq_mlp3_packed_bwd_floats() floats).  Outputs:
+ *   g2 [N][J2] = gy * act2'(pre2)      (may be NULL; equal to gy when act2 is the identity)
+ *   g1 [N][J1], g0 [N][J0]             dL/d(pre-activation) of layers 1 and 0
+ *   gx [N][K0] = dL/dx                 (may be NULL: the last GEMM is then skipped) */
+size_t lipvq_mlp3_packed_bwd_floats(int K0, int J0, int J1, int J2);
+int lipvq_mlp3_pack_bwd_f32(const float* W0, const float* W1, const float* W2, float* packed, int K0,
+                            int J0, int J1, int J2, void* stream);
+int lipvq_mlp3_bwd_f32(const float* gy, const float* pre0, const float* pre1, const float* pre2,
+                       const float* packed_bwd, float* g2, float* g1, float* g0, float* gx, int64_t N,
+                       int K0, int J0, int J1, int J2, int act0, int act1, int act2, void* stream);
+
+/* Weight/bias gradient of one Linear layer:  gW [J][Kd] = G^T . act(H),  gb [J] = column sums of G.
+ * G [N][J] = dL/d(pre-activation); H [N][Kd] = the layer's input, given as a saved pre-activation
+ * plus the activation code h_act to re-apply (LIPVQ_ACT_NONE for raw inputs), or, with hidx,
+ * rows H[hidx[n]] of a table (the codebook gather).  workspace: lipvq_wgrad_workspace_bytes(). */
+size_t lipvq_wgrad_workspace_bytes(int64_t N, int J, int Kd);
+int lipvq_wgrad_f32(const float* G, const float* H, const int64_t* hidx, int h_act, float* gW, float* gb,
+                    void* workspace, int64_t N, int J, int Kd, void* stream);
+
+/* Codebook gradient: gC[idx[n]] += g[n]  (the index_add_ behind v5:47 / vq:66).  gC [K][D] must be
+ * zeroed by the caller.  Uses float atomics: the last bits may differ between runs. */
+int lipvq_scatter_add_f32(const float* g, const int64_t* idx, float* gC, int64_t N, int K, int D,
+                          void* stream);
+
+/* Backward of lipvq_lipschitz_scale_f32: gWn [D][H] -> gW [D][H], gci [D]. */
+int lipvq_lipschitz_bwd_f32(const float* W, const float* ci, const float* gWn, float* gW, float* gci, int D,
+                            int H, void* stream);
+
+/* out = alpha * (gscale ? *gscale : 1) * (a - b) + (c ? c : 0): the d mse / d input terms of
+ * v5:79-81 with the upstream gradient of the loss read from device memory (no host sync). */
+int lipvq_scaled_diff_f32(const float* a, const float* b, const float* c, float alpha, const float* gscale,
+                          float* out, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,11 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
+# torch ships its own libamdhip64; it must be mapped BEFORE our library so that the loader binds
+# our NEEDED libamdhip64.so.7 to that same runtime (one HIP runtime per process: device pointers
+# and streams handed over by PyTorch are only meaningful to the runtime that created them).
+import torch  # noqa: F401  (import order matters)
+
 _LIB_PATH = Path(__file__).resolve().parent / "_lipvq_hip.so"
 
 ACT_NONE, ACT_GELU, ACT_SIGMOID, ACT_RELU = 0, 1, 2, 3
@@ -32,6 +37,14 @@ SIGNATURES = {
     "lipvq_ste_f32": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "lipvq_mse_workspace_bytes": (_sz, []),
     "lipvq_mse_pair_f32": (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "lipvq_mlp3_packed_bwd_floats": (_sz, [_i, _i, _i, _i]),
+    "lipvq_mlp3_pack_bwd_f32": (_i, [_vp] * 4 + [_i] * 4 + [_vp]),
+    "lipvq_mlp3_bwd_f32": (_i, [_vp] * 9 + [_i64] + [_i] * 7 + [_vp]),
+    "lipvq_wgrad_workspace_bytes": (_sz, [_i64, _i, _i]),
+    "lipvq_wgrad_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "lipvq_scatter_add_f32": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "lipvq_lipschitz_bwd_f32": (_i, [_vp] * 5 + [_i, _i, _vp]),
+    "lipvq_scaled_diff_f32": (_i, [_vp, _vp, _vp, C.c_float, _vp, _vp, _i64, _vp]),
 }
 
 

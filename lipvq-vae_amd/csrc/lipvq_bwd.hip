@@ -1,0 +1,169 @@
+// lipvq_bwd.hip -- the parameter-gradient side of the tokenizer's backward pass (what autograd
+// derives from reference backbone_lfqvae_v5.py:70-84 / backbone.py:38-76):
+//   wgrad_kernel          gW = G^T . H and gb = sum_rows G  (contraction over the batch rows, fp32 MFMA,
+//                         split over row chunks into partial slabs)
+//   wgrad_reduce_kernel   deterministic sum of the slabs (double)
+//   scatter_add_kernel    codebook gradient: index_add_ of the gather's backward
+//   lipschitz_bwd_kernel  backward of normalization() (v5:6-12)
+//   scaled_diff_kernel    out = alpha * g * (a - b) + c   (the d mse / d input terms)
+// ABI: include/lipvq.h.
+#include "lipvq_common.h"
+
+#define WGRAD_ROWS_PER_CHUNK 2048
+
+// One wave = one 32x32 tile of gW over one chunk of rows.
+//   A operand: lane (i = lane & 31, kh = lane >> 5) = G[row0 + 2s + kh][32 ti + i]
+//   B operand: lane (j = lane & 31, kh)             = act(H[row0 + 2s + kh][32 tj + j])
+//   D[i][j]  : col j = lane & 31, row i = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+__global__ __launch_bounds__(64) void wgrad_kernel(const float* __restrict__ G, const float* __restrict__ H,
+                                                   const int64_t* __restrict__ hidx, int h_act,
+                                                   float* __restrict__ partW, float* __restrict__ partB,
+                                                   int64_t N, int J, int Kd, int TJ) {
+    const int lane = threadIdx.x;
+    const int li = lane & 31, kh = lane >> 5;
+    const int ti = blockIdx.y / TJ, tj = blockIdx.y % TJ;
+    const int fi = 32 * ti + li, fj = 32 * tj + li;
+    const int64_t r0 = (int64_t)blockIdx.x * WGRAD_ROWS_PER_CHUNK;
+    int64_t r1 = r0 + WGRAD_ROWS_PER_CHUNK;
+    if (r1 > N) r1 = N;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    float bsum = 0.0f;
+    const bool ai = fi < J, bj = fj < Kd;
+#pragma unroll 4
+    for (int64_t row = r0 + kh; row < r1 + kh; row += 2) {
+        const bool in = row < r1;
+        float av = 0.0f, bv = 0.0f;
+        if (in && ai) av = G[(size_t)row * J + fi];
+        if (in && bj) {
+            const int64_t hr = hidx ? hidx[row] : row;
+            bv = lq_act_apply(H[(size_t)hr * Kd + fj], h_act);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        bsum += av;
+    }
+    float* pw = partW + (size_t)blockIdx.x * J * Kd;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int oi = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (oi < J && bj) pw[(size_t)oi * Kd + fj] = acc[r];
+    }
+    if (tj == 0) {
+        const float tot = bsum + __shfl_xor(bsum, 32, 64);
+        if (kh == 0 && ai) partB[(size_t)blockIdx.x * J + fi] = tot;
+    }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nchunks,
+                                    size_t n_elem) {
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_elem) return;
+    double s = 0.0;
+    for (int c = 0; c < nchunks; ++c) s += (double)part[(size_t)c * n_elem + e];
+    out[e] = (float)s;
+}
+
+static inline int wgrad_chunks(int64_t N) { return (int)((N + WGRAD_ROWS_PER_CHUNK - 1) / WGRAD_ROWS_PER_CHUNK); }
+
+extern "C" size_t lipvq_wgrad_workspace_bytes(int64_t N, int J, int Kd) {
+    if (N <= 0 || J <= 0 || Kd <= 0) return 0;
+    return (size_t)wgrad_chunks(N) * ((size_t)J * Kd + J) * sizeof(float);
+}
+
+// gW [J][Kd] = G^T . act(H),  gb [J] = column sums of G.   G [N][J];  H [N][Kd] or, with hidx,
+// row n of H is H[hidx[n]].  h_act is applied to H elements on load (the forward activation of
+// a saved pre-activation).  gb may be NULL.
+extern "C" int lipvq_wgrad_f32(const float* G, const float* H, const int64_t* hidx, int h_act, float* gW,
+                               float* gb, void* workspace, int64_t N, int J, int Kd, void* stream) {
+    if (!G || !H || !gW || !workspace || N <= 0 || J <= 0 || Kd <= 0) return fail(LIPVQ_EINVAL, "wgrad: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = wgrad_chunks(N);
+    const int TI = (J + 31) / 32, TJ = (Kd + 31) / 32;
+    float* partW = (float*)workspace;
+    float* partB = partW + (size_t)nch * J * Kd;
+    hipLaunchKernelGGL(wgrad_kernel, dim3(nch, TI * TJ), dim3(64), 0, st, G, H, hidx, h_act, partW, partB, N, J, Kd, TJ);
+    size_t ne = (size_t)J * Kd;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, partW, gW, nch, ne);
+    if (gb)
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((J + 255) / 256)), dim3(256), 0, st, partB, gb, nch, (size_t)J);
+    return check_launch("wgrad");
+}
+
+// gC[idx[n]][d] += g[n][d].  Float atomics (global_atomic_add_f32): the sum order, hence the last
+// bits, can differ between runs; tests compare with 1e-5.  gC must be zeroed by the caller.
+__global__ void scatter_add_kernel(const float* __restrict__ g, const int64_t* __restrict__ idx,
+                                   float* __restrict__ gC, int64_t N, int D) {
+    const size_t n_elem = (size_t)N * D;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_elem; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = e / D;
+        const int d = (int)(e - n * D);
+        atomicAdd(&gC[(size_t)idx[n] * D + d], g[e]);
+    }
+}
+
+extern "C" int lipvq_scatter_add_f32(const float* g, const int64_t* idx, float* gC, int64_t N, int K, int D,
+                                     void* stream) {
+    if (!g || !idx || !gC || N < 0 || K <= 0 || D <= 0) return fail(LIPVQ_EINVAL, "scatter_add: bad argument");
+    if (N == 0) return LIPVQ_OK;
+    size_t ne = (size_t)N * D;
+    size_t blocks = (ne + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(scatter_add_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, idx, gC, N, D);
+    return check_launch("scatter_add");
+}
+
+// Backward of  Wn = W * sc,  sc = min(1, softplus(ci)/sum|W|)   (v5:6-12).  One thread per row.
+__global__ void lipschitz_bwd_kernel(const float* __restrict__ W, const float* __restrict__ ci,
+                                     const float* __restrict__ gWn, float* __restrict__ gW,
+                                     float* __restrict__ gci, int D, int H) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D) return;
+    const float* w = W + (size_t)i * H;
+    const float* g = gWn + (size_t)i * H;
+    double s = 0.0, gsc = 0.0;
+    float s32 = 0.0f;
+    for (int j = 0; j < H; ++j) {
+        s += fabs((double)w[j]);
+        s32 = s32 + lq_abs(w[j]);
+        gsc += (double)g[j] * (double)w[j];
+    }
+    const float spf = lq_softplus(ci[i]);
+    const bool active = (spf / s32) < 1.0f;        // the same test the forward kernel makes
+    const double sp = (double)spf;
+    const double sc = active ? sp / s : 1.0;
+    const double k = active ? gsc * (-sp / (s * s)) : 0.0;
+    for (int j = 0; j < H; ++j) {
+        const double wj = (double)w[j];
+        gW[(size_t)i * H + j] = (float)((double)g[j] * sc + k * ((wj > 0) - (wj < 0)));
+    }
+    gci[i] = active ? (float)(gsc * (double)lq_sigmoid(ci[i]) / s) : 0.0f;
+}
+
+extern "C" int lipvq_lipschitz_bwd_f32(const float* W, const float* ci, const float* gWn, float* gW, float* gci,
+                                       int D, int H, void* stream) {
+    if (!W || !ci || !gWn || !gW || !gci || D <= 0 || H <= 0) return fail(LIPVQ_EINVAL, "lipschitz_bwd: bad argument");
+    hipLaunchKernelGGL(lipschitz_bwd_kernel, dim3((D + 63) / 64), dim3(64), 0, (hipStream_t)stream, W, ci, gWn, gW, gci, D, H);
+    return check_launch("lipschitz_bwd");
+}
+
+// out = alpha * (gscale ? *gscale : 1) * (a - b) + (c ? c : 0)
+__global__ void scaled_diff_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                   const float* __restrict__ c, float alpha, const float* __restrict__ gscale,
+                                   float* __restrict__ out, int64_t n) {
+    const float f = gscale ? alpha * gscale[0] : alpha;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = f * (a[i] - b[i]);
+        out[i] = c ? v + c[i] : v;
+    }
+}
+
+extern "C" int lipvq_scaled_diff_f32(const float* a, const float* b, const float* c, float alpha,
+                                     const float* gscale, float* out, int64_t n, void* stream) {
+    if (!a || !b || !out || n < 0) return fail(LIPVQ_EINVAL, "scaled_diff: bad argument");
+    if (n == 0) return LIPVQ_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(scaled_diff_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, c, alpha, gscale, out, n);
+    return check_launch("scaled_diff");
+}

@@ -1,0 +1,39 @@
+// lipvq_common.h -- shared by every translation unit of the gfx950 tokenizer library.
+#ifndef LIPVQ_COMMON_H_
+#define LIPVQ_COMMON_H_
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/lipvq.h"
+#include "lipvq_math.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// error plumbing (defined in lipvq_misc.hip)
+int lipvq_fail(int code, const char* fmt, ...);
+int lipvq_check_launch(const char* what);
+#define fail lipvq_fail
+#define check_launch lipvq_check_launch
+
+__host__ __device__ static inline float lq_act_apply(float v, int act) {
+    switch (act) {
+        case LIPVQ_ACT_GELU: return lq_gelu(v);
+        case LIPVQ_ACT_SIGMOID: return lq_sigmoid(v);
+        case LIPVQ_ACT_RELU: return v > 0.0f ? v : 0.0f;
+        default: return v;
+    }
+}
+
+// d act(v) / d v evaluated at the pre-activation v
+__host__ __device__ static inline float lq_act_grad(float v, int act) {
+    switch (act) {
+        case LIPVQ_ACT_GELU: return lq_gelu_grad(v);
+        case LIPVQ_ACT_SIGMOID: { const float s = lq_sigmoid(v); return s * (1.0f - s); }
+        case LIPVQ_ACT_RELU: return v > 0.0f ? 1.0f : 0.0f;
+        default: return 1.0f;
+    }
+}
+#endif

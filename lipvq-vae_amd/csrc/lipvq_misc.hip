@@ -1,0 +1,130 @@
+// lipvq_misc.hip -- error plumbing, Lipschitz normalisation, straight-through value, mse reductions
+// ABI and reference citations: include/lipvq.h.  Arithmetic contract: lipvq_math.h.
+#include "lipvq_common.h"
+
+#undef fail
+#undef check_launch
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+int lipvq_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int lipvq_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return lipvq_fail(LIPVQ_EHIP, "%s: %s", what, hipGetErrorString(e));
+    return LIPVQ_OK;
+}
+
+extern "C" int lipvq_abi_version(void) { return LIPVQ_ABI_VERSION; }
+extern "C" const char* lipvq_last_error(void) { return g_err; }
+
+#define fail lipvq_fail
+#define check_launch lipvq_check_launch
+
+// ------------------------------------------------------------------------------------------
+// v5:6-12  Lipschitz normalisation
+// ------------------------------------------------------------------------------------------
+__global__ void lipschitz_scale_kernel(const float* __restrict__ W, const float* __restrict__ ci,
+                                       float* __restrict__ scale, float* __restrict__ Wn, int D,
+                                       int H) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D) return;
+    const float* w = W + (size_t)i * H;
+    float s = 0.0f;
+    for (int j = 0; j < H; ++j) s = s + lq_abs(w[j]);
+    float sc = lq_softplus(ci[i]) / s;
+    if (!(sc < 1.0f)) sc = 1.0f;
+    if (scale) scale[i] = sc;
+    if (Wn)
+        for (int j = 0; j < H; ++j) Wn[(size_t)i * H + j] = w[j] * sc;
+}
+
+extern "C" int lipvq_lipschitz_scale_f32(const float* W, const float* ci, float* scale, float* Wn,
+                                         int D, int H, void* stream) {
+    if (!W || !ci || D <= 0 || H <= 0) return fail(LIPVQ_EINVAL, "lipschitz_scale: bad argument");
+    hipLaunchKernelGGL(lipschitz_scale_kernel, dim3((D + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                       W, ci, scale, Wn, D, H);
+    return check_launch("lipschitz_scale");
+}
+
+// ------------------------------------------------------------------------------------------
+// vq:74 straight-through value
+// ------------------------------------------------------------------------------------------
+__global__ void ste_kernel(const float* __restrict__ ze, const float* __restrict__ zq,
+                           float* __restrict__ out, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = ze[i] + (zq[i] - ze[i]);
+}
+
+extern "C" int lipvq_ste_f32(const float* ze, const float* zq, float* out, int64_t n_elem, void* stream) {
+    if (n_elem < 0) return fail(LIPVQ_EINVAL, "ste: n < 0");
+    if (n_elem == 0) return LIPVQ_OK;
+    if (!ze || !zq || !out) return fail(LIPVQ_EINVAL, "ste: null pointer");
+    int64_t blocks = (n_elem + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(ste_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ze, zq, out, n_elem);
+    return check_launch("ste");
+}
+
+// ------------------------------------------------------------------------------------------
+// F.mse_loss pair: deterministic two-pass reduction in double
+// ------------------------------------------------------------------------------------------
+#define MSE_BLOCKS 512
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (l == 0) sh[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          int64_t n, double* __restrict__ partial) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double d = (double)a[i] - (double)b[i];
+        acc += d * d;
+    }
+    const double t = block_sum(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void mse_final_kernel(const double* __restrict__ partial, int64_t nx, int64_t nz,
+                                                        float* __restrict__ out2) {
+    __shared__ double sh[4];
+    for (int which = 0; which < 2; ++which) {
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < MSE_BLOCKS; i += blockDim.x) acc += partial[which * MSE_BLOCKS + i];
+        const double t = block_sum(acc, sh);
+        if (threadIdx.x == 0) out2[which] = (float)(t / (double)(which == 0 ? nx : nz));
+    }
+}
+
+extern "C" size_t lipvq_mse_workspace_bytes(void) { return 2 * MSE_BLOCKS * sizeof(double); }
+
+extern "C" int lipvq_mse_pair_f32(const float* xr, const float* x, int64_t nx, const float* zq,
+                                  const float* ze, int64_t nz, float* out2, void* workspace, void* stream) {
+    if (!xr || !x || !zq || !ze || !out2 || !workspace || nx <= 0 || nz <= 0)
+        return fail(LIPVQ_EINVAL, "mse_pair: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    double* part = (double*)workspace;
+    hipLaunchKernelGGL(mse_partial_kernel, dim3(MSE_BLOCKS), dim3(256), 0, st, xr, x, nx, part);
+    hipLaunchKernelGGL(mse_partial_kernel, dim3(MSE_BLOCKS), dim3(256), 0, st, zq, ze, nz, part + MSE_BLOCKS);
+    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, st, part, nx, nz, out2);
+    return check_launch("mse_pair");
+}

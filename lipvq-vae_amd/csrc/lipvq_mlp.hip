@@ -1,0 +1,312 @@
+// lipvq_mlp.hip -- the three-layer perceptron stacks of the tokenizer, forward and backward-data,
+// as ONE fp32-MFMA kernel template (v_mfma_f32_32x32x2_f32) in which activations never leave
+// registers.  ABI and reference citations: include/lipvq.h.  Arithmetic: lipvq_math.h.
+//
+// Layout.  The layers are evaluated TRANSPOSED, Y^T = W . X^T, with the weights as the MFMA
+// A operand (32 output features x 2 k) and the activations as the B operand (2 k x 32 rows).
+// The 32x32 result tile then has the batch row on the lane (col = lane & 31) and 16 output
+// features in the lane's registers, which is exactly the B-operand shape of the next layer:
+// register r of lane-half h feeds k-step r with k = 2r + h.  Choosing the feature <-> tile-row
+// map  feature(i) = 2*((i & 3) + 4*(i >> 3)) + ((i >> 2) & 1)  makes that k order the natural
+// 0,1,2,... order, so every output is ONE k-ordered fmaf chain starting from the bias -- the
+// oracle's definition -- with no LDS round trip and no cross-lane traffic between layers.
+//
+// Backward-data reuses the same chain with the transposed weights (J2 -> J1 -> J0 -> K0, zero
+// biases): the "activation" after a layer becomes a multiplication by act'(saved pre-activation)
+// and the per-layer results g1, g0 are written out for the weight-gradient GEMMs (lipvq_bwd.hip).
+#include "lipvq_common.h"
+
+// ------------------------------------------------------------------------------------------
+// packing
+// ------------------------------------------------------------------------------------------
+__host__ __device__ static inline int feat_of_tile_row(int i) {
+    return 2 * ((i & 3) + 4 * (i >> 3)) + ((i >> 2) & 1);
+}
+
+struct PackedLayout {
+    int S0, S1, S2;      // k-steps per layer (k pairs)
+    int T0, T1, T2;      // 32-feature output tiles per layer
+    size_t oP0, oB0, oP1, oB1, oP2, oB2, total;   // offsets in floats
+};
+
+__host__ __device__ static inline PackedLayout packed_layout(int K0, int J0, int J1, int J2) {
+    PackedLayout L;
+    L.T0 = (J0 + 31) / 32; L.T1 = (J1 + 31) / 32; L.T2 = (J2 + 31) / 32;
+    L.S0 = (K0 + 1) / 2; L.S1 = 16 * L.T0; L.S2 = 16 * L.T1;
+    size_t o = 0;
+    L.oP0 = o; o += (size_t)L.T0 * L.S0 * 64;
+    L.oB0 = o; o += (size_t)L.T0 * 32;
+    L.oP1 = o; o += (size_t)L.T1 * L.S1 * 64;
+    L.oB1 = o; o += (size_t)L.T1 * 32;
+    L.oP2 = o; o += (size_t)L.T2 * L.S2 * 64;
+    L.oB2 = o; o += (size_t)L.T2 * 32;
+    L.total = o;
+    return L;
+}
+
+// P[(t*S + s)*64 + lane] = Wv[32t + feat(lane & 31)][2s + (lane >> 5)]   (0 outside), where the
+// virtual weight Wv[f][k] = W[f*sf + k*sk] (sf,sk select W or its transpose); J x K = its shape.
+__global__ void mlp3_pack_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                 float* __restrict__ P, float* __restrict__ B, int K, int J, int S,
+                                 int T, int sf, int sk) {
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t nP = (size_t)T * S * 64;
+    if (gid < nP) {
+        int lane = (int)(gid & 63);
+        size_t ts = gid >> 6;
+        int s = (int)(ts % S), t = (int)(ts / S);
+        int f = 32 * t + feat_of_tile_row(lane & 31);
+        int k = 2 * s + (lane >> 5);
+        P[gid] = (f < J && k < K) ? W[(size_t)f * sf + (size_t)k * sk] : 0.0f;
+    }
+    if (gid < (size_t)T * 32) B[gid] = (b && (int)gid < J) ? b[gid] : 0.0f;
+}
+
+extern "C" size_t lipvq_mlp3_packed_floats(int K0, int J0, int J1, int J2) {
+    if (K0 <= 0 || J0 <= 0 || J1 <= 0 || J2 <= 0) return 0;
+    return packed_layout(K0, J0, J1, J2).total;
+}
+
+static void pack_layer(const float* W, const float* b, float* packed, size_t oP, size_t oB, int K, int J,
+                       int S, int T, int sf, int sk, hipStream_t st) {
+    size_t n = (size_t)T * S * 64;
+    if (n < (size_t)T * 32) n = (size_t)T * 32;
+    hipLaunchKernelGGL(mlp3_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, b,
+                       packed + oP, packed + oB, K, J, S, T, sf, sk);
+}
+
+static int check_hidden(const char* who, int a, int b) {
+    if (a <= 0 || b <= 0 || (a & 31) || (b & 31) || a > 256 || b > 256)
+        return fail(LIPVQ_EUNSUPPORTED, "%s: hidden widths must be multiples of 32 in [32,256] (got %d,%d)", who, a, b);
+    return LIPVQ_OK;
+}
+
+extern "C" int lipvq_mlp3_pack_f32(const float* W0, const float* b0, const float* W1,
+                                   const float* b1, const float* W2, const float* b2, float* packed,
+                                   int K0, int J0, int J1, int J2, void* stream) {
+    if (!W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !packed) return fail(LIPVQ_EINVAL, "mlp3_pack: null pointer");
+    if (K0 <= 0 || J2 <= 0) return fail(LIPVQ_EINVAL, "mlp3_pack: bad sizes");
+    if (int e = check_hidden("mlp3_pack", J0, J1)) return e;
+    PackedLayout L = packed_layout(K0, J0, J1, J2);
+    hipStream_t st = (hipStream_t)stream;
+    pack_layer(W0, b0, packed, L.oP0, L.oB0, K0, J0, L.S0, L.T0, K0, 1, st);
+    pack_layer(W1, b1, packed, L.oP1, L.oB1, J0, J1, L.S1, L.T1, J0, 1, st);
+    pack_layer(W2, b2, packed, L.oP2, L.oB2, J1, J2, L.S2, L.T2, J1, 1, st);
+    return check_launch("mlp3_pack");
+}
+
+// Backward-data chain J2 -> J1 -> J0 -> K0 with W2^T, W1^T, W0^T and zero biases.
+extern "C" size_t lipvq_mlp3_packed_bwd_floats(int K0, int J0, int J1, int J2) {
+    if (K0 <= 0 || J0 <= 0 || J1 <= 0 || J2 <= 0) return 0;
+    return packed_layout(J2, J1, J0, K0).total;
+}
+
+extern "C" int lipvq_mlp3_pack_bwd_f32(const float* W0, const float* W1, const float* W2, float* packed,
+                                       int K0, int J0, int J1, int J2, void* stream) {
+    if (!W0 || !W1 || !W2 || !packed) return fail(LIPVQ_EINVAL, "mlp3_pack_bwd: null pointer");
+    if (K0 <= 0 || J2 <= 0) return fail(LIPVQ_EINVAL, "mlp3_pack_bwd: bad sizes");
+    if (int e = check_hidden("mlp3_pack_bwd", J0, J1)) return e;
+    PackedLayout L = packed_layout(J2, J1, J0, K0);
+    hipStream_t st = (hipStream_t)stream;
+    // layer 0': in J2, out J1, virtual weight [J1][J2] = W2^T : Wv[f][k] = W2[k][f] = W2[k*J1 + f]
+    pack_layer(W2, nullptr, packed, L.oP0, L.oB0, J2, J1, L.S0, L.T0, 1, J1, st);
+    pack_layer(W1, nullptr, packed, L.oP1, L.oB1, J1, J0, L.S1, L.T1, 1, J0, st);
+    pack_layer(W0, nullptr, packed, L.oP2, L.oB2, J0, K0, L.S2, L.T2, 1, K0, st);
+    return check_launch("mlp3_pack_bwd");
+}
+
+// ------------------------------------------------------------------------------------------
+// the fused three-layer kernel
+// ------------------------------------------------------------------------------------------
+struct Mlp3Args {
+    const float* x;              // fwd: input rows (or gather table); bwd: gy
+    const int64_t* gather_idx;
+    const float* packed;
+    float* y;                    // fwd: output; bwd: gx (NULL: skip the last layer)
+    float* out0;                 // fwd: pre0 save; bwd: g1 = (gy' W2) * act1'(pre1)
+    float* out1;                 // fwd: pre1 save; bwd: g0
+    float* out2;                 // fwd: pre2 save; bwd: g2 = gy * act2'(pre2)
+    const float* in_pre;         // bwd: pre2 (NULL when act2 is the identity)
+    const float* mul0;           // bwd: pre1
+    const float* mul1;           // bwd: pre0
+    int64_t N;
+    int K0, J0, J1, J2;          // widths of THIS chain (bwd: J2, J1, J0, K0 of the forward stack)
+    int act0, act1, act2, act_in;
+};
+
+template <int T0, int T1, bool BWD>
+__global__ __launch_bounds__(256) void mlp3_kernel(Mlp3Args a) {
+    const PackedLayout L = packed_layout(a.K0, a.J0, a.J1, a.J2);
+    const float* __restrict__ P0 = a.packed + L.oP0;
+    const float* __restrict__ B0 = a.packed + L.oB0;
+    const float* __restrict__ P1 = a.packed + L.oP1;
+    const float* __restrict__ B1 = a.packed + L.oB1;
+    const float* __restrict__ P2 = a.packed + L.oP2;
+    const float* __restrict__ B2 = a.packed + L.oB2;
+    const int lane = threadIdx.x & 63;
+    const int h = lane >> 5;
+    const int64_t ntiles = (a.N + 31) / 32;
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+
+    for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
+        const int64_t row = tile * 32 + (lane & 31);
+        const bool valid = row < a.N;
+        const int64_t rowc = valid ? row : a.N - 1;
+        const float* __restrict__ xr =
+            a.gather_idx ? a.x + (size_t)a.gather_idx[rowc] * a.K0 : a.x + (size_t)rowc * a.K0;
+
+        // ---- layer 0: K0 -> 32*T0 ------------------------------------------------------
+        f32x16 acc0[T0];
+#pragma unroll
+        for (int t = 0; t < T0; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[t][r] = B0[32 * t + 2 * r + h];
+        for (int s = 0; s < L.S0; ++s) {
+            const int k = 2 * s + h;
+            float bv = (k < a.K0) ? xr[k] : 0.0f;
+            if (BWD) {
+                if (a.in_pre && k < a.K0) bv = bv * lq_act_grad(a.in_pre[(size_t)rowc * a.K0 + k], a.act_in);
+                if (a.out2 && valid && k < a.K0) a.out2[(size_t)row * a.K0 + k] = bv;
+            }
+#pragma unroll
+            for (int t = 0; t < T0; ++t) {
+                const float av = P0[((size_t)t * L.S0 + s) * 64 + lane];
+                acc0[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc0[t], 0, 0, 0);
+            }
+        }
+        if (!BWD) {
+            if (a.out0 && valid) {
+#pragma unroll
+                for (int t = 0; t < T0; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a.out0[(size_t)row * a.J0 + 32 * t + 2 * r + h] = acc0[t][r];
+            }
+#pragma unroll
+            for (int t = 0; t < T0; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc0[t][r] = lq_act_apply(acc0[t][r], a.act0);
+        } else {
+#pragma unroll
+            for (int t = 0; t < T0; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const size_t o = (size_t)rowc * a.J0 + 32 * t + 2 * r + h;
+                    acc0[t][r] = acc0[t][r] * lq_act_grad(a.mul0[o], a.act0);
+                    if (valid) a.out0[o] = acc0[t][r];
+                }
+        }
+
+        // ---- layer 1: 32*T0 -> 32*T1 ---------------------------------------------------
+        f32x16 acc1[T1];
+#pragma unroll
+        for (int t = 0; t < T1; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[t][r] = B1[32 * t + 2 * r + h];
+#pragma unroll
+        for (int s = 0; s < 16 * T0; ++s) {
+            const float bv = acc0[s / 16][s % 16];
+#pragma unroll
+            for (int t = 0; t < T1; ++t) {
+                const float av = P1[((size_t)t * (16 * T0) + s) * 64 + lane];
+                acc1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc1[t], 0, 0, 0);
+            }
+        }
+        if (!BWD) {
+            if (a.out1 && valid) {
+#pragma unroll
+                for (int t = 0; t < T1; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a.out1[(size_t)row * a.J1 + 32 * t + 2 * r + h] = acc1[t][r];
+            }
+#pragma unroll
+            for (int t = 0; t < T1; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[t][r] = lq_act_apply(acc1[t][r], a.act1);
+        } else {
+#pragma unroll
+            for (int t = 0; t < T1; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const size_t o = (size_t)rowc * a.J1 + 32 * t + 2 * r + h;
+                    acc1[t][r] = acc1[t][r] * lq_act_grad(a.mul1[o], a.act1);
+                    if (valid) a.out1[o] = acc1[t][r];
+                }
+            if (!a.y) continue;      // wave-uniform: the caller does not need d/d(input)
+        }
+
+        // ---- layer 2: 32*T1 -> J2, one 32-feature output tile at a time -----------------
+        for (int t2 = 0; t2 < L.T2; ++t2) {
+            f32x16 acc2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[r] = B2[32 * t2 + 2 * r + h];
+            const float* __restrict__ P2t = P2 + (size_t)t2 * (16 * T1) * 64 + lane;
+#pragma unroll
+            for (int s = 0; s < 16 * T1; ++s) {
+                const float bv = acc1[s / 16][s % 16];
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(P2t[(size_t)s * 64], bv, acc2, 0, 0, 0);
+            }
+            if (valid) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = 32 * t2 + 2 * r + h;
+                    if (f < a.J2) {
+                        if (!BWD && a.out2) a.out2[(size_t)row * a.J2 + f] = acc2[r];
+                        a.y[(size_t)row * a.J2 + f] = BWD ? acc2[r] : lq_act_apply(acc2[r], a.act2);
+                    }
+                }
+            }
+        }
+    }
+}
+
+typedef void (*mlp3_fn)(Mlp3Args);
+
+template <bool BWD>
+static mlp3_fn mlp3_select(int T0, int T1) {
+#define LQ_CASE(a_, b_) if (T0 == a_ && T1 == b_) return mlp3_kernel<a_, b_, BWD>;
+    LQ_CASE(2, 4) LQ_CASE(4, 2)            // the reference's stacks: 64->128 and 128->64
+    LQ_CASE(1, 1) LQ_CASE(2, 1) LQ_CASE(1, 2) LQ_CASE(2, 2) LQ_CASE(2, 3) LQ_CASE(3, 2)   // hidden_dim 32, 64, 96
+#undef LQ_CASE
+    return nullptr;
+}
+
+static int launch_mlp3(mlp3_fn fn, const Mlp3Args& a, hipStream_t st, const char* what) {
+    int64_t ntiles = (a.N + 31) / 32;
+    int64_t blocks = (ntiles + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;        // grid-stride beyond 8 blocks per CU
+    hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    return check_launch(what);
+}
+
+extern "C" int lipvq_mlp3_f32(const float* x, const int64_t* gather_idx, const float* packed, float* y,
+                              float* pre0, float* pre1, float* pre2, int64_t N, int K0, int J0, int J1,
+                              int J2, int act0, int act1, int act2, void* stream) {
+    if (N < 0) return fail(LIPVQ_EINVAL, "mlp3: N < 0");
+    if (N == 0) return LIPVQ_OK;
+    if (!x || !packed || !y) return fail(LIPVQ_EINVAL, "mlp3: null pointer");
+    if (K0 <= 0 || J2 <= 0) return fail(LIPVQ_EINVAL, "mlp3: bad sizes");
+    if (int e = check_hidden("mlp3", J0, J1)) return e;
+    mlp3_fn fn = mlp3_select<false>(J0 / 32, J1 / 32);
+    if (!fn) return fail(LIPVQ_EUNSUPPORTED, "mlp3: no kernel instance for hidden widths %d,%d", J0, J1);
+    Mlp3Args a{x, gather_idx, packed, y, pre0, pre1, pre2, nullptr, nullptr, nullptr,
+               N, K0, J0, J1, J2, act0, act1, act2, LIPVQ_ACT_NONE};
+    return launch_mlp3(fn, a, (hipStream_t)stream, "mlp3");
+}
+
+extern "C" int lipvq_mlp3_bwd_f32(const float* gy, const float* pre0, const float* pre1, const float* pre2,
+                                  const float* packed_bwd, float* g2, float* g1, float* g0, float* gx,
+                                  int64_t N, int K0, int J0, int J1, int J2, int act0, int act1, int act2,
+                                  void* stream) {
+    if (N < 0) return fail(LIPVQ_EINVAL, "mlp3_bwd: N < 0");
+    if (N == 0) return LIPVQ_OK;
+    if (!gy || !pre0 || !pre1 || !packed_bwd || !g1 || !g0) return fail(LIPVQ_EINVAL, "mlp3_bwd: null pointer");
+    if (act2 != LIPVQ_ACT_NONE && !pre2) return fail(LIPVQ_EINVAL, "mlp3_bwd: pre2 required when act2 is not the identity");
+    if (K0 <= 0 || J2 <= 0) return fail(LIPVQ_EINVAL, "mlp3_bwd: bad sizes");
+    if (int e = check_hidden("mlp3_bwd", J0, J1)) return e;
+    mlp3_fn fn = mlp3_select<true>(J1 / 32, J0 / 32);
+    if (!fn) return fail(LIPVQ_EUNSUPPORTED, "mlp3_bwd: no kernel instance for hidden widths %d,%d", J0, J1);
+    Mlp3Args a{gy, nullptr, packed_bwd, gx, g1, g0, g2, (act2 != LIPVQ_ACT_NONE) ? pre2 : nullptr, pre1, pre0,
+               N, J2, J1, J0, K0, act1, act0, LIPVQ_ACT_NONE, act2};
+    return launch_mlp3(fn, a, (hipStream_t)stream, "mlp3_bwd");
+}

@@ -125,9 +125,99 @@ def ste(ze: torch.Tensor, zq: torch.Tensor) -> torch.Tensor:
 def mse_pair(xr, x, zq, ze) -> torch.Tensor:
     """tensor([mean((xr-x)^2), mean((zq-ze)^2)]) on the device."""
     xr, x, zq, ze = _chk(xr, "xr"), _chk(x, "x"), _chk(zq, "zq"), _chk(ze, "ze")
+    if x.numel() == 0 or ze.numel() == 0:        # F.mse_loss of an empty tensor is nan
+        return torch.full((2,), float("nan"), device=x.device, dtype=torch.float32)
     out = torch.empty(2, device=x.device, dtype=torch.float32)
     ws = torch.empty(lib.lipvq_mse_workspace_bytes(), device=x.device, dtype=torch.uint8)
     with torch.cuda.device(x.device):
         check(lib.lipvq_mse_pair_f32(_ptr(xr), _ptr(x), x.numel(), _ptr(zq), _ptr(ze), ze.numel(), _ptr(out),
                                      _ptr(ws), _stream()), "lipvq_mse_pair_f32")
+    return out
+
+
+# ---- backward ---------------------------------------------------------------------------------
+
+def mlp3_pack_bwd(W0, W1, W2) -> PackedMlp3:
+    """Transposed weights of a stack for the backward-data chain (J2 -> J1 -> J0 -> K0)."""
+    W0, W1, W2 = _chk(W0, "W0"), _chk(W1, "W1"), _chk(W2, "W2")
+    J0, K0 = W0.shape
+    J1, J2 = W1.shape[0], W2.shape[0]
+    n = lib.lipvq_mlp3_packed_bwd_floats(K0, J0, J1, J2)
+    buf = torch.empty(n, device=W0.device, dtype=torch.float32)
+    with torch.cuda.device(W0.device):
+        check(lib.lipvq_mlp3_pack_bwd_f32(_ptr(W0), _ptr(W1), _ptr(W2), _ptr(buf), K0, J0, J1, J2, _stream()),
+              "lipvq_mlp3_pack_bwd_f32")
+    return PackedMlp3(buf, K0, J0, J1, J2)
+
+
+def mlp3_bwd(gy, pre, packed_bwd: PackedMlp3, acts, want_gx=True):
+    """(g2, g1, g0, gx): dL/d(pre-activation) of the three layers and dL/d(input)."""
+    gy = _chk(gy, "gy")
+    pre0, pre1 = _chk(pre[0], "pre0"), _chk(pre[1], "pre1")
+    pre2 = _chk(pre[2], "pre2") if pre[2] is not None else None
+    p = packed_bwd
+    N = gy.shape[0]
+    dev = gy.device
+    ident = int(acts[2]) == ACT_NONE
+    g2 = gy if ident else torch.empty_like(gy)
+    g1 = torch.empty((N, p.J1), device=dev, dtype=torch.float32)
+    g0 = torch.empty((N, p.J0), device=dev, dtype=torch.float32)
+    gx = torch.empty((N, p.K0), device=dev, dtype=torch.float32) if want_gx else None
+    with torch.cuda.device(dev):
+        check(lib.lipvq_mlp3_bwd_f32(_ptr(gy), _ptr(pre0), _ptr(pre1), _ptr(pre2), _ptr(p.buf),
+                                     None if ident else _ptr(g2), _ptr(g1), _ptr(g0), _ptr(gx), N, p.K0, p.J0,
+                                     p.J1, p.J2, int(acts[0]), int(acts[1]), int(acts[2]), _stream()),
+              "lipvq_mlp3_bwd_f32")
+    return g2, g1, g0, gx
+
+
+def wgrad(G, H, h_act=ACT_NONE, hidx=None, want_bias=True):
+    """(gW[J,Kd], gb[J]) of one Linear layer; H is the layer input (saved pre-activation + h_act,
+    a raw tensor, or -- with hidx -- a table whose rows hidx select)."""
+    G, H = _chk(G, "G"), _chk(H, "H")
+    N, J = G.shape
+    Kd = H.shape[1]
+    if hidx is not None:
+        hidx = _chk(hidx, "hidx", torch.int64)
+    elif H.shape[0] != N:
+        raise ValueError("wgrad: G and H must have the same number of rows")
+    dev = G.device
+    gW = torch.empty((J, Kd), device=dev, dtype=torch.float32)
+    gb = torch.empty(J, device=dev, dtype=torch.float32) if want_bias else None
+    ws = torch.empty(lib.lipvq_wgrad_workspace_bytes(N, J, Kd), device=dev, dtype=torch.uint8)
+    with torch.cuda.device(dev):
+        check(lib.lipvq_wgrad_f32(_ptr(G), _ptr(H), _ptr(hidx), int(h_act), _ptr(gW), _ptr(gb), _ptr(ws), N, J, Kd,
+                                  _stream()), "lipvq_wgrad_f32")
+    return gW, gb
+
+
+def scatter_add(g, idx, K):
+    g, idx = _chk(g, "g"), _chk(idx, "idx", torch.int64)
+    N, D = g.shape
+    gC = torch.zeros((K, D), device=g.device, dtype=torch.float32)
+    with torch.cuda.device(g.device):
+        check(lib.lipvq_scatter_add_f32(_ptr(g), _ptr(idx), _ptr(gC), N, K, D, _stream()), "lipvq_scatter_add_f32")
+    return gC
+
+
+def lipschitz_bwd(W, ci, gWn):
+    W, ci, gWn = _chk(W, "W"), _chk(ci, "ci"), _chk(gWn, "gWn")
+    gW, gci = torch.empty_like(W), torch.empty_like(ci)
+    with torch.cuda.device(W.device):
+        check(lib.lipvq_lipschitz_bwd_f32(_ptr(W), _ptr(ci), _ptr(gWn), _ptr(gW), _ptr(gci), W.shape[0], W.shape[1],
+                                          _stream()), "lipvq_lipschitz_bwd_f32")
+    return gW, gci
+
+
+def scaled_diff(a, b, alpha, gscale=None, c=None):
+    """alpha * gscale * (a - b) + c, gscale a 0-dim/1-element device tensor (the upstream dL/dloss)."""
+    a, b = _chk(a, "a"), _chk(b, "b")
+    if c is not None:
+        c = _chk(c, "c")
+    if gscale is not None:
+        gscale = _chk(gscale.reshape(1), "gscale")
+    out = torch.empty_like(a)
+    with torch.cuda.device(a.device):
+        check(lib.lipvq_scaled_diff_f32(_ptr(a), _ptr(b), _ptr(c), float(alpha), _ptr(gscale), _ptr(out), a.numel(),
+                                        _stream()), "lipvq_scaled_diff_f32")
     return out

@@ -198,11 +198,14 @@ def run_nearest_edge(ref, name, D=64, K=96, N=160):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only-init", action="store_true")
     args = ap.parse_args()
     ref_root = Path(args.ref)
     v5 = load_ref(ref_root, "robomimic/models/vq_vae/backbone_lfqvae_v5.py", "_ref_v5")
     vq = load_ref(ref_root, "robomimic/models/vq_vae/backbone.py", "_ref_vq")
     GOLD.mkdir(parents=True, exist_ok=True)
+    if args.only_init:
+        return run_init(v5, vq)
     torch.set_num_threads(1)       # what the reference's train() sets (scripts/train.py:57)
     orc = O.CanonicalOracle()
     # BASELINE config 1 (CPU plumbing case), full fwd + bwd + AdamW
@@ -226,6 +229,20 @@ def main():
     run_vq(vq, "vq_main_trained", 202, 80, 12, 64, 512, oracle=orc)
     run_vq(vq, "vq_default_init", 203, 128, 7, 32, 128, regime="default", oracle=orc)
     run_nearest_edge(v5, "llfq_nearest_edge")
+    run_init(v5, vq)
+
+
+def run_init(v5, vq):
+    """Initial parameters the reference constructors draw under a fixed torch seed (drop-in check:
+    the replacement modules must consume the RNG identically)."""
+    torch.manual_seed(1234)
+    m = v5.LLFQVAE_V4(12, 48, num_codes=96)
+    out = {"llfq/" + k: v.numpy().copy() for k, v in m.state_dict().items()}
+    torch.manual_seed(4321)
+    m = vq.VQVAE(12, 48, num_embeddings=64)
+    out.update({"vq/" + k: v.numpy().copy() for k, v in m.state_dict().items()})
+    np.savez_compressed(GOLD / "init_seeded.npz", **out)
+    print("init_seeded: done")
 
 
 if __name__ == "__main__":

@@ -211,6 +211,51 @@ class CanonicalOracle:
                     recon_loss=recon, embedding_loss=emb, loss=float(loss), pre_enc=pre_e,
                     pre_dec=pre_d)
 
+    # -- whole-path gradients (double accumulation; compared with a tolerance) ----------------
+    def llfq_grads(self, p, x, fwd=None):
+        """dict of the 14 parameter gradients of loss (v5:83) for upstream gradient 1."""
+        f = fwd or self.llfq_forward(p, x)
+        x = _f32(x)
+        N, A = x.shape
+        ze, zq, idx = f["z_e"], f["z_q"], f["indices"]
+        D = ze.shape[1]
+        g_xrec = (2.0 / (N * A)) * (f["x_recon"].astype(np.float64) - x)
+        gd = self.mlp3_bwd(zq, p["decoder.0.weight"], p["decoder.2.weight"], p["to_output.weight"],
+                           f["pre_dec"], g_xrec.astype(np.float32), (ACT_GELU, ACT_GELU, ACT_NONE))
+        g_zq = gd["x"].astype(np.float64) + (0.5 / (N * D)) * (zq.astype(np.float64) - ze)
+        g_cb = self.scatter_add(g_zq.astype(np.float32), idx, p["quantizer.codebook"].shape[0])
+        g_ze = ((0.5 / (N * D)) * (ze.astype(np.float64) - zq)).astype(np.float32)
+        _, Wn = self.lipschitz_scale(p["to_latent.W"], p["to_latent.ci"])
+        ge = self.mlp3_bwd(x, p["encoder.0.weight"], p["encoder.2.weight"], Wn, f["pre_enc"], g_ze,
+                           (ACT_GELU, ACT_GELU, ACT_SIGMOID), want_gx=False)
+        gW, gci = self.lipschitz_bwd(p["to_latent.W"], p["to_latent.ci"], ge["W2"])
+        return {"encoder.0.weight": ge["W0"], "encoder.0.bias": ge["b0"], "encoder.2.weight": ge["W1"],
+                "encoder.2.bias": ge["b1"], "to_latent.W": gW, "to_latent.b": ge["b2"], "to_latent.ci": gci,
+                "quantizer.codebook": g_cb, "decoder.0.weight": gd["W0"], "decoder.0.bias": gd["b0"],
+                "decoder.2.weight": gd["W1"], "decoder.2.bias": gd["b1"], "to_output.weight": gd["W2"],
+                "to_output.bias": gd["b2"]}
+
+    def vq_grads(self, p, x, commitment_cost=0.25, fwd=None):
+        f = fwd or self.vq_forward(p, x, commitment_cost)
+        x = _f32(x)
+        N, A = x.shape
+        ze, zq, idx = f["z_e"], f["z_q"], f["indices"]
+        D = ze.shape[1]
+        R = (ACT_RELU, ACT_RELU, ACT_RELU)
+        g_xrec = ((2.0 / (N * A)) * (f["x_recon"].astype(np.float64) - x)).astype(np.float32)
+        gd = self.mlp3_bwd(f["z_latent"], p["decoder.0.weight"], p["decoder.2.weight"], p["decoder.4.weight"],
+                           f["pre_dec"], g_xrec, R)
+        g_emb = self.scatter_add(((2.0 / (N * D)) * (zq.astype(np.float64) - ze)).astype(np.float32), idx,
+                                 p["embedding.weight"].shape[0])
+        g_ze = (gd["x"].astype(np.float64) + (commitment_cost * 2.0 / (N * D)) * (ze.astype(np.float64) - zq))
+        ge = self.mlp3_bwd(x, p["encoder.0.weight"], p["encoder.2.weight"], p["encoder.4.weight"], f["pre_enc"],
+                           g_ze.astype(np.float32), R, want_gx=False)
+        out = {"embedding.weight": g_emb}
+        for i, k in ((0, "0"), (1, "2"), (2, "4")):
+            out[f"encoder.{k}.weight"], out[f"encoder.{k}.bias"] = ge[f"W{i}"], ge[f"b{i}"]
+            out[f"decoder.{k}.weight"], out[f"decoder.{k}.bias"] = gd[f"W{i}"], gd[f"b{i}"]
+        return out
+
 
 # ---------------------------------------------------------------------------------------------
 # torch-CPU restatement (same op sequence as the reference; bit-identical to it in-process)
