@@ -175,12 +175,14 @@ def run_nearest_edge(ref, name, D=64, K=96, N=160):
     for r in range(5, 69):
         a, b = rng.integers(0, K, 2)
         z[r] = (cb[a] * np.float32(0.5) + cb[b] * np.float32(0.5))
-    # sqrt-merge: two codes at squared distances s and nextafter(s) from one row
+    # sqrt-merge: code 51 is strictly closer in SQUARED distance than code 50 (s vs nextafter(s)), but
+    # both squares round to one fp32 square root, so torch.norm + argmin pick the LOWER index, 50.
     z[70] = 0.0
     cb[50] = 0.0
     cb[51] = 0.0
-    cb[51, 0] = np.float32(0.75)                       # s = 0.5625
-    cb[50, 0] = np.nextafter(np.float32(0.75), np.float32(1))   # slightly larger square, lower index
+    cb[51, 0] = np.float32(0.6)                          # s1 = fl(0.36)
+    cb[50, 0] = np.float32(0.6)
+    cb[50, 1] = np.float32(1.7263e-4)                    # adds ~1 ulp(s1): s2 = nextafter(s1)
     q = ref.LFQQuantizer(K, D)
     with torch.no_grad():
         q.codebook.copy_(torch.from_numpy(cb))
@@ -189,6 +191,8 @@ def run_nearest_edge(ref, name, D=64, K=96, N=160):
         m = torch.clamp((2 * torch.sign(zt) + 1).unsqueeze(1), max=1)
         dist = torch.norm(m * (zt.unsqueeze(1) - q.codebook.unsqueeze(0)), dim=-1)
     assert idx[0].item() == 7
+    sq = ((zt[70].unsqueeze(0) - q.codebook[50:52]) ** 2).sum(-1)
+    assert sq[0].item() > sq[1].item() and dist[70, 50].item() == dist[70, 51].item() and idx[70].item() == 50
     np.savez_compressed(GOLD / f"{name}.npz", meta=meta_of(name=name, variant="llfq-quantizer"),
                         z_e=z, codebook=cb, indices=idx.numpy().astype(np.int32), z_q=zq.numpy(),
                         distances=dist.numpy())
@@ -199,6 +203,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--only-init", action="store_true")
+    ap.add_argument("--only-edge", action="store_true")
     args = ap.parse_args()
     ref_root = Path(args.ref)
     v5 = load_ref(ref_root, "robomimic/models/vq_vae/backbone_lfqvae_v5.py", "_ref_v5")
@@ -206,6 +211,8 @@ def main():
     GOLD.mkdir(parents=True, exist_ok=True)
     if args.only_init:
         return run_init(v5, vq)
+    if args.only_edge:
+        return run_nearest_edge(v5, "llfq_nearest_edge")
     torch.set_num_threads(1)       # what the reference's train() sets (scripts/train.py:57)
     orc = O.CanonicalOracle()
     # BASELINE config 1 (CPU plumbing case), full fwd + bwd + AdamW

@@ -1,0 +1,121 @@
+"""CPU: pin the oracle against the golden vectors the REFERENCE produced (oracle/gen_golden.py).
+
+ - oracle.torch_* (the restatement bench.py times) must reproduce the reference's outputs: exactly when
+   torch build and CPU capability equal the fixture's, else within 1e-6;
+ - the canonical C oracle: indices identical (a mismatch is tolerated only on a row whose reference
+   top-2 distance gap is below fp32 noise), floats within 1e-5; its quantizer fed the reference's own
+   z_e must be EXACT (the distance arithmetic is torch's, bit for bit)."""
+import glob
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lipvq_oracle as O
+
+GOLD = Path(__file__).resolve().parent / "golden"
+TOL = 1e-5
+LLFQ = sorted(Path(p).stem for p in glob.glob(str(GOLD / "llfq_*.npz")) if "nearest_edge" not in p)
+VQ = sorted(Path(p).stem for p in glob.glob(str(GOLD / "vq_*.npz")))
+
+
+def _meta(g):
+    return dict(eval(str(g["meta"])))
+
+
+def _same_platform(g):
+    m = _meta(g)
+    return m["torch_version"] == torch.__version__ and m["cpu_capability"] == torch.backends.cpu.get_cpu_capability()
+
+
+def _check_indices(got, g):
+    ref = g["indices"].astype(np.int64)
+    bad = np.nonzero(got != ref)[0]
+    if bad.size:
+        gap = (g["d_second"][bad] - g["d_best"][bad]) / np.maximum(g["d_second"][bad], 1e-30)
+        assert (gap < 1e-5).all(), f"{bad.size} index mismatches that are not near-ties (gaps {gap})"
+
+
+def test_fixture_inventory():
+    assert len(LLFQ) >= 9 and len(VQ) >= 3 and (GOLD / "llfq_nearest_edge.npz").exists()
+
+
+@pytest.mark.parametrize("name", LLFQ)
+def test_llfq_oracles_vs_reference(name, oracle):
+    g = np.load(GOLD / f"{name}.npz")
+    m = _meta(g)
+    A, D, K, N = int(g["A"]), int(g["D"]), int(g["K"]), int(g["N"])
+    p = O.make_params(int(g["seed"]), A, D, K, regime=m["regime"], oracle=oracle)
+    assert O.params_digest(p) == str(g["params_sha256"])
+    x = O.make_inputs(int(g["seed"]), N, A, clamp=m["clamp"])
+    # canonical C oracle
+    r = oracle.llfq_forward(p, x)
+    assert np.abs(r["z_e"] - g["z_e"]).max() <= TOL
+    _check_indices(r["indices"], g)
+    idx2, _, _ = oracle.nearest(g["z_e"], p["quantizer.codebook"])
+    assert np.array_equal(idx2, g["indices"].astype(np.int64)), "quantizer on the reference's z_e must be exact"
+    assert np.array_equal(r["z_latent"], p["quantizer.codebook"][r["indices"]])
+    if "loss" in g.files:
+        assert np.abs(r["x_recon"] - g["x_recon"]).max() <= TOL
+        for k in ("recon_loss", "commitment_loss", "loss"):
+            assert abs(r[k] - float(g[k])) <= TOL * abs(float(g[k])), k
+    # torch-CPU restatement
+    torch.set_num_threads(1)
+    chunk = 256 if K * D <= 65536 else 32
+    idx_t, _ = O.torch_llfq_tokenize(O.to_torch(p), torch.from_numpy(x), chunk=chunk)
+    if _same_platform(g):
+        assert np.array_equal(idx_t.numpy(), g["indices"].astype(np.int64))
+    else:
+        _check_indices(idx_t.numpy(), g)
+    if m["full"]:
+        og = oracle.llfq_grads(p, x, fwd=r)
+        for k in O.LLFQ_KEYS:
+            ref = g["grad/" + k]
+            assert np.abs(og[k] - ref).max() <= TOL * max(np.abs(ref).max(), 1e-12), k
+        # restatement backward + AdamW (icl.py:887-889, 968-970) reproduces the reference's step
+        tp = {k: v.requires_grad_(True) for k, v in O.to_torch(p).items()}
+        opt = torch.optim.AdamW(list(tp.values()), lr=1e-3, weight_decay=1e-4)
+        _, loss, _ = O.torch_llfq_forward(tp, torch.from_numpy(x))
+        loss.backward()
+        opt.step()
+        for k in O.LLFQ_KEYS:
+            tol = 0 if _same_platform(g) else 1e-6
+            assert np.abs(tp[k].detach().numpy() - g["post/" + k]).max() <= tol, k
+
+
+@pytest.mark.parametrize("name", VQ)
+def test_vq_oracles_vs_reference(name, oracle):
+    g = np.load(GOLD / f"{name}.npz")
+    m = _meta(g)
+    A, D, K, N = int(g["A"]), int(g["D"]), int(g["K"]), int(g["N"])
+    p = O.make_params(int(g["seed"]), A, D, K, regime=m["regime"], variant="vq", oracle=oracle)
+    assert O.params_digest(p) == str(g["params_sha256"])
+    x = O.make_inputs(int(g["seed"]), N, A)
+    r = oracle.vq_forward(p, x)
+    _check_indices(r["indices"], g)
+    idx2, _, _ = oracle.nearest(g["z_e"], p["embedding.weight"], O.DIST_SQSUM)
+    assert np.array_equal(idx2, g["indices"].astype(np.int64))
+    assert np.abs(r["z_latent"] - g["z_latent"]).max() <= TOL
+    assert np.abs(r["x_recon"] - g["x_recon"]).max() <= TOL
+    assert abs(r["loss"] - float(g["loss"])) <= TOL * abs(float(g["loss"]))
+    og = oracle.vq_grads(p, x, fwd=r)
+    for k in O.VQ_KEYS:
+        ref = g["grad/" + k]
+        assert np.abs(og[k] - ref).max() <= TOL * max(np.abs(ref).max(), 1e-12), k
+    z_t, loss_t, _ = O.torch_vq_forward(O.to_torch(p), torch.from_numpy(x))
+    tol = 0 if _same_platform(g) else 1e-6
+    assert np.abs(z_t.numpy() - g["z_latent"]).max() <= tol
+
+
+def test_quantizer_edge_cases_exact(oracle):
+    """Duplicate codes, zero distance, sign mask, and two squares sharing one fp32 square root."""
+    g = np.load(GOLD / "llfq_nearest_edge.npz")
+    idx, zq, _ = oracle.nearest(g["z_e"], g["codebook"])
+    assert np.array_equal(idx, g["indices"].astype(np.int64))
+    assert np.array_equal(zq, g["z_q"])
+    assert np.array_equal(oracle.distances(g["z_e"], g["codebook"]), g["distances"]), "distances must be torch's, bitwise"
+    assert idx[0] == 7          # rows equal to duplicated codes 7/40/41 -> lowest index
+    assert idx[70] == 50        # sqrt merge: code 51 has the smaller square, but both share one fp32 root -> lower index
+    d = g["distances"]
+    assert d[70, 50] == d[70, 51]
