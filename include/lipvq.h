@@ -88,6 +88,25 @@ int lipvq_mse_pair_f32(const float* xr, const float* x, int64_t nx, const float*
                        int64_t nz, float* out2, void* workspace, void* stream);
 
 
+/* ---- nearest code, fast path: MFMA screening + exact re-scoring (same results as
+ *      lipvq_nearest_f32(.., LIPVQ_DIST_NORM); design: lipvq-vae_amd/csrc/lipvq_screen.hip) ------ */
+
+/* Per-codebook preparation (centred, fp16 hi/lo split, MFMA fragment order, |e|^2, bounds).
+ * Redo it whenever the codebook changes.  prep: lipvq_nearest_prep_bytes(K, D) bytes. */
+size_t lipvq_nearest_prep_bytes(int K, int D);
+int lipvq_nearest_prepare_f32(const float* codebook, void* prep, int K, int D, void* stream);
+int lipvq_nearest_screened_supported(int K, int D);          /* 1 for D in {32, 64, 128, 208} */
+size_t lipvq_nearest_workspace_bytes(int64_t N);
+/* idx / zq / usage exactly as lipvq_nearest_f32.  After the call the first int of `workspace`
+ * holds how many rows were decided by the exact kernel (the rest were certified by the screen). */
+int lipvq_nearest_screened_f32(const float* z, const float* codebook, const void* prep, int64_t* idx, float* zq,
+                               int64_t* usage, void* workspace, int64_t N, int K, int D, void* stream);
+/* Test hook: also dumps the approximate distances d~ [N][Kpad] (Kpad = K rounded up to 32) and takes
+ * the error-bound factor gamma from the caller. */
+int lipvq_screen_debug_f32(const float* z, const float* codebook, const void* prep, int64_t* idx, float* zq,
+                           int64_t* usage, void* workspace, float* dtilde, float gamma, int64_t N, int K, int D,
+                           void* stream);
+
 /* ---- backward (what autograd derives from v5:70-84 / vq:38-76) --------------------------- */
 
 /* Backward-data of lipvq_mlp3_f32.  gy [N][J2] = dL/dy.  pre0/pre1/pre2 are the saved

@@ -35,7 +35,7 @@ class _LLFQFn(torch.autograd.Function):
             z_e, pre_e = ops.mlp3(x, enc_packed, _ENC_ACTS, save_pre=True)
         else:
             z_e, pre_e = ops.mlp3(x, enc_packed, _ENC_ACTS), None
-        idx, z_q, _ = ops.nearest(z_e, codebook, DIST_NORM, usage=module.code_usage)
+        idx, z_q = module._quantize(z_e, module.code_usage)
         if need_grad:
             x_rec, pre_d = ops.mlp3(codebook, dec_packed, _DEC_ACTS, gather_idx=idx, save_pre=True)
         else:

@@ -1,0 +1,478 @@
+// lipvq_screen.hip -- nearest-code search, fast path: MFMA screening + exact re-scoring.
+// Replaces the same reference lines as lipvq_nearest.hip (v5:37-48) with the SAME results.
+//
+// Idea.  argmin_k |z - e_k| only needs the exact (torch-order, fp32) distance for codes that can
+// possibly win.  A cheap approximation  d~(n,k) = |e'_k|^2 - 2 z'_n . e'_k  (centred operands
+// z' = z - mu, e' = e - mu; the row constant |z'|^2 is dropped) is computed on the matrix cores:
+// every operand is split into two fp16 pieces (x = hi + lo, 22 significant bits) and three
+// products hi*hi + lo*hi + hi*lo are accumulated in fp32 by v_mfma_f32_32x32x16_f16.  Each lane
+// tracks, per row, the smallest and second smallest d~ it has seen and the code of the smallest.
+// If, after all codes, the second smallest exceeds the smallest by more than W_n = 2 eps_n (eps_n
+// bounds |d~ - d| for the row, see "error bound"), the approximate argmin IS the exact argmin in
+// real arithmetic with a margin that also covers the rounding of the reference's own fp32
+// distance, hence it is the reference's index.  Otherwise the row is appended to a list and the
+// exact kernel (nearest_rows_kernel: torch's 8-accumulator order, sqrt comparison, first-minimum
+// rule) decides it.  No row is ever decided by the approximation alone unless it is certified.
+//
+// Error bound.  |d~ - d| <= eps_n = gamma * (E2max + 2 |z'_n| Emax), with E2max = max_k |e'_k|^2,
+// Emax = max_k |e'_k|.  Analytically the fp16 split leaves 3 * 2^-22 * sum|z'e'| per dot product;
+// the fp32 accumulation inside the MFMA adds a few 2^-24 of the partial sums' magnitude.  gamma
+// (LIPVQ_SCREEN_GAMMA) is 2^-17, > 30x the largest error measured with lipvq_screen_debug_f32 over
+// 10^8 pairs (tests/test_gpu_screen.py::test_error_bound_holds asserts a 16x margin on every run).
+#include <hip/hip_fp16.h>
+
+#include "lipvq_common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+#define LIPVQ_SCREEN_GAMMA 7.62939453125e-06f   /* 2^-17 */
+#define SCREEN_WAVES 8
+
+struct PrepLayout {
+    int S, Dpad, Kpad, ntiles;
+    size_t o_hdr, o_mu, o_tiles, tile_bytes, total;
+};
+
+__host__ __device__ static inline PrepLayout prep_layout(int K, int D) {
+    PrepLayout L;
+    L.S = (D + 15) / 16;
+    L.Dpad = L.S * 16;
+    L.Kpad = ((K + 31) / 32) * 32;
+    L.ntiles = L.Kpad / 32;
+    L.o_hdr = 0;                       // 16 floats: [0] E2max bits, [1] Emax^2 bits, [2] max|2e'| bits
+    L.o_mu = 64;
+    L.o_tiles = L.o_mu + sizeof(float) * (size_t)L.Dpad;
+    L.o_tiles = (L.o_tiles + 255) & ~(size_t)255;
+    L.tile_bytes = (size_t)L.S * 2048 + 128;    // S steps x {hi,lo} x 32 codes x 2 halves x 16 B, then 32 x e2
+    L.total = L.o_tiles + (size_t)L.ntiles * L.tile_bytes;
+    return L;
+}
+
+extern "C" size_t lipvq_nearest_prep_bytes(int K, int D) {
+    if (K <= 0 || D <= 0) return 0;
+    return prep_layout(K, D).total;
+}
+
+// column means (double accumulation), one thread per dimension
+__global__ void prep_mean_kernel(const float* __restrict__ cb, float* __restrict__ mu, int K, int D, int Dpad) {
+    int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= Dpad) return;
+    double s = 0.0;
+    if (d < D)
+        for (int k = 0; k < K; ++k) s += (double)cb[(size_t)k * D + d];
+    mu[d] = (d < D) ? (float)(s / (double)K) : 0.0f;
+}
+
+// one thread per (code, step, half): 8 centred, -2-scaled elements -> fp16 hi/lo fragments
+__global__ void prep_frag_kernel(const float* __restrict__ cb, const float* __restrict__ mu,
+                                 unsigned char* __restrict__ tiles, int K, int D, PrepLayout L) {
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t n = (size_t)L.Kpad * L.S * 2;
+    if (gid >= n) return;
+    const int h = (int)(gid & 1);
+    const int s = (int)((gid >> 1) % L.S);
+    const int k = (int)(gid / (2 * (size_t)L.S));
+    f16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int d = 16 * s + 2 * j + h;
+        float v = 0.0f;
+        if (k < K && d < D) v = -2.0f * (cb[(size_t)k * D + d] - mu[d]);
+        const _Float16 vh = (_Float16)v;
+        hi[j] = vh;
+        lo[j] = (_Float16)(v - (float)vh);
+    }
+    unsigned char* t = tiles + (size_t)(k >> 5) * L.tile_bytes;
+    const int c = k & 31;
+    *reinterpret_cast<f16x8*>(t + (((size_t)s * 2 + 0) * 64 + h * 32 + c) * 16) = hi;   // lane = h*32 + c
+    *reinterpret_cast<f16x8*>(t + (((size_t)s * 2 + 1) * 64 + h * 32 + c) * 16) = lo;
+}
+
+// one thread per code: |e'|^2 (double), statistics for the error bound
+__global__ void prep_e2_kernel(const float* __restrict__ cb, const float* __restrict__ mu,
+                               unsigned char* __restrict__ tiles, unsigned* __restrict__ hdr, int K, int D,
+                               PrepLayout L) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= L.Kpad) return;
+    float* e2p = reinterpret_cast<float*>(tiles + (size_t)(k >> 5) * L.tile_bytes + (size_t)L.S * 2048) + (k & 31);
+    if (k >= K) { *e2p = INFINITY; return; }
+    double s = 0.0;
+    float mx = 0.0f;
+    for (int d = 0; d < D; ++d) {
+        const float v = cb[(size_t)k * D + d] - mu[d];
+        s += (double)v * (double)v;
+        mx = fmaxf(mx, fabsf(2.0f * v));
+    }
+    const float e2 = (float)s;
+    *e2p = e2;
+    atomicMax(&hdr[0], __float_as_uint(e2));          // non-negative floats order like their bit patterns
+    atomicMax(&hdr[1], __float_as_uint(e2));          // Emax^2 (same quantity; kept separate for clarity)
+    atomicMax(&hdr[2], __float_as_uint(mx));
+}
+
+extern "C" int lipvq_nearest_prepare_f32(const float* codebook, void* prep, int K, int D, void* stream) {
+    if (!codebook || !prep || K <= 0 || D <= 0) return fail(LIPVQ_EINVAL, "nearest_prepare: bad argument");
+    PrepLayout L = prep_layout(K, D);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char* base = (unsigned char*)prep;
+    hipError_t e = hipMemsetAsync(base, 0, 64, st);
+    if (e != hipSuccess) return fail(LIPVQ_EHIP, "nearest_prepare: %s", hipGetErrorString(e));
+    float* mu = (float*)(base + L.o_mu);
+    hipLaunchKernelGGL(prep_mean_kernel, dim3((L.Dpad + 63) / 64), dim3(64), 0, st, codebook, mu, K, D, L.Dpad);
+    size_t n = (size_t)L.Kpad * L.S * 2;
+    hipLaunchKernelGGL(prep_frag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, codebook, mu,
+                       base + L.o_tiles, K, D, L);
+    hipLaunchKernelGGL(prep_e2_kernel, dim3((L.Kpad + 255) / 256), dim3(256), 0, st, codebook, mu, base + L.o_tiles,
+                       (unsigned*)base, K, D, L);
+    return check_launch("nearest_prepare");
+}
+
+// ------------------------------------------------------------------------------------------
+// screening kernel: 8 waves x 32 rows per workgroup, codebook tiles double-buffered in LDS
+// ------------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
+    const float* __restrict__ z, const unsigned char* __restrict__ prep, const float* __restrict__ cb,
+    int64_t* __restrict__ idx, float* __restrict__ zq, unsigned long long* __restrict__ usage,
+    int* __restrict__ amb_list, int* __restrict__ amb_count, float* __restrict__ dbg, int64_t N, int K, int D,
+    float gamma) {
+    constexpr int TILE_BYTES = S * 2048 + 128;
+    constexpr int TC = (S <= 2) ? 8 : (S <= 4) ? 4 : (S <= 8) ? 2 : 1;      // column tiles per LDS stage
+    constexpr int STAGE_BYTES = TC * TILE_BYTES;
+    constexpr int STAGE_VEC = STAGE_BYTES / 16;
+    constexpr int NT = SCREEN_WAVES * 64;
+    constexpr int VPT = (STAGE_VEC + NT - 1) / NT;                            // 16-byte vectors per thread per stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const PrepLayout L = prep_layout(K, D);
+    const unsigned* hdr = reinterpret_cast<const unsigned*>(prep);
+    const float* mu = reinterpret_cast<const float*>(prep + L.o_mu);
+    const unsigned char* tiles = prep + L.o_tiles;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ln = lane & 31, h = lane >> 5;
+    const int64_t row0 = ((int64_t)blockIdx.x * SCREEN_WAVES + wave) * 32;
+    const int64_t row = row0 + ln;
+    const int64_t rowc = row < N ? row : N - 1;
+
+    // ---- this wave's 32 rows -> centred fp16 hi/lo A fragments --------------------------
+    f16x8 ah[S], al[S];
+    float n2 = 0.0f;
+    {
+        const float* zr = z + (size_t)rowc * D;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = 16 * s + 2 * j + h;
+                float v = 0.0f;
+                if (d < D) v = zr[d] - mu[d];
+                const _Float16 vh = (_Float16)v;
+                ah[s][j] = vh;
+                al[s][j] = (_Float16)(v - (float)vh);
+                n2 = lq_fma(v, v, n2);
+            }
+        }
+    }
+    n2 += __shfl_xor(n2, 32, 64);                         // |z'|^2 of row `ln`, in both halves
+
+    float m1[16], m2[16];
+    int k1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { m1[r] = INFINITY; m2[r] = INFINITY; k1[r] = 0; }
+
+    // ---- stream the prepared codebook through LDS ---------------------------------------
+    const int nstage = (L.ntiles + TC - 1) / TC;
+    uint4 pre[VPT];
+    auto stage_load = [&](int st) {
+        const uint4* src = reinterpret_cast<const uint4*>(tiles + (size_t)st * STAGE_BYTES);
+        const size_t avail = ((size_t)L.ntiles * TILE_BYTES - (size_t)st * STAGE_BYTES) / 16;
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            const int i = tid + v * NT;
+            pre[v] = (i < STAGE_VEC && (size_t)i < avail) ? src[i] : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto stage_store = [&](int buf) {
+        uint4* dst = reinterpret_cast<uint4*>(lds + (size_t)buf * STAGE_BYTES);
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            const int i = tid + v * NT;
+            if (i < STAGE_VEC) dst[i] = pre[v];
+        }
+    };
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    for (int st = 0; st < nstage; ++st) {
+        if (st + 1 < nstage) stage_load(st + 1);
+        const unsigned char* sb = lds + (size_t)(st & 1) * STAGE_BYTES;
+#pragma unroll
+        for (int c = 0; c < TC; ++c) {
+            const int ct = st * TC + c;
+            if (ct < L.ntiles) {                                  // uniform
+                const unsigned char* tb = sb + (size_t)c * TILE_BYTES;
+                const float e2 = reinterpret_cast<const float*>(tb + S * 2048)[ln];
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = e2;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const f16x8 bh = *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 0) * 64 + lane) * 16);
+                    const f16x8 bl = *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 1) * 64 + lane) * 16);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl, acc, 0, 0, 0);
+                }
+                const int code = ct * 32 + ln;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[r];
+                    if (dbg) {
+                        const int64_t rr = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (rr < N) dbg[(size_t)rr * L.Kpad + code] = v;
+                    }
+                    k1[r] = (v < m1[r]) ? code : k1[r];
+                    m2[r] = __builtin_amdgcn_fmed3f(v, m1[r], m2[r]);
+                    m1[r] = fminf(v, m1[r]);
+                }
+            }
+        }
+        if (st + 1 < nstage) stage_store((st + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- merge the 32 lanes of each half: global (min, argmin, second min) per row --------
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            const float om1 = __shfl_xor(m1[r], o, 64);
+            const float om2 = __shfl_xor(m2[r], o, 64);
+            const int ok1 = __shfl_xor(k1[r], o, 64);
+            const float hi = fmaxf(m1[r], om1);
+            m2[r] = fminf(fminf(m2[r], om2), hi);
+            const bool take = (om1 < m1[r]) || (om1 == m1[r] && ok1 < k1[r]);
+            k1[r] = take ? ok1 : k1[r];
+            m1[r] = fminf(m1[r], om1);
+        }
+    }
+    // hand row i's result to lane i (i < 32) through a small per-wave LDS scratch (after the last
+    // __syncthreads no wave touches the stage buffers again)
+    float* scr = reinterpret_cast<float*>(lds) + wave * 96;
+    if (ln == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+            scr[i] = m1[r];
+            scr[32 + i] = m2[r];
+            reinterpret_cast<int*>(scr)[64 + i] = k1[r];
+        }
+    }
+    __syncthreads();                              // every wave reaches this point (no early exit above)
+    int my_k = 0;
+    bool certified = false;
+    if (h == 0) {
+        const float a = scr[ln], b = scr[32 + ln];
+        my_k = reinterpret_cast<const int*>(scr)[64 + ln];
+        const float E2max = __uint_as_float(hdr[0]);
+        const float Emax = lq_sqrt(__uint_as_float(hdr[1]));
+        const float twoemax = __uint_as_float(hdr[2]);
+        const float cross = 2.0f * lq_sqrt(n2) * Emax;
+        // screening error + the rounding of the reference's own fp32 distance / square root (2^-20 of
+        // the largest full squared distance the row can see)
+        const float eps = gamma * (E2max + cross) + 9.5367431640625e-07f * (n2 + E2max + cross);
+        // fp16 range guard: -2e' must stay finite in fp16, else nothing is certified
+        certified = (twoemax < 60000.0f) && (b - a > 2.0f * eps) && (my_k < K);
+    }
+    // ---- outputs ---------------------------------------------------------------------------
+    if (h == 0 && row < N) {
+        if (certified) {
+            idx[row] = (int64_t)my_k;
+            if (usage) atomicAdd(&usage[my_k], 1ull);
+        } else {
+            const int slot = atomicAdd(amb_count, 1);
+            amb_list[slot] = (int)row;
+        }
+    }
+    if (zq) {
+        const int nvec = D / 4;
+        for (int rr = 0; rr < 32; rr += 4) {
+            const int src_lane = rr + (lane >> 4);
+            const int kk = __shfl(my_k, src_lane, 64);
+            const bool ok = __shfl((int)certified, src_lane, 64) != 0;
+            const int64_t orow = row0 + src_lane;
+            if (ok && orow < N) {
+                const float4* src = reinterpret_cast<const float4*>(cb + (size_t)kk * D);
+                float4* dst = reinterpret_cast<float4*>(zq + (size_t)orow * D);
+                for (int v = lane & 15; v < nvec; v += 16) dst[v] = src[v];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// exact decision for the listed rows: 16 rows x 16 code slices per workgroup
+// ------------------------------------------------------------------------------------------
+template <int DCH>
+__global__ __launch_bounds__(256) void nearest_rows_kernel(
+    const float* __restrict__ z, const float* __restrict__ cb, int64_t* __restrict__ idx, float* __restrict__ zq,
+    unsigned long long* __restrict__ usage, const int* __restrict__ row_list, const int* __restrict__ row_count,
+    int K) {
+    constexpr int D = DCH * 8;
+    __shared__ float s_v[16][16];
+    __shared__ float s_s[16][16];
+    __shared__ int s_k[16][16];
+    const int count = *row_count;
+    const int base = blockIdx.x * 16;
+    if (base >= count) return;
+    const int r = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int slot = base + r;
+    const bool valid = slot < count;
+    const int64_t row = row_list[valid ? slot : count - 1];
+    float zr[D];
+    {
+        const float4* z4 = reinterpret_cast<const float4*>(z + (size_t)row * D);
+#pragma unroll
+        for (int i = 0; i < D / 4; ++i) {
+            const float4 v = z4[i];
+            zr[4 * i + 0] = v.x; zr[4 * i + 1] = v.y; zr[4 * i + 2] = v.z; zr[4 * i + 3] = v.w;
+        }
+    }
+    const int per = (K + 15) / 16;
+    const int kb = sl * per, ke = (kb + per < K) ? kb + per : K;
+    float best_v = INFINITY, best_s = INFINITY;
+    int best_k = 0x7fffffff;
+    for (int k = kb; k < ke; ++k) {
+        const float4* c4 = reinterpret_cast<const float4*>(cb + (size_t)k * D);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+#pragma unroll
+        for (int i = 0; i < DCH; ++i) {
+            const float4 lo = c4[2 * i], hi = c4[2 * i + 1];
+            const float d0 = zr[8 * i + 0] - lo.x, d1 = zr[8 * i + 1] - lo.y;
+            const float d2 = zr[8 * i + 2] - lo.z, d3 = zr[8 * i + 3] - lo.w;
+            const float d4 = zr[8 * i + 4] - hi.x, d5 = zr[8 * i + 5] - hi.y;
+            const float d6 = zr[8 * i + 6] - hi.z, d7 = zr[8 * i + 7] - hi.w;
+            a0 = lq_fma(d0, d0, a0); a1 = lq_fma(d1, d1, a1);
+            a2 = lq_fma(d2, d2, a2); a3 = lq_fma(d3, d3, a3);
+            a4 = lq_fma(d4, d4, a4); a5 = lq_fma(d5, d5, a5);
+            a6 = lq_fma(d6, d6, a6); a7 = lq_fma(d7, d7, a7);
+        }
+        const float s = ((((((a0 + a1) + a2) + a3) + a4) + a5) + a6) + a7;
+        if (s < best_s) {
+            const float v = lq_sqrt(s);
+            if (v < best_v) { best_v = v; best_s = s; best_k = k; }
+        }
+    }
+    s_v[r][sl] = best_v; s_s[r][sl] = best_s; s_k[r][sl] = best_k;
+    __syncthreads();
+    if (sl == 0 && valid) {
+        // slices hold increasing code ranges: the first slice reaching the minimum root wins
+        float bv = s_v[r][0];
+        int bk = s_k[r][0];
+        for (int q = 1; q < 16; ++q)
+            if (s_v[r][q] < bv) { bv = s_v[r][q]; bk = s_k[r][q]; }
+        idx[row] = (int64_t)bk;
+        if (usage) atomicAdd(&usage[bk], 1ull);
+        s_k[r][0] = bk;
+    }
+    __syncthreads();
+    if (zq && valid) {
+        const int bk = s_k[r][0];
+        const float4* src = reinterpret_cast<const float4*>(cb + (size_t)bk * D);
+        float4* dst = reinterpret_cast<float4*>(zq + (size_t)row * D);
+        for (int v = sl; v < D / 4; v += 16) dst[v] = src[v];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+extern "C" size_t lipvq_nearest_workspace_bytes(int64_t N) {
+    if (N <= 0) return 0;
+    return 64 + sizeof(int) * (size_t)N;          // [0] ambiguous-row counter, then the row list
+}
+
+template <int S>
+static int launch_screen(const float* z, const unsigned char* prep, const float* cb, int64_t* idx, float* zq,
+                         int64_t* usage, int* amb_list, int* amb_count, float* dbg, int64_t N, int K, int D,
+                         float gamma, hipStream_t st) {
+    constexpr int TILE_BYTES = S * 2048 + 128;
+    constexpr int TC = (S <= 2) ? 8 : (S <= 4) ? 4 : (S <= 8) ? 2 : 1;
+    size_t lds = (size_t)2 * TC * TILE_BYTES;
+    if (lds < SCREEN_WAVES * 96 * sizeof(float)) lds = SCREEN_WAVES * 96 * sizeof(float);
+    const int64_t rows_per_block = SCREEN_WAVES * 32;
+    unsigned blocks = (unsigned)((N + rows_per_block - 1) / rows_per_block);
+    auto kfn = screen_kernel<S>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(LIPVQ_EHIP, "screen: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(SCREEN_WAVES * 64), lds, st, z, prep, cb, idx, zq,
+                       (unsigned long long*)usage, amb_list, amb_count, dbg, N, K, D, gamma);
+    return check_launch("screen");
+}
+
+template <int DCH>
+static int launch_rows(const float* z, const float* cb, int64_t* idx, float* zq, int64_t* usage,
+                       const int* amb_list, const int* amb_count, int64_t N, int K, hipStream_t st) {
+    // the count lives on the device: launch for the worst case, surplus workgroups exit at once
+    unsigned blocks = (unsigned)((N + 15) / 16);
+    hipLaunchKernelGGL((nearest_rows_kernel<DCH>), dim3(blocks), dim3(256), 0, st, z, cb, idx, zq,
+                       (unsigned long long*)usage, amb_list, amb_count, K);
+    return check_launch("nearest_rows");
+}
+
+static int screened_impl(const float* z, const float* cb, const void* prep, int64_t* idx, float* zq,
+                         int64_t* usage, void* workspace, float* dbg, int64_t N, int K, int D, float gamma,
+                         hipStream_t st) {
+    int* amb_count = (int*)workspace;
+    int* amb_list = (int*)((unsigned char*)workspace + 64);
+    hipError_t e = hipMemsetAsync(amb_count, 0, 64, st);
+    if (e != hipSuccess) return fail(LIPVQ_EHIP, "nearest_screened: %s", hipGetErrorString(e));
+    const unsigned char* p = (const unsigned char*)prep;
+    int rc;
+    switch (D) {
+        case 32: rc = launch_screen<2>(z, p, cb, idx, zq, usage, amb_list, amb_count, dbg, N, K, D, gamma, st); break;
+        case 64: rc = launch_screen<4>(z, p, cb, idx, zq, usage, amb_list, amb_count, dbg, N, K, D, gamma, st); break;
+        case 128: rc = launch_screen<8>(z, p, cb, idx, zq, usage, amb_list, amb_count, dbg, N, K, D, gamma, st); break;
+        case 208: rc = launch_screen<13>(z, p, cb, idx, zq, usage, amb_list, amb_count, dbg, N, K, D, gamma, st); break;
+        default: return fail(LIPVQ_EUNSUPPORTED, "nearest_screened: D=%d has no screening instance (32, 64, 128, 208)", D);
+    }
+    if (rc) return rc;
+    switch (D) {
+        case 32: return launch_rows<4>(z, cb, idx, zq, usage, amb_list, amb_count, N, K, st);
+        case 64: return launch_rows<8>(z, cb, idx, zq, usage, amb_list, amb_count, N, K, st);
+        case 128: return launch_rows<16>(z, cb, idx, zq, usage, amb_list, amb_count, N, K, st);
+        default: return launch_rows<26>(z, cb, idx, zq, usage, amb_list, amb_count, N, K, st);
+    }
+}
+
+extern "C" int lipvq_nearest_screened_supported(int K, int D) {
+    return (K > 0 && (D == 32 || D == 64 || D == 128 || D == 208)) ? 1 : 0;
+}
+
+// Same contract as lipvq_nearest_f32(.., LIPVQ_DIST_NORM) -- identical idx / zq / usage -- through the
+// screening fast path.  prep: lipvq_nearest_prepare_f32 of THIS codebook; workspace:
+// lipvq_nearest_workspace_bytes(N).  After the call workspace[0] (int) holds the number of rows
+// that needed the exact kernel.
+extern "C" int lipvq_nearest_screened_f32(const float* z, const float* codebook, const void* prep, int64_t* idx,
+                                          float* zq, int64_t* usage, void* workspace, int64_t N, int K, int D,
+                                          void* stream) {
+    if (N < 0 || K <= 0 || D <= 0) return fail(LIPVQ_EINVAL, "nearest_screened: bad sizes");
+    if (N == 0) return LIPVQ_OK;
+    if (!z || !codebook || !prep || !idx || !workspace) return fail(LIPVQ_EINVAL, "nearest_screened: null pointer");
+    if (N > 2147483647LL) return fail(LIPVQ_EUNSUPPORTED, "nearest_screened: N too large");
+    if ((((uintptr_t)z | (uintptr_t)codebook | (uintptr_t)zq) & 15) != 0)
+        return fail(LIPVQ_EINVAL, "nearest_screened: z, codebook and zq must be 16-byte aligned");
+    return screened_impl(z, codebook, prep, idx, zq, usage, workspace, nullptr, N, K, D, LIPVQ_SCREEN_GAMMA,
+                         (hipStream_t)stream);
+}
+
+// Test hook: also writes the approximate distances d~ [N][Kpad] and uses the caller's gamma
+// (gamma = 0 sends every row to the exact kernel; a huge gamma certifies nothing either).
+extern "C" int lipvq_screen_debug_f32(const float* z, const float* codebook, const void* prep, int64_t* idx,
+                                      float* zq, int64_t* usage, void* workspace, float* dtilde, float gamma,
+                                      int64_t N, int K, int D, void* stream) {
+    if (!z || !codebook || !prep || !idx || !workspace || N <= 0) return fail(LIPVQ_EINVAL, "screen_debug: bad argument");
+    if (!lipvq_nearest_screened_supported(K, D)) return fail(LIPVQ_EUNSUPPORTED, "screen_debug: unsupported D");
+    return screened_impl(z, codebook, prep, idx, zq, usage, workspace, dtilde, N, K, D, gamma, (hipStream_t)stream);
+}

@@ -221,3 +221,64 @@ def scaled_diff(a, b, alpha, gscale=None, c=None):
         check(lib.lipvq_scaled_diff_f32(_ptr(a), _ptr(b), _ptr(c), float(alpha), _ptr(gscale), _ptr(out), a.numel(),
                                         _stream()), "lipvq_scaled_diff_f32")
     return out
+
+
+# ---- nearest code, screened fast path ------------------------------------------------------------
+
+class PreparedCodebook:
+    """Per-codebook data of the MFMA screen (lipvq_nearest_prepare_f32); rebuild when the codebook changes."""
+
+    __slots__ = ("buf", "K", "D")
+
+    def __init__(self, buf, K, D):
+        self.buf, self.K, self.D = buf, K, D
+
+
+def nearest_screen_supported(K: int, D: int) -> bool:
+    return bool(lib.lipvq_nearest_screened_supported(int(K), int(D)))
+
+
+def nearest_prepare(codebook: torch.Tensor) -> PreparedCodebook:
+    codebook = _chk(codebook, "codebook")
+    K, D = codebook.shape
+    buf = torch.empty(lib.lipvq_nearest_prep_bytes(K, D), device=codebook.device, dtype=torch.uint8)
+    with torch.cuda.device(codebook.device):
+        check(lib.lipvq_nearest_prepare_f32(_ptr(codebook), _ptr(buf), K, D, _stream()), "lipvq_nearest_prepare_f32")
+    return PreparedCodebook(buf, K, D)
+
+
+def nearest_screened(z, codebook, prep: PreparedCodebook, usage=None, want_zq=True, return_workspace=False,
+                     debug_gamma=None):
+    """Same results as nearest(z, codebook, DIST_NORM), via MFMA screening + exact re-scoring of the
+    rows the screen cannot certify.  With return_workspace the int32 workspace is returned too
+    (element 0 = number of rows decided by the exact kernel).  debug_gamma: test hook, returns the
+    approximate distance matrix as well."""
+    z, codebook = _chk(z, "z"), _chk(codebook, "codebook")
+    N, D = z.shape
+    K = codebook.shape[0]
+    if (prep.K, prep.D) != (K, D) or codebook.shape[1] != D:
+        raise ValueError("nearest_screened: prepared codebook does not match")
+    if usage is not None:
+        usage = _chk(usage, "usage", torch.int64)
+    dev = z.device
+    idx = torch.empty(N, device=dev, dtype=torch.int64)
+    zq = torch.empty_like(z) if want_zq else None
+    ws = torch.empty(max(16, lib.lipvq_nearest_workspace_bytes(N) // 4), device=dev, dtype=torch.int32)
+    dt = None
+    with torch.cuda.device(dev):
+        if debug_gamma is None:
+            check(lib.lipvq_nearest_screened_f32(_ptr(z), _ptr(codebook), _ptr(prep.buf), _ptr(idx), _ptr(zq),
+                                                 _ptr(usage), _ptr(ws), N, K, D, _stream()),
+                  "lipvq_nearest_screened_f32")
+        else:
+            kpad = (K + 31) // 32 * 32
+            dt = torch.empty((N, kpad), device=dev, dtype=torch.float32)
+            check(lib.lipvq_screen_debug_f32(_ptr(z), _ptr(codebook), _ptr(prep.buf), _ptr(idx), _ptr(zq),
+                                             _ptr(usage), _ptr(ws), _ptr(dt), float(debug_gamma), N, K, D,
+                                             _stream()), "lipvq_screen_debug_f32")
+    out = (idx, zq)
+    if return_workspace:
+        out = out + (ws,)
+    if debug_gamma is not None:
+        out = out + (dt,)
+    return out

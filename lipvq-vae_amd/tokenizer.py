@@ -82,6 +82,8 @@ class _TokenizerBase(nn.Module):
         self.last_indices = None
         self._enc_cache = _PackCache()
         self._dec_cache = _PackCache()
+        self._cb_cache = _PackCache()
+        self.last_exact_rows = None      # int32 device tensor: element 0 = rows the screen could not certify
 
     def reset_usage(self):
         self.code_usage.zero_()
@@ -138,6 +140,18 @@ class LLFQVAE_V4(_TokenizerBase):
             return ops.mlp3_pack(*(t.detach() for t in self._dec_params()))
         return self._dec_cache.get(self._dec_params(), build)
 
+    def _quantize(self, z_e, usage):
+        """(idx, z_q) of v5:37-48: MFMA screen + exact re-scoring where the latent width has a
+        screening instance, the all-pairs exact kernel otherwise.  Identical results either way."""
+        cb = self.quantizer.codebook.detach()
+        if ops.nearest_screen_supported(cb.shape[0], cb.shape[1]) and z_e.shape[0] > 0:
+            prep = self._cb_cache.get((self.quantizer.codebook,), lambda: ops.nearest_prepare(cb))
+            idx, zq, ws = ops.nearest_screened(z_e, cb, prep, usage=usage, return_workspace=True)
+            self.last_exact_rows = ws
+            return idx, zq
+        idx, zq, _ = ops.nearest(z_e, cb, DIST_NORM, usage=usage)
+        return idx, zq
+
     # -- the metric's path ------------------------------------------------------------------
     @torch.no_grad()
     def encode(self, x):
@@ -149,8 +163,7 @@ class LLFQVAE_V4(_TokenizerBase):
     def tokenize(self, x, count_usage=True):
         """encode + quantize: (indices[N] int64, z_latent[N,D])   (v5:71-74)."""
         z_e = self.encode(x)
-        idx, zq, _ = ops.nearest(z_e, self.quantizer.codebook.detach(), DIST_NORM,
-                                 usage=self.code_usage if count_usage else None)
+        idx, zq = self._quantize(z_e, self.code_usage if count_usage else None)
         self.last_indices = idx
         return idx, zq
 

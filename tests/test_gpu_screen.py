@@ -1,0 +1,109 @@
+"""GPU: the MFMA-screened nearest-code path returns EXACTLY what the exact kernel / the oracle return,
+its error bound holds with margin, and rows it cannot certify are really sent to the exact kernel."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lipvq_oracle as O
+
+pytestmark = pytest.mark.gpu
+GAMMA = 2.0 ** -17
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import lipvq_vae_amd
+    return lipvq_vae_amd.ops
+
+
+def _case(seed, N, K, D, spread=1.0):
+    rng = np.random.default_rng(seed)
+    cb = (0.5 + spread * (rng.uniform(0, 1, (K, D)) - 0.5)).astype(np.float32)
+    z = rng.uniform(0, 1, (N, D)).astype(np.float32)
+    m = min(N, K) // 2
+    z[:m] = cb[rng.permutation(K)[:m]] + (0.02 * rng.standard_normal((m, D))).astype(np.float32)
+    return z, cb
+
+
+@pytest.mark.parametrize("N,K,D", [(4096, 1024, 64), (1000, 256, 32), (700, 1000, 128), (80, 1024, 208),
+                                   (33, 37, 64), (1, 5, 32), (513, 8192, 128)])
+def test_screened_equals_oracle(ops, oracle, N, K, D):
+    z, cb = _case(N + K + D, N, K, D)
+    if K > 3:
+        cb[K - 1] = cb[1]                       # exact duplicate -> an exact tie the screen cannot certify
+    idx_ref, zq_ref, usage_ref = oracle.nearest(z, cb)
+    cbd = dev(cb)
+    prep = ops.nearest_prepare(cbd)
+    usage = torch.zeros(K, dtype=torch.int64, device="cuda")
+    idx, zq, ws = ops.nearest_screened(dev(z), cbd, prep, usage=usage, return_workspace=True)
+    assert np.array_equal(idx.cpu().numpy(), idx_ref)
+    assert np.array_equal(zq.cpu().numpy(), zq_ref)
+    assert np.array_equal(usage.cpu().numpy(), usage_ref)
+    n_exact = int(ws[0])
+    assert 0 <= n_exact <= N
+    # rows whose winner is the duplicated code cannot be certified
+    dup_rows = int(((idx_ref == 1)).sum())
+    assert n_exact >= dup_rows
+
+
+def test_error_bound_holds(ops):
+    """|d~ - d| measured against float64 stays below 1/16 of the bound the kernel uses."""
+    worst = 0.0
+    for seed, (N, K, D, spread) in enumerate([(512, 1024, 64, 1.0), (256, 2048, 128, 1.0), (256, 512, 32, 1.0),
+                                              (128, 1024, 208, 1.0), (512, 1024, 64, 0.2), (512, 1024, 64, 3.0)]):
+        z, cb = _case(100 + seed, N, K, D, spread)
+        cbd = dev(cb)
+        prep = ops.nearest_prepare(cbd)
+        idx, zq, dt = ops.nearest_screened(dev(z), cbd, prep, debug_gamma=GAMMA)
+        dt = dt.cpu().numpy().astype(np.float64)[:, :K]
+        mu = cb.astype(np.float64).mean(0)
+        zc, ec = z.astype(np.float64) - mu, cb.astype(np.float64) - mu
+        d = (ec * ec).sum(1)[None, :] - 2.0 * zc @ ec.T
+        e2max = (ec * ec).sum(1).max()
+        bound = GAMMA * (e2max + 2.0 * np.sqrt((zc * zc).sum(1)) * np.sqrt(e2max))
+        ratio = (np.abs(dt - d) / bound[:, None]).max()
+        worst = max(worst, ratio)
+    assert worst < 1.0 / 16.0, f"screening error reached {worst:.3f} of its bound"
+
+
+def test_gamma_extremes_still_exact(ops, oracle):
+    """gamma = 0 certifies every row with a positive gap; a huge gamma certifies nothing: same answer."""
+    z, cb = _case(9, 2000, 512, 64)
+    idx_ref, _, _ = oracle.nearest(z, cb)
+    cbd, zd = dev(cb), dev(z)
+    prep = ops.nearest_prepare(cbd)
+    idx, _, ws, _ = ops.nearest_screened(zd, cbd, prep, return_workspace=True, debug_gamma=1e6)
+    assert int(ws[0]) == 2000 and np.array_equal(idx.cpu().numpy(), idx_ref)
+    idx, _, ws, _ = ops.nearest_screened(zd, cbd, prep, return_workspace=True, debug_gamma=GAMMA)
+    assert int(ws[0]) < 400 and np.array_equal(idx.cpu().numpy(), idx_ref)
+
+
+def test_near_ties_go_to_exact_kernel(ops, oracle):
+    """Rows placed (almost) on the bisector of two codes: the screen must not decide them."""
+    rng = np.random.default_rng(4)
+    K, D, N = 256, 64, 1024
+    cb = rng.uniform(0, 1, (K, D)).astype(np.float32)
+    z = np.empty((N, D), np.float32)
+    for n in range(N):
+        a, b = rng.choice(K, 2, replace=False)
+        t = np.float32(0.5 + (n % 8) * 1e-8)
+        z[n] = cb[a] * t + cb[b] * (np.float32(1) - t)
+    idx_ref, _, _ = oracle.nearest(z, cb)
+    cbd = dev(cb)
+    idx, _, ws = ops.nearest_screened(dev(z), cbd, ops.nearest_prepare(cbd), return_workspace=True)
+    assert np.array_equal(idx.cpu().numpy(), idx_ref)
+    assert int(ws[0]) > N // 2
+
+
+def test_fp16_overflow_guard(ops, oracle):
+    """Codebook entries beyond the fp16 range: nothing may be certified, results still exact."""
+    z, cb = _case(11, 300, 128, 32)
+    cb[5] *= 1e6
+    idx_ref, _, _ = oracle.nearest(z, cb)
+    cbd = dev(cb)
+    idx, _, ws = ops.nearest_screened(dev(z), cbd, ops.nearest_prepare(cbd), return_workspace=True)
+    assert int(ws[0]) == 300 and np.array_equal(idx.cpu().numpy(), idx_ref)
