@@ -19,34 +19,7 @@
 // the fp32 accumulation inside the MFMA adds a few 2^-24 of the partial sums' magnitude.  gamma
 // (LIPVQ_SCREEN_GAMMA) is 2^-17, > 30x the largest error measured with lipvq_screen_debug_f32 over
 // 10^8 pairs (tests/test_gpu_screen.py::test_error_bound_holds asserts a 16x margin on every run).
-#include <hip/hip_fp16.h>
-
-#include "lipvq_common.h"
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
-#define LIPVQ_SCREEN_GAMMA 7.62939453125e-06f   /* 2^-17 */
-#define SCREEN_WAVES 8
-
-struct PrepLayout {
-    int S, Dpad, Kpad, ntiles;
-    size_t o_hdr, o_mu, o_tiles, tile_bytes, total;
-};
-
-__host__ __device__ static inline PrepLayout prep_layout(int K, int D) {
-    PrepLayout L;
-    L.S = (D + 15) / 16;
-    L.Dpad = L.S * 16;
-    L.Kpad = ((K + 31) / 32) * 32;
-    L.ntiles = L.Kpad / 32;
-    L.o_hdr = 0;                       // 16 floats: [0] E2max bits, [1] Emax^2 bits, [2] max|2e'| bits
-    L.o_mu = 64;
-    L.o_tiles = L.o_mu + sizeof(float) * (size_t)L.Dpad;
-    L.o_tiles = (L.o_tiles + 255) & ~(size_t)255;
-    L.tile_bytes = (size_t)L.S * 2048 + 128;    // S steps x {hi,lo} x 32 codes x 2 halves x 16 B, then 32 x e2
-    L.total = L.o_tiles + (size_t)L.ntiles * L.tile_bytes;
-    return L;
-}
+#include "lipvq_screen.h"
 
 extern "C" size_t lipvq_nearest_prep_bytes(int K, int D) {
     if (K <= 0 || D <= 0) return 0;
@@ -316,21 +289,21 @@ template <int DCH>
 __global__ __launch_bounds__(256) void nearest_rows_kernel(
     const float* __restrict__ z, const float* __restrict__ cb, int64_t* __restrict__ idx, float* __restrict__ zq,
     unsigned long long* __restrict__ usage, const int* __restrict__ row_list, const int* __restrict__ row_count,
-    int K) {
+    int K, int z_by_slot) {
     constexpr int D = DCH * 8;
     __shared__ float s_v[16][16];
     __shared__ float s_s[16][16];
     __shared__ int s_k[16][16];
     const int count = *row_count;
-    const int base = blockIdx.x * 16;
-    if (base >= count) return;
     const int r = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  for (int base = blockIdx.x * 16; base < count; base += gridDim.x * 16) {
     const int slot = base + r;
     const bool valid = slot < count;
-    const int64_t row = row_list[valid ? slot : count - 1];
+    const int cslot = valid ? slot : count - 1;
+    const int64_t row = row_list[cslot];
     float zr[D];
     {
-        const float4* z4 = reinterpret_cast<const float4*>(z + (size_t)row * D);
+        const float4* z4 = reinterpret_cast<const float4*>(z + (size_t)(z_by_slot ? (int64_t)cslot : row) * D);
 #pragma unroll
         for (int i = 0; i < D / 4; ++i) {
             const float4 v = z4[i];
@@ -381,6 +354,8 @@ __global__ __launch_bounds__(256) void nearest_rows_kernel(
         float4* dst = reinterpret_cast<float4*>(zq + (size_t)row * D);
         for (int v = sl; v < D / 4; v += 16) dst[v] = src[v];
     }
+    __syncthreads();
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -412,13 +387,25 @@ static int launch_screen(const float* z, const unsigned char* prep, const float*
 }
 
 template <int DCH>
-static int launch_rows(const float* z, const float* cb, int64_t* idx, float* zq, int64_t* usage,
-                       const int* amb_list, const int* amb_count, int64_t N, int K, hipStream_t st) {
-    // the count lives on the device: launch for the worst case, surplus workgroups exit at once
-    unsigned blocks = (unsigned)((N + 15) / 16);
-    hipLaunchKernelGGL((nearest_rows_kernel<DCH>), dim3(blocks), dim3(256), 0, st, z, cb, idx, zq,
-                       (unsigned long long*)usage, amb_list, amb_count, K);
+static int launch_rows_t(const float* z, int z_by_slot, const float* cb, int64_t* idx, float* zq, int64_t* usage,
+                         const int* amb_list, const int* amb_count, int64_t N, int K, hipStream_t st) {
+    // the count lives on the device: a bounded grid strides over however many rows were listed
+    int64_t blocks = (N + 15) / 16;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL((nearest_rows_kernel<DCH>), dim3((unsigned)blocks), dim3(256), 0, st, z, cb, idx, zq,
+                       (unsigned long long*)usage, amb_list, amb_count, K, z_by_slot);
     return check_launch("nearest_rows");
+}
+
+int lipvq_launch_rows(const float* z, int z_by_slot, const float* cb, int64_t* idx, float* zq, int64_t* usage,
+                      const int* amb_list, const int* amb_count, int64_t N, int K, int D, hipStream_t st) {
+    switch (D) {
+        case 32: return launch_rows_t<4>(z, z_by_slot, cb, idx, zq, usage, amb_list, amb_count, N, K, st);
+        case 64: return launch_rows_t<8>(z, z_by_slot, cb, idx, zq, usage, amb_list, amb_count, N, K, st);
+        case 128: return launch_rows_t<16>(z, z_by_slot, cb, idx, zq, usage, amb_list, amb_count, N, K, st);
+        case 208: return launch_rows_t<26>(z, z_by_slot, cb, idx, zq, usage, amb_list, amb_count, N, K, st);
+        default: return fail(LIPVQ_EUNSUPPORTED, "nearest_rows: D=%d has no instance", D);
+    }
 }
 
 static int screened_impl(const float* z, const float* cb, const void* prep, int64_t* idx, float* zq,
@@ -438,12 +425,7 @@ static int screened_impl(const float* z, const float* cb, const void* prep, int6
         default: return fail(LIPVQ_EUNSUPPORTED, "nearest_screened: D=%d has no screening instance (32, 64, 128, 208)", D);
     }
     if (rc) return rc;
-    switch (D) {
-        case 32: return launch_rows<4>(z, cb, idx, zq, usage, amb_list, amb_count, N, K, st);
-        case 64: return launch_rows<8>(z, cb, idx, zq, usage, amb_list, amb_count, N, K, st);
-        case 128: return launch_rows<16>(z, cb, idx, zq, usage, amb_list, amb_count, N, K, st);
-        default: return launch_rows<26>(z, cb, idx, zq, usage, amb_list, amb_count, N, K, st);
-    }
+    return lipvq_launch_rows(z, 0, cb, idx, zq, usage, amb_list, amb_count, N, K, D, st);
 }
 
 extern "C" int lipvq_nearest_screened_supported(int K, int D) {

@@ -282,3 +282,30 @@ def nearest_screened(z, codebook, prep: PreparedCodebook, usage=None, want_zq=Tr
     if debug_gamma is not None:
         out = out + (dt,)
     return out
+
+
+# ---- fused encode + quantize ------------------------------------------------------------------------
+
+def tokenize_supported(A, J0, J1, D, K) -> bool:
+    return bool(lib.lipvq_tokenize_supported(int(A), int(J0), int(J1), int(D), int(K)))
+
+
+def tokenize(x, packed: PackedMlp3, codebook, prep: PreparedCodebook, usage=None, want_zq=True, want_ze=False):
+    """(idx, zq, ze, workspace) of the fused encode + quantize launch (lipvq_tokenize_f32)."""
+    x, codebook = _chk(x, "x"), _chk(codebook, "codebook")
+    N, A = x.shape
+    K, D = codebook.shape
+    if (packed.K0, packed.J2) != (A, D) or (prep.K, prep.D) != (K, D):
+        raise ValueError("tokenize: packed encoder / prepared codebook do not match the inputs")
+    if usage is not None:
+        usage = _chk(usage, "usage", torch.int64)
+    dev = x.device
+    idx = torch.empty(N, device=dev, dtype=torch.int64)
+    zq = torch.empty((N, D), device=dev, dtype=torch.float32) if want_zq else None
+    ze = torch.empty((N, D), device=dev, dtype=torch.float32) if want_ze else None
+    ws = torch.empty(max(16, (lib.lipvq_tokenize_workspace_bytes(N, D) + 3) // 4), device=dev, dtype=torch.int32)
+    with torch.cuda.device(dev):
+        check(lib.lipvq_tokenize_f32(_ptr(x), _ptr(packed.buf), _ptr(codebook), _ptr(prep.buf), _ptr(idx), _ptr(zq),
+                                     _ptr(usage), _ptr(ze), _ptr(ws), N, A, packed.J0, packed.J1, D, K, _stream()),
+              "lipvq_tokenize_f32")
+    return idx, zq, ze, ws

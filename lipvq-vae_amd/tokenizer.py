@@ -162,8 +162,17 @@ class LLFQVAE_V4(_TokenizerBase):
     @torch.no_grad()
     def tokenize(self, x, count_usage=True):
         """encode + quantize: (indices[N] int64, z_latent[N,D])   (v5:71-74)."""
-        z_e = self.encode(x)
-        idx, zq = self._quantize(z_e, self.code_usage if count_usage else None)
+        x = self._as_rows(x)
+        usage = self.code_usage if count_usage else None
+        cb = self.quantizer.codebook.detach()
+        if x.shape[0] > 0 and ops.tokenize_supported(self.feature_dim, 64, self.hidden_dim, self.latent_dim, self.num_codes):
+            # one persistent launch: z_e never leaves registers (csrc/lipvq_fused.hip)
+            packed, _, _ = self._packed_encoder()
+            prep = self._cb_cache.get((self.quantizer.codebook,), lambda: ops.nearest_prepare(cb))
+            idx, zq, _, ws = ops.tokenize(x, packed, cb, prep, usage=usage)
+            self.last_exact_rows = ws
+        else:
+            idx, zq = self._quantize(self.encode(x), usage)
         self.last_indices = idx
         return idx, zq
 

@@ -1,0 +1,56 @@
+"""GPU: the fused encode+quantize launch (lipvq_tokenize_f32) equals the oracle bit for bit and equals the
+unfused path (lipvq_mlp3_f32 + lipvq_nearest_f32), including z_e when requested."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lipvq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(seed, A, D, K, oracle):
+    from lipvq_vae_amd.tokenizer import LLFQVAE_V4
+    p = O.make_params(seed, A, D, K, oracle=oracle)
+    model = LLFQVAE_V4(A, D, num_codes=K).cuda()
+    model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in p.items()})
+    return p, model
+
+
+@pytest.mark.parametrize("N,A,D,K", [(5000, 7, 64, 1024), (1024, 7, 32, 256), (777, 12, 128, 1000), (33, 7, 64, 37),
+                                     (1, 7, 32, 256), (256 * 300 + 5, 7, 64, 1024), (600, 3, 64, 512)])
+def test_fused_equals_oracle_and_unfused(oracle, N, A, D, K):
+    from lipvq_vae_amd import ops
+    p, model = _setup(N + D, A, D, K, oracle)
+    assert ops.tokenize_supported(A, 64, 128, D, K)
+    x = O.make_inputs(N, N, A)
+    xt = torch.from_numpy(x).cuda()
+    ze_ref = oracle.llfq_encode(p, x)
+    idx_ref, zq_ref, usage_ref = oracle.nearest(ze_ref, p["quantizer.codebook"])
+    packed, _, _ = model._packed_encoder()
+    cb = model.quantizer.codebook.detach()
+    prep = ops.nearest_prepare(cb)
+    usage = torch.zeros(K, dtype=torch.int64, device="cuda")
+    idx, zq, ze, ws = ops.tokenize(xt, packed, cb, prep, usage=usage, want_ze=True)
+    assert np.array_equal(ze.cpu().numpy(), ze_ref)
+    assert np.array_equal(idx.cpu().numpy(), idx_ref)
+    assert np.array_equal(zq.cpu().numpy(), zq_ref)
+    assert np.array_equal(usage.cpu().numpy(), usage_ref)
+    assert 0 <= int(ws[0]) <= N
+    # module level: tokenize() takes the fused launch, encode()+_quantize() the unfused one
+    idx2, zq2 = model.tokenize(xt, count_usage=False)
+    idx3, zq3 = model._quantize(model.encode(xt), None)
+    assert torch.equal(idx2, idx) and torch.equal(idx3, idx) and torch.equal(zq2, zq) and torch.equal(zq3, zq)
+
+
+def test_fused_without_optional_outputs(oracle):
+    from lipvq_vae_amd import ops
+    p, model = _setup(3, 7, 64, 256, oracle)
+    x = torch.from_numpy(O.make_inputs(3, 999, 7)).cuda()
+    packed, _, _ = model._packed_encoder()
+    cb = model.quantizer.codebook.detach()
+    prep = ops.nearest_prepare(cb)
+    idx, zq, ze, _ = ops.tokenize(x, packed, cb, prep, want_zq=False)
+    assert zq is None and ze is None
+    idx2, _, _, _ = ops.tokenize(x, packed, cb, prep)
+    assert torch.equal(idx, idx2)
