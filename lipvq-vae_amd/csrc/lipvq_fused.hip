@@ -5,7 +5,8 @@
 // Replaces reference backbone_lfqvae_v5.py:71-74 (encoder, to_latent, quantizer, z_latent) with the SAME
 // results as lipvq_mlp3_f32 + lipvq_nearest_f32: phase A is mlp3_kernel's arithmetic (one k-ordered fmaf
 // chain per output, lipvq_mlp.hip), phase B is screen_kernel's (lipvq_screen.hip).  z_e never touches HBM
-// unless the caller asks for it (training) or a row is uncertified (<1 % of rows at BASELINE config 2).
+// as an operand of the screen; it is written once (coalesced 16-byte stores) so that the exact kernel can
+// re-score the <1 % of rows the screen cannot certify, and for the caller when training.
 //
 // Why fused: the two stand-alone kernels are latency bound (rocprofv3 PMC, profiles/r01_b: MFMA pipe 13-18 %
 // busy, half of all wave cycles parked in s_waitcnt/barriers): mlp3 streams its A operands from L2 at one
@@ -17,6 +18,8 @@
 
 #define FUSED_WAVES 8
 #define FUSED_THREADS (FUSED_WAVES * 64)
+// LDS budget: the D = 128 instance holds 105 KB of weights, so its codebook stages are one tile deep
+constexpr int fused_tc(int S) { return (S <= 2) ? 8 : (S <= 4) ? 4 : 1; }
 
 struct TokArgs {
     const float* x;              // [N][A]
@@ -29,7 +32,6 @@ struct TokArgs {
     float* ze_out;               // [N][D] or NULL
     int* amb_count;              // workspace[0]
     int* amb_list;               // [N]
-    float* amb_z;                // [N][D] compact z_e rows of uncertified rows
     int64_t N;
     int A, D, K;
     float gamma;
@@ -40,11 +42,6 @@ template <int S>
 __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
     constexpr int T0 = 2, T1 = 4, T2 = S / 2;
     constexpr int S1 = 16 * T0, S2 = 16 * T1;               // k-steps (pairs) of layers 1 and 2
-    constexpr int TILE_BYTES = S * 2048 + 128;
-    constexpr int TC = (S <= 2) ? 8 : (S <= 4) ? 4 : 1;     // column tiles per LDS stage
-    constexpr int STAGE_BYTES = TC * TILE_BYTES;
-    constexpr int STAGE_VEC = STAGE_BYTES / 16;
-    constexpr int VPT = (STAGE_VEC + FUSED_THREADS - 1) / FUSED_THREADS;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const PackedLayout PL = packed_layout(a.A, 32 * T0, 32 * T1, 16 * S);
@@ -93,7 +90,6 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
 
     const unsigned* hdr = reinterpret_cast<const unsigned*>(a.prep);
     const unsigned char* tiles = a.prep + L.o_tiles;
-    const int nstage = (L.ntiles + TC - 1) / TC;
     const int64_t nblk = (a.N + FUSED_WAVES * 32 - 1) / (FUSED_WAVES * 32);
 
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
@@ -147,7 +143,6 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) h1[t][r] = lq_gelu(acc[r]);
         }
-        f32x16 zf[T2];                   // z_e in fp32 (kept for uncertified rows / ze_out)
         f16x8 ah[S], al[S];
         float n2 = 0.0f;
 #pragma unroll
@@ -166,7 +161,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float zv = lq_sigmoid(acc[r]);
-                zf[t][r] = zv;
+                acc[r] = zv;
                 // register r of tile t is feature 32t + 2r + h = screen slot (step 2t + (r >> 3), element r & 7)
                 const float v = zv - w_mu[32 * t + 2 * r + h];
                 const _Float16 vh = (_Float16)v;
@@ -174,157 +169,60 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
                 al[2 * t + (r >> 3)][r & 7] = (_Float16)(v - (float)vh);
                 n2 = lq_fma(v, v, n2);
             }
+            // z_e row store.  Lane (n, h) holds features 32t + 2r + h (r = 0..15) of row n: the even ones in
+            // the low half-wave, the odd ones in the high half.  One v_permlane32_swap per register pair
+            // (low half's r >= 8 <-> high half's r < 8) leaves the low lane with features 32t .. 32t+15 and
+            // the high lane with 32t+16 .. 32t+31, i.e. four 16-byte stores of consecutive floats per lane
+            // (64 contiguous bytes per lane) instead of sixteen 4-byte stores scattered over the row.
+            if (a.ze_out) {
+                float lo8[8], hi8[8];                 // after the swaps: lo8[j] = feature base + 2j, hi8[j] = base + 2j + 1
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    // vdst = low half's register r = 8 + j (goes up), src = high half's register r = j (comes down)
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[j]), __float_as_uint(acc[8 + j]), false, false);
+                    // sw[0]: lanes 0-31 keep acc[j] (own even features 2j), lanes 32-63 receive low half's acc[8+j]
+                    // sw[1]: lanes 0-31 receive high half's acc[j] (odd features 2j+1), lanes 32-63 keep acc[8+j]
+                    lo8[j] = __uint_as_float(sw[0]);
+                    hi8[j] = __uint_as_float(sw[1]);
+                }
+                // low lanes : lo8[j] = feat 2j (own, even), hi8[j] = feat 2j+1 (from the high lane)        -> base 32t
+                // high lanes: lo8[j] = feat 16+2j (from the low lane, even), hi8[j] = feat 16+2j+1 (own) -> base 32t+16
+                if (row < a.N) {
+                    float4* dst = reinterpret_cast<float4*>(a.ze_out + (size_t)row * a.D + 32 * t + 16 * h);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) dst[q] = make_float4(lo8[2 * q], hi8[2 * q], lo8[2 * q + 1], hi8[2 * q + 1]);
+                }
+            }
         }
         n2 += __shfl_xor(n2, 32, 64);
-        if (a.ze_out && row < a.N) {
-#pragma unroll
-            for (int t = 0; t < T2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) a.ze_out[(size_t)row * a.D + 32 * t + 2 * r + h] = zf[t][r];
-        }
-
-        // ================= phase B: MFMA screen (same arithmetic as screen_kernel) ============
+        // ================= phase B: MFMA screen (lq_screen_core, lipvq_screen.h) ==============
         float m1[16], m2[16];
         int k1[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { m1[r] = INFINITY; m2[r] = INFINITY; k1[r] = 0; }
-        uint4 pre[VPT];
-        auto stage_load = [&](int st) {
-            const uint4* src = reinterpret_cast<const uint4*>(tiles + (size_t)st * STAGE_BYTES);
-            const size_t avail = ((size_t)L.ntiles * TILE_BYTES - (size_t)st * STAGE_BYTES) / 16;
-#pragma unroll
-            for (int v = 0; v < VPT; ++v) {
-                const int i = tid + v * FUSED_THREADS;
-                pre[v] = (i < STAGE_VEC && (size_t)i < avail) ? src[i] : make_uint4(0, 0, 0, 0);
-            }
-        };
-        auto stage_store = [&](int buf) {
-            uint4* dst = reinterpret_cast<uint4*>(stage0 + (size_t)buf * STAGE_BYTES);
-#pragma unroll
-            for (int v = 0; v < VPT; ++v) {
-                const int i = tid + v * FUSED_THREADS;
-                if (i < STAGE_VEC) dst[i] = pre[v];
-            }
-        };
-        stage_load(0);
-        __syncthreads();                 // previous block's readers of stage buffers / scratch are done
-        stage_store(0);
-        __syncthreads();
-        for (int st = 0; st < nstage; ++st) {
-            if (st + 1 < nstage) stage_load(st + 1);
-            const unsigned char* sb = stage0 + (size_t)(st & 1) * STAGE_BYTES;
-#pragma unroll
-            for (int c = 0; c < TC; ++c) {
-                const int ct = st * TC + c;
-                if (ct < L.ntiles) {
-                    const unsigned char* tb = sb + (size_t)c * TILE_BYTES;
-                    const float e2 = reinterpret_cast<const float*>(tb + S * 2048)[ln];
-                    f32x16 acc;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = e2;
-#pragma unroll
-                    for (int s = 0; s < S; ++s) {
-                        const f16x8 bh = *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 0) * 64 + lane) * 16);
-                        const f16x8 bl = *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 1) * 64 + lane) * 16);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl, acc, 0, 0, 0);
-                    }
-                    const int code = ct * 32 + ln;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float v = acc[r];
-                        k1[r] = (v < m1[r]) ? code : k1[r];
-                        m2[r] = __builtin_amdgcn_fmed3f(v, m1[r], m2[r]);
-                        m1[r] = fminf(v, m1[r]);
-                    }
-                }
-            }
-            if (st + 1 < nstage) stage_store((st + 1) & 1);
-            __syncthreads();
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-#pragma unroll
-            for (int o = 1; o < 32; o <<= 1) {
-                const float om1 = __shfl_xor(m1[r], o, 64);
-                const float om2 = __shfl_xor(m2[r], o, 64);
-                const int ok1 = __shfl_xor(k1[r], o, 64);
-                const float hi = fmaxf(m1[r], om1);
-                m2[r] = fminf(fminf(m2[r], om2), hi);
-                const bool take = (om1 < m1[r]) || (om1 == m1[r] && ok1 < k1[r]);
-                k1[r] = take ? ok1 : k1[r];
-                m1[r] = fminf(m1[r], om1);
+        lq_screen_core<S, FUSED_THREADS, fused_tc(S)>(ah, al, tiles, L.ntiles, stage0, tid, m1, m2, k1);
+        lq_screen_merge(m1, m2, k1);
+        int my_k;
+        const bool certified = lq_screen_decide(m1, m2, k1, scr_all + wave * 96, hdr, n2, a.gamma, a.K, lane, my_k);
+        if (h == 0 && row < a.N) {
+            if (certified) {
+                a.idx[row] = (int64_t)my_k;
+                if (a.usage) atomicAdd(&a.usage[my_k], 1ull);
+            } else {
+                a.amb_list[atomicAdd(a.amb_count, 1)] = (int)row;
             }
         }
-        float* scr = scr_all + wave * 96;
-        if (ln == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-                scr[i] = m1[r];
-                scr[32 + i] = m2[r];
-                reinterpret_cast<int*>(scr)[64 + i] = k1[r];
-            }
-        }
-        __syncthreads();
-        int my_k = 0, my_slot = -1;
-        bool certified = false;
-        if (h == 0) {
-            const float av = scr[ln], bv = scr[32 + ln];
-            my_k = reinterpret_cast<const int*>(scr)[64 + ln];
-            const float E2max = __uint_as_float(hdr[0]);
-            const float Emax = lq_sqrt(__uint_as_float(hdr[1]));
-            const float twoemax = __uint_as_float(hdr[2]);
-            const float cross = 2.0f * lq_sqrt(n2) * Emax;
-            const float eps = a.gamma * (E2max + cross) + 9.5367431640625e-07f * (n2 + E2max + cross);
-            certified = (twoemax < 60000.0f) && (bv - av > 2.0f * eps) && (my_k < a.K);
-            if (row < a.N) {
-                if (certified) {
-                    a.idx[row] = (int64_t)my_k;
-                    if (a.usage) atomicAdd(&a.usage[my_k], 1ull);
-                } else {
-                    my_slot = atomicAdd(a.amb_count, 1);
-                    a.amb_list[my_slot] = (int)row;
-                }
-            }
-        }
-        // uncertified rows: hand the exact fp32 z_e row to the exact kernel (both lane halves hold half the row)
-        {
-            const int slot = __shfl(my_slot, ln, 64);
-            if (slot >= 0) {
-#pragma unroll
-                for (int t = 0; t < T2; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) a.amb_z[(size_t)slot * a.D + 32 * t + 2 * r + h] = zf[t][r];
-            }
-        }
-        if (a.zq) {
-            const int nvec = a.D / 4;
-            for (int rr = 0; rr < 32; rr += 4) {
-                const int src_lane = rr + (lane >> 4);
-                const int kk = __shfl(my_k, src_lane, 64);
-                const bool ok = __shfl((int)certified, src_lane, 64) != 0;
-                const int64_t orow = row0 + src_lane;
-                if (ok && orow < a.N) {
-                    const float4* src = reinterpret_cast<const float4*>(a.cb + (size_t)kk * a.D);
-                    float4* dst = reinterpret_cast<float4*>(a.zq + (size_t)orow * a.D);
-                    for (int v = lane & 15; v < nvec; v += 16) dst[v] = src[v];
-                }
-            }
-        }
+        if (a.zq) lq_screen_gather(a.cb, a.zq, my_k, certified, row0, a.N, a.D, lane);
     }
 }
 
 template <int S>
 static size_t fused_lds_bytes(int A) {
     constexpr int T0 = 2, T1 = 4, T2 = S / 2;
-    constexpr int TILE_BYTES = S * 2048 + 128;
-    constexpr int TC = (S <= 2) ? 8 : (S <= 4) ? 4 : 1;
     const int S0q = ((A + 1) / 2 + 3) / 4;
     size_t fl = (size_t)T0 * S0q * 256 + 32 * T0 + (size_t)T1 * 8 * 256 + 32 * T1 + (size_t)T2 * 16 * 256 + 32 * T2 + 16 * S +
                 FUSED_WAVES * 96;
-    return fl * sizeof(float) + 2 * (size_t)TC * TILE_BYTES;
+    return fl * sizeof(float) + 2 * (size_t)ScreenCfg<S, fused_tc(S)>::STAGE_BYTES;
 }
 
 template <int S>
@@ -363,16 +261,19 @@ extern "C" int lipvq_tokenize_f32(const float* x, const float* packed, const flo
     if (!lipvq_tokenize_supported(A, J0, J1, D, K))
         return fail(LIPVQ_EUNSUPPORTED, "tokenize: unsupported shape A=%d J0=%d J1=%d D=%d K=%d", A, J0, J1, D, K);
     if (N > 2147483647LL) return fail(LIPVQ_EUNSUPPORTED, "tokenize: N too large");
-    if ((((uintptr_t)codebook | (uintptr_t)zq) & 15) != 0) return fail(LIPVQ_EINVAL, "tokenize: codebook and zq must be 16-byte aligned");
+    if ((((uintptr_t)codebook | (uintptr_t)zq | (uintptr_t)ze_out | (uintptr_t)workspace) & 15) != 0)
+        return fail(LIPVQ_EINVAL, "tokenize: codebook, zq, ze_out and workspace must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     unsigned char* ws = (unsigned char*)workspace;
     int* amb_count = (int*)ws;
     int* amb_list = (int*)(ws + 64);
-    float* amb_z = (float*)(ws + 64 + (((sizeof(int) * (size_t)N) + 63) & ~(size_t)63));
+    // z_e is always materialised (coalesced 16-byte stores, ~134 MB at BASELINE config 2): the exact kernel
+    // reads the rows it needs from it; the caller's buffer is used when one is given
+    float* ze_buf = ze_out ? ze_out : (float*)(ws + 64 + (((sizeof(int) * (size_t)N) + 63) & ~(size_t)63));
     hipError_t e = hipMemsetAsync(amb_count, 0, 64, st);
     if (e != hipSuccess) return fail(LIPVQ_EHIP, "tokenize: %s", hipGetErrorString(e));
-    TokArgs a{x, packed, (const unsigned char*)prep, codebook, idx, zq, (unsigned long long*)usage, ze_out,
-              amb_count, amb_list, amb_z, N, A, D, K, LIPVQ_SCREEN_GAMMA};
+    TokArgs a{x, packed, (const unsigned char*)prep, codebook, idx, zq, (unsigned long long*)usage, ze_buf,
+              amb_count, amb_list, N, A, D, K, LIPVQ_SCREEN_GAMMA};
     int rc;
     switch (D) {
         case 32: rc = launch_tokenize<2>(a, st); break;
@@ -380,5 +281,6 @@ extern "C" int lipvq_tokenize_f32(const float* x, const float* packed, const flo
         default: rc = launch_tokenize<8>(a, st); break;
     }
     if (rc) return rc;
-    return lipvq_launch_rows(amb_z, 1, codebook, idx, zq, usage, amb_list, amb_count, N, K, D, st);
+    // uncertified rows (count on the device) are decided exactly from their stored z_e rows
+    return lipvq_launch_rows(a.ze_out, 0, codebook, idx, zq, usage, amb_list, amb_count, N, K, D, st);
 }

@@ -21,7 +21,7 @@ __host__ __device__ static inline PrepLayout prep_layout(int K, int D) {
     L.S = (D + 15) / 16;
     L.Dpad = L.S * 16;
     L.Kpad = ((K + 31) / 32) * 32;
-    L.ntiles = L.Kpad / 32;
+    L.ntiles = ((L.Kpad / 32 + 7) / 8) * 8;   // whole LDS stages: pad tiles carry e2 = +inf, zero fragments
     L.o_hdr = 0;                       // 16 floats: [0] E2max bits, [1] Emax^2 bits, [2] max|2e'| bits
     L.o_mu = 64;
     L.o_tiles = L.o_mu + sizeof(float) * (size_t)L.Dpad;
@@ -31,6 +31,222 @@ __host__ __device__ static inline PrepLayout prep_layout(int K, int D) {
     return L;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// The screening main loop, shared by screen_kernel (lipvq_screen.hip) and tokenize_kernel
+// (lipvq_fused.hip).  NT threads stream the prepared codebook through two LDS stage buffers of TC
+// column tiles; each wave multiplies its 32 rows (fp16 hi/lo A fragments ah/al) against every
+// tile and keeps, per accumulator register (= row) and lane (= code mod 32), the smallest d~, its
+// code, and the second smallest d~.
+//
+// The two waves of a SIMD are staggered by one tile's bookkeeping (see "Stagger" below): rocprofv3 PMC
+// before this change showed the matrix pipe 32 % busy with both waves in lockstep.
+// ------------------------------------------------------------------------------------------
+constexpr int screen_default_tc(int S) { return (S <= 2) ? 8 : (S <= 4) ? 4 : (S <= 8) ? 2 : 1; }
+
+template <int S, int TC_ = screen_default_tc(S)>
+struct ScreenCfg {
+    static constexpr int TILE_BYTES = S * 2048 + 128;
+    static constexpr int TC = TC_;                                              // tiles per stage (divides 8)
+    static constexpr int STAGE_BYTES = TC * TILE_BYTES;
+    static constexpr int STAGE_VEC = STAGE_BYTES / 16;
+};
+
+__device__ __forceinline__ void lq_track(const f32x16& acc, int code, float (&m1)[16], float (&m2)[16], int (&k1)[16]) {
+#ifdef LQ_ABL_NOTRACK
+    m1[0] = fminf(m1[0], acc[0] + acc[5] + acc[10] + acc[15]); return;   // keeps the MFMAs alive
+#endif
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float v = acc[r];
+        const bool lt = v < m1[r];              // one compare feeds both selects (fminf would cost two
+        k1[r] = lt ? code : k1[r];              // NaN-canonicalising v_max as well)
+        m2[r] = __builtin_amdgcn_fmed3f(v, m1[r], m2[r]);
+        m1[r] = lt ? v : m1[r];
+    }
+}
+
+template <int S, int NT, int TC_ = screen_default_tc(S)>
+__device__ __forceinline__ void lq_screen_core(const f16x8 (&ah)[S], const f16x8 (&al)[S],
+                                               const unsigned char* __restrict__ tiles, int ntiles,
+                                               unsigned char* stage0, int tid, float (&m1)[16], float (&m2)[16],
+                                               int (&k1)[16]) {
+    using C = ScreenCfg<S, TC_>;
+    constexpr int VPT = (C::STAGE_VEC + NT - 1) / NT;
+    const int lane = tid & 63, ln = lane & 31;
+#ifdef LQ_ABL_NOLOOP
+    const int nstage = 0;            // ablation build only (scripts/ablate.sh)
+#else
+    const int nstage = ntiles / C::TC;
+#endif
+    // Stage copies go global -> LDS directly (global_load_lds_dwordx4: no VGPR round trip, no ds_write
+    // issue; ablation: the register-staged copy cost 84 us of a 440 us launch).  One wave-instruction
+    // moves 64 x 16 B to a wave-uniform LDS base + lane*16, which is exactly this linear copy.
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+    auto stage_dma = [&](int st, int buf) {
+        const unsigned char* src = tiles + (size_t)st * C::STAGE_BYTES;
+        unsigned char* dst = stage0 + (size_t)buf * C::STAGE_BYTES;
+        const int wbase = tid & ~63;                                     // first thread of this wave
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            const int i = tid + v * NT;
+            if (i < C::STAGE_VEC)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (size_t)i * 16),
+                                                 (lds_ptr_t)(dst + (size_t)(wbase + v * NT) * 16), 16, 0, 0);
+        }
+    };
+    // Stagger (MI355X_MICROARCH "Two waves per SIMD", item 9): the two waves that share a SIMD run the
+    // same program and would otherwise issue their MFMA chains -- and then their bookkeeping -- at the
+    // same time.  Waves 4..7 (the second wave of each SIMD) therefore book-keep tile t-1 BEFORE the
+    // chain of tile t (carrying one accumulator across stage barriers); waves 0..3 book-keep tile t
+    // right after its chain.  Same work, same results; the halves alternate between the two pipes.
+#ifdef LQ_OPT_NODEFER
+    const bool deferred = false;
+#else
+    const bool deferred = __builtin_amdgcn_readfirstlane(tid) >= NT / 2;
+#endif
+    f32x16 accP;                                  // deferred waves: tile whose bookkeeping is pending
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accP[r] = INFINITY;     // tracking +inf changes nothing
+    int codeP = 0;
+    __syncthreads();                              // earlier readers of the stage buffers are done
+    stage_dma(0, 0);
+    __syncthreads();                              // (drains the DMA: hipcc waits vmcnt(0) before the barrier)
+    for (int st = 0; st < nstage; ++st) {
+#ifndef LQ_ABL_NOSTAGE
+        if (st + 1 < nstage) stage_dma(st + 1, (st + 1) & 1);     // its last readers passed the previous barrier
+#endif
+#ifdef LQ_ABL_NOSTAGE
+        const unsigned char* sb = stage0;
+#else
+        const unsigned char* sb = stage0 + (size_t)(st & 1) * C::STAGE_BYTES;
+#endif
+        // B fragments are read one tile AHEAD of their use (2*S 16-byte LDS reads in flight under the
+        // previous tile's MFMA chain); read just in time, every 3-MFMA step sat behind ~100 cycles of
+        // LDS latency (ISA + SQ_WAIT counters, profiles/r01_c).
+        f16x8 bq[2][S][2];
+        float e2q[2];
+        auto frag_load = [&](int c, int slot) {
+            const unsigned char* tb = sb + (size_t)c * C::TILE_BYTES;
+            e2q[slot] = reinterpret_cast<const float*>(tb + S * 2048)[ln];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                bq[slot][s][0] = *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 0) * 64 + lane) * 16);
+                bq[slot][s][1] = *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 1) * 64 + lane) * 16);
+            }
+        };
+        frag_load(0, 0);
+#pragma unroll
+        for (int c = 0; c < C::TC; ++c) {
+            const int code = (st * C::TC + c) * 32 + ln;
+#ifdef LQ_OPT_NOPREFETCH
+            if (c > 0) frag_load(c, c & 1);
+#else
+            if (c + 1 < C::TC) frag_load(c + 1, (c + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);            // keep the prefetch above the chain
+#endif
+            if (deferred) lq_track(accP, codeP, m1, m2, k1);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = e2q[c & 1];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bq[c & 1][s][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bq[c & 1][s][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bq[c & 1][s][1], acc, 0, 0, 0);
+            }
+            if (deferred) {
+                accP = acc;
+                codeP = code;
+            } else {
+                lq_track(acc, code, m1, m2, k1);
+            }
+        }
+#ifndef LQ_ABL_NOBARRIER
+        __syncthreads();
+#endif
+    }
+    if (deferred) lq_track(accP, codeP, m1, m2, k1);
+}
+
+// merge the 32 lanes of each half: per row the global (min, argmin, second min)
+__device__ __forceinline__ void lq_screen_merge(float (&m1)[16], float (&m2)[16], int (&k1)[16]) {
+#ifdef LQ_ABL_NOMERGE
+    return;
+#endif
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            const float om1 = __shfl_xor(m1[r], o, 64);
+            const float om2 = __shfl_xor(m2[r], o, 64);
+            const int ok1 = __shfl_xor(k1[r], o, 64);
+            const float hi = fmaxf(m1[r], om1);
+            m2[r] = fminf(fminf(m2[r], om2), hi);
+            const bool take = (om1 < m1[r]) || (om1 == m1[r] && ok1 < k1[r]);
+            k1[r] = take ? ok1 : k1[r];
+            m1[r] = fminf(m1[r], om1);
+        }
+    }
+}
+
+// row i's (m1, m2, k1) -> lane i (i < 32) through a 96-float per-wave LDS scratch; then the decision.
+// Returns certified; my_k valid in lanes < 32.
+__device__ __forceinline__ bool lq_screen_decide(const float (&m1)[16], const float (&m2)[16], const int (&k1)[16],
+                                                 float* scr, const unsigned* hdr, float n2, float gamma, int K,
+                                                 int lane, int& my_k) {
+    const int ln = lane & 31, h = lane >> 5;
+    if (ln == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+            scr[i] = m1[r];
+            scr[32 + i] = m2[r];
+            reinterpret_cast<int*>(scr)[64 + i] = k1[r];
+        }
+    }
+    __syncthreads();                              // every wave reaches this point (no early exit in callers)
+    bool certified = false;
+    my_k = 0;
+    if (h == 0) {
+        const float a = scr[ln], b = scr[32 + ln];
+        my_k = reinterpret_cast<const int*>(scr)[64 + ln];
+        const float E2max = __uint_as_float(hdr[0]);
+        const float Emax = lq_sqrt(__uint_as_float(hdr[1]));
+        const float twoemax = __uint_as_float(hdr[2]);
+        const float cross = 2.0f * lq_sqrt(n2) * Emax;
+        // screening error + the rounding of the reference's own fp32 distance / square root (2^-20 of
+        // the largest full squared distance the row can see)
+        const float eps = gamma * (E2max + cross) + 9.5367431640625e-07f * (n2 + E2max + cross);
+        // fp16 range guard: -2e' must stay finite in fp16, else nothing is certified
+        certified = (twoemax < 60000.0f) && (b - a > 2.0f * eps) && (my_k < K);
+#ifdef LQ_ABL_CERT_ALL
+        certified = true; my_k = my_k < K ? (my_k < 0 ? 0 : my_k) : 0;
+#endif
+    }
+    return certified;
+}
+
+// z_q rows of certified rows: 16 lanes copy one codebook row (16 B each), 4 rows per pass
+__device__ __forceinline__ void lq_screen_gather(const float* __restrict__ cb, float* __restrict__ zq, int my_k,
+                                                 bool certified, int64_t row0, int64_t N, int D, int lane) {
+#ifdef LQ_ABL_NOGATHER
+    return;
+#endif
+    const int nvec = D / 4;
+    for (int rr = 0; rr < 32; rr += 4) {
+        const int src_lane = rr + (lane >> 4);
+        const int kk = __shfl(my_k, src_lane, 64);
+        const bool ok = __shfl((int)certified, src_lane, 64) != 0;
+        const int64_t orow = row0 + src_lane;
+        if (ok && orow < N) {
+            const float4* src = reinterpret_cast<const float4*>(cb + (size_t)kk * D);
+            float4* dst = reinterpret_cast<float4*>(zq + (size_t)orow * D);
+            for (int v = lane & 15; v < nvec; v += 16) dst[v] = src[v];
+        }
+    }
+}
 
 // exact decision for listed rows (lipvq_screen.hip); z_by_slot: z is a compact [count][D] buffer
 int lipvq_launch_rows(const float* z, int z_by_slot, const float* cb, int64_t* idx, float* zq, int64_t* usage,

@@ -40,7 +40,7 @@ __global__ void prep_mean_kernel(const float* __restrict__ cb, float* __restrict
 __global__ void prep_frag_kernel(const float* __restrict__ cb, const float* __restrict__ mu,
                                  unsigned char* __restrict__ tiles, int K, int D, PrepLayout L) {
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t n = (size_t)L.Kpad * L.S * 2;
+    size_t n = (size_t)L.ntiles * 32 * L.S * 2;
     if (gid >= n) return;
     const int h = (int)(gid & 1);
     const int s = (int)((gid >> 1) % L.S);
@@ -66,7 +66,7 @@ __global__ void prep_e2_kernel(const float* __restrict__ cb, const float* __rest
                                unsigned char* __restrict__ tiles, unsigned* __restrict__ hdr, int K, int D,
                                PrepLayout L) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= L.Kpad) return;
+    if (k >= L.ntiles * 32) return;
     float* e2p = reinterpret_cast<float*>(tiles + (size_t)(k >> 5) * L.tile_bytes + (size_t)L.S * 2048) + (k & 31);
     if (k >= K) { *e2p = INFINITY; return; }
     double s = 0.0;
@@ -92,29 +92,24 @@ extern "C" int lipvq_nearest_prepare_f32(const float* codebook, void* prep, int 
     if (e != hipSuccess) return fail(LIPVQ_EHIP, "nearest_prepare: %s", hipGetErrorString(e));
     float* mu = (float*)(base + L.o_mu);
     hipLaunchKernelGGL(prep_mean_kernel, dim3((L.Dpad + 63) / 64), dim3(64), 0, st, codebook, mu, K, D, L.Dpad);
-    size_t n = (size_t)L.Kpad * L.S * 2;
+    size_t n = (size_t)L.ntiles * 32 * L.S * 2;
     hipLaunchKernelGGL(prep_frag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, codebook, mu,
                        base + L.o_tiles, K, D, L);
-    hipLaunchKernelGGL(prep_e2_kernel, dim3((L.Kpad + 255) / 256), dim3(256), 0, st, codebook, mu, base + L.o_tiles,
+    hipLaunchKernelGGL(prep_e2_kernel, dim3((L.ntiles * 32 + 255) / 256), dim3(256), 0, st, codebook, mu, base + L.o_tiles,
                        (unsigned*)base, K, D, L);
     return check_launch("nearest_prepare");
 }
 
 // ------------------------------------------------------------------------------------------
-// screening kernel: 8 waves x 32 rows per workgroup, codebook tiles double-buffered in LDS
+// screening kernel: 8 waves x 32 rows per workgroup (main loop: lq_screen_core, lipvq_screen.h)
 // ------------------------------------------------------------------------------------------
-template <int S>
+template <int S, bool DBG>
 __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
     const float* __restrict__ z, const unsigned char* __restrict__ prep, const float* __restrict__ cb,
     int64_t* __restrict__ idx, float* __restrict__ zq, unsigned long long* __restrict__ usage,
     int* __restrict__ amb_list, int* __restrict__ amb_count, float* __restrict__ dbg, int64_t N, int K, int D,
     float gamma) {
-    constexpr int TILE_BYTES = S * 2048 + 128;
-    constexpr int TC = (S <= 2) ? 8 : (S <= 4) ? 4 : (S <= 8) ? 2 : 1;      // column tiles per LDS stage
-    constexpr int STAGE_BYTES = TC * TILE_BYTES;
-    constexpr int STAGE_VEC = STAGE_BYTES / 16;
-    constexpr int NT = SCREEN_WAVES * 64;
-    constexpr int VPT = (STAGE_VEC + NT - 1) / NT;                            // 16-byte vectors per thread per stage
+    using C = ScreenCfg<S>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const PrepLayout L = prep_layout(K, D);
     const unsigned* hdr = reinterpret_cast<const unsigned*>(prep);
@@ -126,7 +121,7 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
     const int64_t row = row0 + ln;
     const int64_t rowc = row < N ? row : N - 1;
 
-    // ---- this wave's 32 rows -> centred fp16 hi/lo A fragments --------------------------
+    // this wave's 32 rows -> centred fp16 hi/lo A fragments (slot (h, j) of step s = feature 16s + 2j + h)
     f16x8 ah[S], al[S];
     float n2 = 0.0f;
     {
@@ -152,111 +147,39 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) { m1[r] = INFINITY; m2[r] = INFINITY; k1[r] = 0; }
 
-    // ---- stream the prepared codebook through LDS ---------------------------------------
-    const int nstage = (L.ntiles + TC - 1) / TC;
-    uint4 pre[VPT];
-    auto stage_load = [&](int st) {
-        const uint4* src = reinterpret_cast<const uint4*>(tiles + (size_t)st * STAGE_BYTES);
-        const size_t avail = ((size_t)L.ntiles * TILE_BYTES - (size_t)st * STAGE_BYTES) / 16;
+    if (DBG) {
+        // test hook: plain loop straight from global memory, dumping every approximate distance
+        for (int ct = 0; ct < L.ntiles; ++ct) {
+            const unsigned char* tb = tiles + (size_t)ct * C::TILE_BYTES;
+            const float e2 = reinterpret_cast<const float*>(tb + S * 2048)[ln];
+            f32x16 acc;
 #pragma unroll
-        for (int v = 0; v < VPT; ++v) {
-            const int i = tid + v * NT;
-            pre[v] = (i < STAGE_VEC && (size_t)i < avail) ? src[i] : make_uint4(0, 0, 0, 0);
-        }
-    };
-    auto stage_store = [&](int buf) {
-        uint4* dst = reinterpret_cast<uint4*>(lds + (size_t)buf * STAGE_BYTES);
+            for (int r = 0; r < 16; ++r) acc[r] = e2;
 #pragma unroll
-        for (int v = 0; v < VPT; ++v) {
-            const int i = tid + v * NT;
-            if (i < STAGE_VEC) dst[i] = pre[v];
-        }
-    };
-    stage_load(0);
-    stage_store(0);
-    __syncthreads();
-    for (int st = 0; st < nstage; ++st) {
-        if (st + 1 < nstage) stage_load(st + 1);
-        const unsigned char* sb = lds + (size_t)(st & 1) * STAGE_BYTES;
-#pragma unroll
-        for (int c = 0; c < TC; ++c) {
-            const int ct = st * TC + c;
-            if (ct < L.ntiles) {                                  // uniform
-                const unsigned char* tb = sb + (size_t)c * TILE_BYTES;
-                const float e2 = reinterpret_cast<const float*>(tb + S * 2048)[ln];
-                f32x16 acc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = e2;
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const f16x8 bh = *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 0) * 64 + lane) * 16);
-                    const f16x8 bl = *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 1) * 64 + lane) * 16);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl, acc, 0, 0, 0);
-                }
-                const int code = ct * 32 + ln;
+            for (int s = 0; s < S; ++s) {
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 0) * 64 + lane) * 16);
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 1) * 64 + lane) * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl, acc, 0, 0, 0);
+            }
+            const int code = ct * 32 + ln;
+            if (dbg && code < L.Kpad) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float v = acc[r];
-                    if (dbg) {
-                        const int64_t rr = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (rr < N) dbg[(size_t)rr * L.Kpad + code] = v;
-                    }
-                    k1[r] = (v < m1[r]) ? code : k1[r];
-                    m2[r] = __builtin_amdgcn_fmed3f(v, m1[r], m2[r]);
-                    m1[r] = fminf(v, m1[r]);
+                    const int64_t rr = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (rr < N) dbg[(size_t)rr * L.Kpad + code] = acc[r];
                 }
             }
+            lq_track(acc, code, m1, m2, k1);
         }
-        if (st + 1 < nstage) stage_store((st + 1) & 1);
-        __syncthreads();
+    } else {
+        lq_screen_core<S, SCREEN_WAVES * 64>(ah, al, tiles, L.ntiles, lds, tid, m1, m2, k1);
     }
-
-    // ---- merge the 32 lanes of each half: global (min, argmin, second min) per row --------
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-#pragma unroll
-        for (int o = 1; o < 32; o <<= 1) {
-            const float om1 = __shfl_xor(m1[r], o, 64);
-            const float om2 = __shfl_xor(m2[r], o, 64);
-            const int ok1 = __shfl_xor(k1[r], o, 64);
-            const float hi = fmaxf(m1[r], om1);
-            m2[r] = fminf(fminf(m2[r], om2), hi);
-            const bool take = (om1 < m1[r]) || (om1 == m1[r] && ok1 < k1[r]);
-            k1[r] = take ? ok1 : k1[r];
-            m1[r] = fminf(m1[r], om1);
-        }
-    }
-    // hand row i's result to lane i (i < 32) through a small per-wave LDS scratch (after the last
-    // __syncthreads no wave touches the stage buffers again)
-    float* scr = reinterpret_cast<float*>(lds) + wave * 96;
-    if (ln == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-            scr[i] = m1[r];
-            scr[32 + i] = m2[r];
-            reinterpret_cast<int*>(scr)[64 + i] = k1[r];
-        }
-    }
-    __syncthreads();                              // every wave reaches this point (no early exit above)
-    int my_k = 0;
-    bool certified = false;
-    if (h == 0) {
-        const float a = scr[ln], b = scr[32 + ln];
-        my_k = reinterpret_cast<const int*>(scr)[64 + ln];
-        const float E2max = __uint_as_float(hdr[0]);
-        const float Emax = lq_sqrt(__uint_as_float(hdr[1]));
-        const float twoemax = __uint_as_float(hdr[2]);
-        const float cross = 2.0f * lq_sqrt(n2) * Emax;
-        // screening error + the rounding of the reference's own fp32 distance / square root (2^-20 of
-        // the largest full squared distance the row can see)
-        const float eps = gamma * (E2max + cross) + 9.5367431640625e-07f * (n2 + E2max + cross);
-        // fp16 range guard: -2e' must stay finite in fp16, else nothing is certified
-        certified = (twoemax < 60000.0f) && (b - a > 2.0f * eps) && (my_k < K);
-    }
-    // ---- outputs ---------------------------------------------------------------------------
+    lq_screen_merge(m1, m2, k1);
+    float* scr = reinterpret_cast<float*>(lds + 2 * C::STAGE_BYTES) + wave * 96;
+    int my_k;
+    const bool certified = lq_screen_decide(m1, m2, k1, scr, hdr, n2, gamma, K, lane, my_k);
     if (h == 0 && row < N) {
         if (certified) {
             idx[row] = (int64_t)my_k;
@@ -266,24 +189,11 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
             amb_list[slot] = (int)row;
         }
     }
-    if (zq) {
-        const int nvec = D / 4;
-        for (int rr = 0; rr < 32; rr += 4) {
-            const int src_lane = rr + (lane >> 4);
-            const int kk = __shfl(my_k, src_lane, 64);
-            const bool ok = __shfl((int)certified, src_lane, 64) != 0;
-            const int64_t orow = row0 + src_lane;
-            if (ok && orow < N) {
-                const float4* src = reinterpret_cast<const float4*>(cb + (size_t)kk * D);
-                float4* dst = reinterpret_cast<float4*>(zq + (size_t)orow * D);
-                for (int v = lane & 15; v < nvec; v += 16) dst[v] = src[v];
-            }
-        }
-    }
+    if (zq) lq_screen_gather(cb, zq, my_k, certified, row0, N, D, lane);
 }
 
 // ------------------------------------------------------------------------------------------
-// exact decision for the listed rows: 16 rows x 16 code slices per workgroup
+// exact decision for the listed rows: 4 rows x 64 code slices per workgroup
 // ------------------------------------------------------------------------------------------
 template <int DCH>
 __global__ __launch_bounds__(256) void nearest_rows_kernel(
@@ -291,12 +201,12 @@ __global__ __launch_bounds__(256) void nearest_rows_kernel(
     unsigned long long* __restrict__ usage, const int* __restrict__ row_list, const int* __restrict__ row_count,
     int K, int z_by_slot) {
     constexpr int D = DCH * 8;
-    __shared__ float s_v[16][16];
-    __shared__ float s_s[16][16];
-    __shared__ int s_k[16][16];
+    constexpr int RB = 4, SL = 64;               // rows per workgroup, code slices per row
+    __shared__ float s_v[RB][SL];
+    __shared__ int s_k[RB][SL];
     const int count = *row_count;
-    const int r = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  for (int base = blockIdx.x * 16; base < count; base += gridDim.x * 16) {
+    const int r = threadIdx.x & (RB - 1), sl = threadIdx.x / RB;
+  for (int base = blockIdx.x * RB; base < count; base += gridDim.x * RB) {
     const int slot = base + r;
     const bool valid = slot < count;
     const int cslot = valid ? slot : count - 1;
@@ -310,7 +220,7 @@ __global__ __launch_bounds__(256) void nearest_rows_kernel(
             zr[4 * i + 0] = v.x; zr[4 * i + 1] = v.y; zr[4 * i + 2] = v.z; zr[4 * i + 3] = v.w;
         }
     }
-    const int per = (K + 15) / 16;
+    const int per = (K + SL - 1) / SL;
     const int kb = sl * per, ke = (kb + per < K) ? kb + per : K;
     float best_v = INFINITY, best_s = INFINITY;
     int best_k = 0x7fffffff;
@@ -335,13 +245,13 @@ __global__ __launch_bounds__(256) void nearest_rows_kernel(
             if (v < best_v) { best_v = v; best_s = s; best_k = k; }
         }
     }
-    s_v[r][sl] = best_v; s_s[r][sl] = best_s; s_k[r][sl] = best_k;
+    s_v[r][sl] = best_v; s_k[r][sl] = best_k;
     __syncthreads();
     if (sl == 0 && valid) {
         // slices hold increasing code ranges: the first slice reaching the minimum root wins
         float bv = s_v[r][0];
         int bk = s_k[r][0];
-        for (int q = 1; q < 16; ++q)
+        for (int q = 1; q < SL; ++q)
             if (s_v[r][q] < bv) { bv = s_v[r][q]; bk = s_k[r][q]; }
         idx[row] = (int64_t)bk;
         if (usage) atomicAdd(&usage[bk], 1ull);
@@ -352,7 +262,7 @@ __global__ __launch_bounds__(256) void nearest_rows_kernel(
         const int bk = s_k[r][0];
         const float4* src = reinterpret_cast<const float4*>(cb + (size_t)bk * D);
         float4* dst = reinterpret_cast<float4*>(zq + (size_t)row * D);
-        for (int v = sl; v < D / 4; v += 16) dst[v] = src[v];
+        for (int v = sl; v < D / 4; v += SL) dst[v] = src[v];
     }
     __syncthreads();
   }
@@ -370,13 +280,11 @@ template <int S>
 static int launch_screen(const float* z, const unsigned char* prep, const float* cb, int64_t* idx, float* zq,
                          int64_t* usage, int* amb_list, int* amb_count, float* dbg, int64_t N, int K, int D,
                          float gamma, hipStream_t st) {
-    constexpr int TILE_BYTES = S * 2048 + 128;
-    constexpr int TC = (S <= 2) ? 8 : (S <= 4) ? 4 : (S <= 8) ? 2 : 1;
-    size_t lds = (size_t)2 * TC * TILE_BYTES;
-    if (lds < SCREEN_WAVES * 96 * sizeof(float)) lds = SCREEN_WAVES * 96 * sizeof(float);
+    using C = ScreenCfg<S>;
+    const size_t lds = (size_t)2 * C::STAGE_BYTES + SCREEN_WAVES * 96 * sizeof(float);
     const int64_t rows_per_block = SCREEN_WAVES * 32;
     unsigned blocks = (unsigned)((N + rows_per_block - 1) / rows_per_block);
-    auto kfn = screen_kernel<S>;
+    auto kfn = dbg ? screen_kernel<S, true> : screen_kernel<S, false>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(LIPVQ_EHIP, "screen: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
@@ -390,8 +298,8 @@ template <int DCH>
 static int launch_rows_t(const float* z, int z_by_slot, const float* cb, int64_t* idx, float* zq, int64_t* usage,
                          const int* amb_list, const int* amb_count, int64_t N, int K, hipStream_t st) {
     // the count lives on the device: a bounded grid strides over however many rows were listed
-    int64_t blocks = (N + 15) / 16;
-    if (blocks > 2048) blocks = 2048;
+    int64_t blocks = (N + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL((nearest_rows_kernel<DCH>), dim3((unsigned)blocks), dim3(256), 0, st, z, cb, idx, zq,
                        (unsigned long long*)usage, amb_list, amb_count, K, z_by_slot);
     return check_launch("nearest_rows");
