@@ -10,11 +10,12 @@ independent) and the per-step code-usage histogram [K] int64 is all-reduced over
 path's only cross-GPU dependency.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      dominant kernel (nearest code search = MFMA screen + exact re-scoring): algorithmic
-                2*K*D flop per row / mean duration measured with HIP events on its own stream,
-                against the dense fp16 MFMA peak (the screen's pipe; it executes 3 split products
-                per algorithmic product); `frac_of_fp32_peak` relates the same flops to the
-                157.3 TFLOP/s fp32 peak that SURVEY.md 8d prices the exact all-pairs scan against.
+  roofline      the fused tokenize launch: algorithmic flops per launch (164 736 flop
+                per row at config 2) / mean duration from HIP events on its stream, against the
+                blended matrix-pipe peak of its instruction mix (encoder on the fp32 MFMA pipe,
+                distance screen on the fp16 MFMA pipe with 3 split products per algorithmic
+                product); `frac_of_fp32_peak` relates the same flops to the 157.3 TFLOP/s fp32
+                peak that SURVEY.md 8d prices the exact all-pairs scan against.
   cpu_baseline  the torch-CPU restatement of the reference (oracle/lipvq_oracle.py,
                 kind="port"), timed on a bounded row sample on this box's host cores.
 """
@@ -122,17 +123,17 @@ def main():
     gx = torch.Generator(device="cpu").manual_seed(1234 + rank)
     x = torch.randn(B, T, A, generator=gx).to(dev).reshape(N, A)     # flattened as tensor_utils.py:1066-1067 does
 
-    codebook = model.quantizer.codebook.detach()
     usage = model.code_usage
     ev_pairs = []
 
     def step(timed):
-        # == LLFQVAE_V4.tokenize, with HIP events around the dominant kernel on its own stream
-        z_e = model.encode(x)
+        # == LLFQVAE_V4.tokenize: ONE fused launch (encoder + Lipschitz layer + MFMA screen, csrc/lipvq_fused.hip)
+        # followed by the exact kernel for the rows the screen could not certify.  HIP events bracket it
+        # on the stream it is launched on (torch's current stream is handed to the C ABI).
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        idx, zq = model._quantize(z_e, usage)        # MFMA screen + exact re-scoring (lipvq_screen.hip)
+        idx, zq = model.tokenize(x)
         if timed:
             e1.record()
             ev_pairs.append((e0, e1))
@@ -161,28 +162,42 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    near_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / max(1, len(ev_pairs))
+    tok_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / max(1, len(ev_pairs))
     value = world * N * args.steps / elapsed
-    algo_flop = 2.0 * N * K * D                       # 2*K*D per row for the distance term
-    achieved = algo_flop / (near_ms * 1e-3) / 1e12 if near_ms > 0 else 0.0
+    # algorithmic work per launch: encoder 2*(A*64+64*128+128*D) + distance 2*K*D flop per row
+    enc_flop = 2.0 * N * (A * 64 + 64 * 128 + 128 * D)
+    dist_flop = 2.0 * N * K * D
+    algo_flop = enc_flop + dist_flop
+    # the kernel executes the encoder on the fp32 matrix pipe (157.3 TF/s) and the distance screen on the
+    # fp16 matrix pipe with 3 split products per algorithmic product (2500 TF/s dense): its floor is the sum
+    # of both pipe times, and the peak it is priced against is the algorithmic flops over that floor
+    t_floor = enc_flop / (PEAK_FP32_TFLOPS * 1e12) + 3.0 * dist_flop / (PEAK_F16_MFMA_TFLOPS * 1e12)
+    peak_blend = algo_flop / t_floor / 1e12
+    achieved = algo_flop / (tok_ms * 1e-3) / 1e12 if tok_ms > 0 else 0.0
+    exact_rows = int(model.last_exact_rows[0]) if model.last_exact_rows is not None else None
+    traffic = None
+    tfile = ROOT / "profiles" / "hbm_traffic.json"           # PMC-derived bytes per launch (separate rocprofv3 --pmc runs)
+    if tfile.exists():
+        t = json.loads(tfile.read_text())
+        if t.get("workload") == args.workload:
+            traffic = t.get("bytes_per_launch")
     out = {
         "metric": "actions tokenized/sec (encode+quantize) at B=4096 T=128 K=1024, 1/2/4/8 GPU",
         "value": value, "unit": "actions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: B={B} T={T} action_dim={A} codebook K={K} d={D}, "
-                               f"fp32 encoder + fp32 argmin (parity mode), per-GPU batch fixed",
+                               f"fp32 encoder + fp32 argmin (parity mode: indices bit-identical to the CPU oracle), "
+                               f"per-GPU batch fixed",
                    "rows_per_gpu": N, "parallelism": f"batch-sharded x{world}, all-reduce of code usage [K] int64"},
-        # The nearest-code search runs its screening on the fp16 matrix pipe (3 split products per
-        # algorithmic product, fp32 accumulate) and finishes uncertified rows in exact fp32: the
-        # bounding pipe is the dense fp16 MFMA peak; the fraction of the fp32 peak the same
-        # algorithmic flops would represent is given beside it for comparison with SURVEY.md 8d.
-        "roofline": {"bound": "mfma", "kernel": "screen_kernel (+ nearest_rows_kernel for uncertified rows)",
-                     "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_F16_MFMA_TFLOPS, "traffic": None, "ms_per_launch": near_ms,
-                     "algorithmic_flop_per_launch": algo_flop, "executed_mfma_flop_per_launch": 3.0 * algo_flop,
+        "roofline": {"bound": "mfma", "kernel": "tokenize_kernel (+ nearest_rows_kernel for uncertified rows)",
+                     "achieved": achieved, "peak": peak_blend, "unit": "TFLOP/s", "frac": achieved / peak_blend,
+                     "traffic": traffic, "ms_per_launch": tok_ms, "algorithmic_flop_per_launch": algo_flop,
+                     "floor_ms": t_floor * 1e3,
+                     "peak_note": "algorithmic flop / (encoder flop / 157.3 TF/s fp32 MFMA + 3 x distance flop / 2500 TF/s fp16 MFMA)",
                      "frac_of_fp32_peak": achieved / PEAK_FP32_TFLOPS,
-                     "rows_decided_by_exact_kernel": int(model.last_exact_rows[0]) if model.last_exact_rows is not None else None},
+                     "algorithmic_bytes_per_launch": float(N) * (4 * A + 4 * D + 8),
+                     "rows_decided_by_exact_kernel": exact_rows},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, x, idx)

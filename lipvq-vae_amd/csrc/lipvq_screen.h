@@ -222,7 +222,7 @@ __device__ __forceinline__ bool lq_screen_decide(const float (&m1)[16], const fl
         // fp16 range guard: -2e' must stay finite in fp16, else nothing is certified
         certified = (twoemax < 60000.0f) && (b - a > 2.0f * eps) && (my_k < K);
 #ifdef LQ_ABL_CERT_ALL
-        certified = true; my_k = my_k < K ? (my_k < 0 ? 0 : my_k) : 0;
+        certified = true; my_k = (my_k >= 0 && my_k < K) ? my_k : (lane * 7) % K;
 #endif
     }
     return certified;

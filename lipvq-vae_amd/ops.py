@@ -290,7 +290,13 @@ def tokenize_supported(A, J0, J1, D, K) -> bool:
     return bool(lib.lipvq_tokenize_supported(int(A), int(J0), int(J1), int(D), int(K)))
 
 
-def tokenize(x, packed: PackedMlp3, codebook, prep: PreparedCodebook, usage=None, want_zq=True, want_ze=False):
+def tokenize_workspace(N: int, D: int, device) -> torch.Tensor:
+    """int32 workspace of lipvq_tokenize_f32 (row list + z_e scratch); callers may keep and reuse it."""
+    return torch.empty(max(16, (lib.lipvq_tokenize_workspace_bytes(N, D) + 3) // 4), device=device, dtype=torch.int32)
+
+
+def tokenize(x, packed: PackedMlp3, codebook, prep: PreparedCodebook, usage=None, want_zq=True, want_ze=False,
+             workspace=None):
     """(idx, zq, ze, workspace) of the fused encode + quantize launch (lipvq_tokenize_f32)."""
     x, codebook = _chk(x, "x"), _chk(codebook, "codebook")
     N, A = x.shape
@@ -303,7 +309,7 @@ def tokenize(x, packed: PackedMlp3, codebook, prep: PreparedCodebook, usage=None
     idx = torch.empty(N, device=dev, dtype=torch.int64)
     zq = torch.empty((N, D), device=dev, dtype=torch.float32) if want_zq else None
     ze = torch.empty((N, D), device=dev, dtype=torch.float32) if want_ze else None
-    ws = torch.empty(max(16, (lib.lipvq_tokenize_workspace_bytes(N, D) + 3) // 4), device=dev, dtype=torch.int32)
+    ws = workspace if workspace is not None else tokenize_workspace(N, D, dev)
     with torch.cuda.device(dev):
         check(lib.lipvq_tokenize_f32(_ptr(x), _ptr(packed.buf), _ptr(codebook), _ptr(prep.buf), _ptr(idx), _ptr(zq),
                                      _ptr(usage), _ptr(ze), _ptr(ws), N, A, packed.J0, packed.J1, D, K, _stream()),

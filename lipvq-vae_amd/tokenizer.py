@@ -169,7 +169,10 @@ class LLFQVAE_V4(_TokenizerBase):
             # one persistent launch: z_e never leaves registers (csrc/lipvq_fused.hip)
             packed, _, _ = self._packed_encoder()
             prep = self._cb_cache.get((self.quantizer.codebook,), lambda: ops.nearest_prepare(cb))
-            idx, zq, _, ws = ops.tokenize(x, packed, cb, prep, usage=usage)
+            key = (x.shape[0], x.device)
+            if getattr(self, "_tok_ws_key", None) != key:        # the scratch (row list + z_e) is reused across calls
+                self._tok_ws, self._tok_ws_key = ops.tokenize_workspace(x.shape[0], self.latent_dim, x.device), key
+            idx, zq, _, ws = ops.tokenize(x, packed, cb, prep, usage=usage, workspace=self._tok_ws)
             self.last_exact_rows = ws
         else:
             idx, zq = self._quantize(self.encode(x), usage)
