@@ -1,0 +1,101 @@
+"""CPU, world_size 2, gloo: the multi-rank host logic (sharding, usage all-reduce, flat gradient
+all-reduce).  The per-rank tokenizer here is the oracle (allowed in tests); on GPUs it is LLFQVAE_V4."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+WORLD = 2
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class _OracleTokenizer:
+    def __init__(self, p, K):
+        from oracle import lipvq_oracle as O
+        self.o, self.p = O.CanonicalOracle(), p
+        self.code_usage = torch.zeros(K, dtype=torch.int64)
+
+    def tokenize(self, x):
+        ze = self.o.llfq_encode(self.p, x.numpy())
+        idx, zq, usage = self.o.nearest(ze, self.p["quantizer.codebook"])
+        self.code_usage += torch.from_numpy(usage)
+        return torch.from_numpy(idx), torch.from_numpy(zq)
+
+
+def _worker(rank, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        import lipvq_vae_amd  # noqa: F401
+        from lipvq_vae_amd import sharded
+        from oracle import lipvq_oracle as O
+        A, D, K, B, T = 7, 32, 64, 9, 5            # B odd: ragged shards (5 + 4 sequences)
+        orc = O.CanonicalOracle()
+        p = O.make_params(21, A, D, K, oracle=orc)
+        x = torch.from_numpy(O.make_inputs(21, B * T, A)).reshape(B, T, A)
+        tok = _OracleTokenizer(p, K)
+        st = sharded.ShardedTokenizer(tok)
+        idx, z = st.tokenize(x)
+        s, e = sharded.shard_bounds(B, rank, WORLD)
+        assert idx.shape == (e - s, T) and z.shape == (e - s, T, D)
+        # gradients of the global-mean loss from per-shard gradients
+        xl = x[s:e].reshape(-1, A).numpy()
+        g_local = orc.llfq_grads(p, xl)
+        params = [torch.nn.Parameter(torch.from_numpy(p[k].copy())) for k in O.LLFQ_KEYS]
+        for prm, k in zip(params, O.LLFQ_KEYS):
+            prm.grad = torch.from_numpy(g_local[k].copy())
+        sharded.all_reduce_gradients(params, n_local=xl.shape[0], n_global=B * T)
+        np.savez(Path(out_dir) / f"rank{rank}.npz", idx=idx.numpy(), usage=tok.code_usage.numpy(),
+                 **{"g/" + k: prm.grad.numpy() for prm, k in zip(params, O.LLFQ_KEYS)})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharding_usage_and_gradients(tmp_path, oracle):
+    from oracle import lipvq_oracle as O
+    port = _free_port()
+    mp.spawn(_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    A, D, K, B, T = 7, 32, 64, 9, 5
+    p = O.make_params(21, A, D, K, oracle=oracle)
+    x = O.make_inputs(21, B * T, A)
+    full = oracle.llfq_forward(p, x)
+    # shards concatenate to the single-process result; the histogram is the global one on every rank
+    assert np.array_equal(np.concatenate([r0["idx"].reshape(-1), r1["idx"].reshape(-1)]), full["indices"])
+    assert np.array_equal(r0["usage"], full["usage"]) and np.array_equal(r1["usage"], full["usage"])
+    assert int(r0["usage"].sum()) == B * T
+    # weighted flat all-reduce == gradient of the loss over the whole batch, identical on both ranks
+    # (holds for every term that is a mean over rows; the codebook term too, since scatter-add is linear)
+    g_full = oracle.llfq_grads(p, x, fwd=full)
+    for k in O.LLFQ_KEYS:
+        assert np.array_equal(r0["g/" + k], r1["g/" + k]), k
+        scale = max(np.abs(g_full[k]).max(), 1e-12)
+        assert np.abs(r0["g/" + k] - g_full[k]).max() <= 1e-5 * scale, k
+
+
+def test_shard_bounds_cover_and_balance():
+    from lipvq_vae_amd.sharded import shard_batch, shard_bounds
+    for n in (0, 1, 7, 8, 4096, 4099):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - s for s, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+    x = torch.arange(2 * 3 * 4, dtype=torch.float32).reshape(2, 3, 4)
+    assert torch.equal(shard_batch(x, 1, 2), x[1].reshape(3, 4))
+    with pytest.raises(ValueError):
+        shard_bounds(4, 2, 2)
