@@ -36,4 +36,6 @@ if wl == "cfg2" or "--direct" in sys.argv:
     print(f"direct   : {timeit(lambda: ops.nearest(z, cb), 5):8.3f} ms")
 print(f"screened : {timeit(lambda: ops.nearest_screened(z, cb, prep)):8.3f} ms   (prepare {t_prep:.3f} ms)")
 print(f"encode   : {timeit(lambda: model.encode(x)):8.3f} ms")
-print(f"fused tokenize: {timeit(lambda: model.tokenize(x)):8.3f} ms  rows to exact: {int(model.last_exact_rows[0])}")
+import os
+cu = os.environ.get("LQ_NO_USAGE") is None
+print(f"fused tokenize: {timeit(lambda: model.tokenize(x, count_usage=cu)):8.3f} ms  rows to exact: {int(model.last_exact_rows[0])}")
