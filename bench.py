@@ -104,12 +104,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if os.environ.get("LIPVQ_BENCH_BACKEND", "nccl") != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+        # "nccl" is RCCL on ROCm.  LIPVQ_BENCH_BACKEND=gloo exists only to rehearse the multi-process
+        # flow on a box with fewer GPUs than ranks (ranks then share cuda:0).
+        backend = os.environ.get("LIPVQ_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import lipvq_vae_amd  # noqa: F401  (fails loudly if the HIP library is missing)
     from lipvq_vae_amd import ops
@@ -123,10 +131,20 @@ def main():
     gx = torch.Generator(device="cpu").manual_seed(1234 + rank)
     x = torch.randn(B, T, A, generator=gx).to(dev).reshape(N, A)     # flattened as tensor_utils.py:1066-1067 does
 
-    usage = model.code_usage
+    # two histograms: the all-reduce of step k runs asynchronously (RCCL's own stream) under step k+1
+    ubuf = [torch.zeros_like(model.code_usage), torch.zeros_like(model.code_usage)]
+    pending = [None, None]
     ev_pairs = []
+    step_no = [0]
 
     def step(timed):
+        b = step_no[0] & 1
+        step_no[0] += 1
+        if pending[b] is not None:
+            pending[b].wait()               # the stream waits for that reduction before the buffer is reused
+            pending[b] = None
+        ubuf[b].zero_()
+        model.code_usage = ubuf[b]
         # == LLFQVAE_V4.tokenize: ONE fused launch (encoder + Lipschitz layer + MFMA screen, csrc/lipvq_fused.hip)
         # followed by the exact kernel for the rows the screen could not certify.  HIP events bracket it
         # on the stream it is launched on (torch's current stream is handed to the C ABI).
@@ -138,7 +156,7 @@ def main():
             e1.record()
             ev_pairs.append((e0, e1))
         if dist is not None:
-            dist.all_reduce(usage)          # global code-usage histogram (8 KiB for K=1024)
+            pending[b] = dist.all_reduce(ubuf[b], async_op=True)   # global code-usage histogram (8 KiB for K=1024)
         return idx, zq
 
     def fence():
@@ -147,14 +165,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def drain():
+        for b in (0, 1):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
+
     for _ in range(args.warmup):
-        usage.zero_()
         step(False)
+    drain()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        usage.zero_()
         idx, zq = step(True)
+    drain()                                 # every histogram reduction is inside the timed region
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
