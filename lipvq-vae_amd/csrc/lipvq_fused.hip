@@ -16,10 +16,22 @@
 #include "lipvq_mlp.h"
 #include "lipvq_screen.h"
 
+#ifdef LQ_ABL_NOGELU            // ablation builds only (scripts/ablate.sh): wrong results, timing only
+#define FUSED_GELU(v) (v)
+#else
+#define FUSED_GELU(v) lq_gelu(v)
+#endif
+
+#ifndef FUSED_WAVES
 #define FUSED_WAVES 8
+#endif
 #define FUSED_THREADS (FUSED_WAVES * 64)
 // LDS budget: the D = 128 instance holds 105 KB of weights, so its codebook stages are one tile deep
+#ifdef LQ_OPT_TC
+constexpr int fused_tc(int S) { return (S <= 4) ? LQ_OPT_TC : 1; }
+#else
 constexpr int fused_tc(int S) { return (S <= 2) ? 8 : (S <= 4) ? 4 : 1; }
+#endif
 
 struct TokArgs {
     const float* x;              // [N][A]
@@ -124,7 +136,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
 #pragma unroll
             for (int t = 0; t < T0; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) h0[t][r] = lq_gelu(h0[t][r]);
+                for (int r = 0; r < 16; ++r) h0[t][r] = FUSED_GELU(h0[t][r]);
         }
         f32x16 h1[T1];
 #pragma unroll
@@ -141,7 +153,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, h0[(4 * sq + 3) / 16][(4 * sq + 3) % 16], acc, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) h1[t][r] = lq_gelu(acc[r]);
+            for (int r = 0; r < 16; ++r) h1[t][r] = FUSED_GELU(acc[r]);
         }
         f16x8 ah[S], al[S];
         float n2 = 0.0f;
@@ -174,6 +186,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
             // (low half's r >= 8 <-> high half's r < 8) leaves the low lane with features 32t .. 32t+15 and
             // the high lane with 32t+16 .. 32t+31, i.e. four 16-byte stores of consecutive floats per lane
             // (64 contiguous bytes per lane) instead of sixteen 4-byte stores scattered over the row.
+#ifndef LQ_ABL_NOZESTORE
             if (a.ze_out) {
                 float lo8[8], hi8[8];                 // after the swaps: lo8[j] = feature base + 2j, hi8[j] = base + 2j + 1
 #pragma unroll
@@ -193,6 +206,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
                     for (int q = 0; q < 4; ++q) dst[q] = make_float4(lo8[2 * q], hi8[2 * q], lo8[2 * q + 1], hi8[2 * q + 1]);
                 }
             }
+#endif
         }
         n2 += __shfl_xor(n2, 32, 64);
         // ================= phase B: MFMA screen (lq_screen_core, lipvq_screen.h) ==============

@@ -8,7 +8,7 @@
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-#define LIPVQ_SCREEN_GAMMA 7.62939453125e-06f   /* 2^-17 */
+#define LIPVQ_SCREEN_GAMMA 3.814697265625e-06f   /* 2^-18 */
 #define SCREEN_WAVES 8
 
 struct PrepLayout {
@@ -39,10 +39,15 @@ __host__ __device__ static inline PrepLayout prep_layout(int K, int D) {
 // tile and keeps, per accumulator register (= row) and lane (= code mod 32), the smallest d~, its
 // code, and the second smallest d~.
 //
-// The two waves of a SIMD are staggered by one tile's bookkeeping (see "Stagger" below): rocprofv3 PMC
-// before this change showed the matrix pipe 32 % busy with both waves in lockstep.
+// Measured variants that did NOT pay on this loop (A/B builds, scripts/ablate.sh): deferring half the waves'
+// bookkeeping by one tile (helped with register-staged copies, hurt once staging became DMA), reading B
+// fragments one tile ahead, sched_group_barrier interleaving, 3-4 waves per SIMD (spills).
 // ------------------------------------------------------------------------------------------
+#ifdef LQ_OPT_TC
+constexpr int screen_default_tc(int S) { return (S <= 4) ? LQ_OPT_TC : (S <= 8) ? 2 : 1; }
+#else
 constexpr int screen_default_tc(int S) { return (S <= 2) ? 8 : (S <= 4) ? 4 : (S <= 8) ? 2 : 1; }
+#endif
 
 template <int S, int TC_ = screen_default_tc(S)>
 struct ScreenCfg {
@@ -96,20 +101,6 @@ __device__ __forceinline__ void lq_screen_core(const f16x8 (&ah)[S], const f16x8
                                                  (lds_ptr_t)(dst + (size_t)(wbase + v * NT) * 16), 16, 0, 0);
         }
     };
-    // Stagger (MI355X_MICROARCH "Two waves per SIMD", item 9): the two waves that share a SIMD run the
-    // same program and would otherwise issue their MFMA chains -- and then their bookkeeping -- at the
-    // same time.  Waves 4..7 (the second wave of each SIMD) therefore book-keep tile t-1 BEFORE the
-    // chain of tile t (carrying one accumulator across stage barriers); waves 0..3 book-keep tile t
-    // right after its chain.  Same work, same results; the halves alternate between the two pipes.
-#ifdef LQ_OPT_NODEFER
-    const bool deferred = false;
-#else
-    const bool deferred = __builtin_amdgcn_readfirstlane(tid) >= NT / 2;
-#endif
-    f32x16 accP;                                  // deferred waves: tile whose bookkeeping is pending
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accP[r] = INFINITY;     // tracking +inf changes nothing
-    int codeP = 0;
     __syncthreads();                              // earlier readers of the stage buffers are done
     stage_dma(0, 0);
     __syncthreads();                              // (drains the DMA: hipcc waits vmcnt(0) before the barrier)
@@ -122,52 +113,55 @@ __device__ __forceinline__ void lq_screen_core(const f16x8 (&ah)[S], const f16x8
 #else
         const unsigned char* sb = stage0 + (size_t)(st & 1) * C::STAGE_BYTES;
 #endif
-        // B fragments are read one tile AHEAD of their use (2*S 16-byte LDS reads in flight under the
-        // previous tile's MFMA chain); read just in time, every 3-MFMA step sat behind ~100 cycles of
-        // LDS latency (ISA + SQ_WAIT counters, profiles/r01_c).
+#ifdef LQ_OPT_PREFETCH
+        // B fragments read one tile ahead of their use (2*S 16-byte LDS reads in flight under the previous chain)
         f16x8 bq[2][S][2];
         float e2q[2];
         auto frag_load = [&](int c, int slot) {
-            const unsigned char* tb = sb + (size_t)c * C::TILE_BYTES;
-            e2q[slot] = reinterpret_cast<const float*>(tb + S * 2048)[ln];
+            const unsigned char* tbq = sb + (size_t)c * C::TILE_BYTES;
+            e2q[slot] = reinterpret_cast<const float*>(tbq + S * 2048)[ln];
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                bq[slot][s][0] = *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 0) * 64 + lane) * 16);
-                bq[slot][s][1] = *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 1) * 64 + lane) * 16);
+                bq[slot][s][0] = *reinterpret_cast<const f16x8*>(tbq + (((size_t)s * 2 + 0) * 64 + lane) * 16);
+                bq[slot][s][1] = *reinterpret_cast<const f16x8*>(tbq + (((size_t)s * 2 + 1) * 64 + lane) * 16);
             }
         };
         frag_load(0, 0);
+#endif
 #pragma unroll
         for (int c = 0; c < C::TC; ++c) {
+            const unsigned char* tb = sb + (size_t)c * C::TILE_BYTES;
             const int code = (st * C::TC + c) * 32 + ln;
-#ifdef LQ_OPT_NOPREFETCH
-            if (c > 0) frag_load(c, c & 1);
-#else
+#ifdef LQ_OPT_PREFETCH
             if (c + 1 < C::TC) frag_load(c + 1, (c + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);            // keep the prefetch above the chain
+            __builtin_amdgcn_sched_barrier(0);
 #endif
-            if (deferred) lq_track(accP, codeP, m1, m2, k1);
+#ifdef LQ_OPT_PREFETCH
+            const float e2 = e2q[c & 1];
+#else
+            const float e2 = reinterpret_cast<const float*>(tb + S * 2048)[ln];
+#endif
             f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = e2q[c & 1];
+            for (int r = 0; r < 16; ++r) acc[r] = e2;
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bq[c & 1][s][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bq[c & 1][s][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bq[c & 1][s][1], acc, 0, 0, 0);
+#ifdef LQ_OPT_PREFETCH
+                const f16x8 bh = bq[c & 1][s][0], bl = bq[c & 1][s][1];
+#else
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 0) * 64 + lane) * 16);
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 1) * 64 + lane) * 16);
+#endif
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl, acc, 0, 0, 0);
             }
-            if (deferred) {
-                accP = acc;
-                codeP = code;
-            } else {
-                lq_track(acc, code, m1, m2, k1);
-            }
+            lq_track(acc, code, m1, m2, k1);
         }
 #ifndef LQ_ABL_NOBARRIER
         __syncthreads();
 #endif
     }
-    if (deferred) lq_track(accP, codeP, m1, m2, k1);
 }
 
 // merge the 32 lanes of each half: per row the global (min, argmin, second min)

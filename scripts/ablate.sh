@@ -1,13 +1,13 @@
 #!/bin/bash
-# Dev tool (GPU box): rebuild the library with parts of the screening kernels disabled and time each build.
-# Results of ablated builds are WRONG by construction; only the timings are of interest.
+# Dev tool (GPU box): rebuild the library with extra -D flags and time each build with scripts/measure_screen.py.
+# Usage: bash scripts/ablate.sh "<flags A>" "<flags B>" ...   (ablation builds may compute WRONG results by construction)
 set -e
 cd "$(dirname "$0")/.."
-export LQ_NO_USAGE=1
-for abl in "-DLQ_ABL_CERT_ALL" "-DLQ_ABL_CERT_ALL -DLQ_ABL_NOLOOP" "-DLQ_ABL_CERT_ALL -DLQ_ABL_NOLOOP -DLQ_ABL_NOMERGE -DLQ_ABL_NOGATHER" "-DLQ_ABL_CERT_ALL -DLQ_ABL_NOTRACK"; do
+BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-function"
+for abl in "$@"; do
   make -s -C lipvq-vae_amd/csrc clean
-  make -s -j8 -C lipvq-vae_amd/csrc FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-function $abl" 2>&1 | grep -E "error" || true
-  echo "=== ablation: [$abl]"
-  python scripts/measure_screen.py cfg2 2>&1 | grep -E "screened|fused" || true
+  make -s -j8 -C lipvq-vae_amd/csrc FLAGS="$BASE $abl" 2>&1 | grep -E "error" || true
+  echo "=== build: [$abl]"
+  python scripts/measure_screen.py cfg2 2>&1 | grep -E "equal|screened|fused" || true
 done
 make -s -C lipvq-vae_amd/csrc clean; make -s -j8 -C lipvq-vae_amd/csrc 2>&1 | grep error || true

@@ -7,7 +7,7 @@ import torch
 from oracle import lipvq_oracle as O
 
 pytestmark = pytest.mark.gpu
-GAMMA = 2.0 ** -17
+GAMMA = 2.0 ** -18
 
 
 def dev(a):
@@ -51,7 +51,7 @@ def test_screened_equals_oracle(ops, oracle, N, K, D):
 
 
 def test_error_bound_holds(ops):
-    """|d~ - d| measured against float64 stays below 1/16 of the bound the kernel uses."""
+    """|d~ - d| measured against float64 stays below 1/4 of the bound the kernel uses."""
     worst = 0.0
     for seed, (N, K, D, spread) in enumerate([(512, 1024, 64, 1.0), (256, 2048, 128, 1.0), (256, 512, 32, 1.0),
                                               (128, 1024, 208, 1.0), (512, 1024, 64, 0.2), (512, 1024, 64, 3.0)]):
@@ -67,7 +67,7 @@ def test_error_bound_holds(ops):
         bound = GAMMA * (e2max + 2.0 * np.sqrt((zc * zc).sum(1)) * np.sqrt(e2max))
         ratio = (np.abs(dt - d) / bound[:, None]).max()
         worst = max(worst, ratio)
-    assert worst < 1.0 / 16.0, f"screening error reached {worst:.3f} of its bound"
+    assert worst < 1.0 / 4.0, f"screening error reached {worst:.3f} of its bound"
 
 
 def test_gamma_extremes_still_exact(ops, oracle):

@@ -28,7 +28,7 @@ def test_erf_gelu(oracle):
     assert (np.abs(got) <= 1.0).all() and np.array_equal(got, -oracle.math_probe(-x, 1))
     g = oracle.math_probe(x, 2)
     gref = 0.5 * x.astype(np.float64) * (1 + special.erf(x.astype(np.float64) / np.sqrt(2)))
-    assert np.abs(g - gref).max() < 8e-7
+    assert np.abs(g - gref).max() < 8e-7           # measured 6e-7
     gg = oracle.math_probe(x, 5)
     xd = x.astype(np.float64)
     ggref = 0.5 * (1 + special.erf(xd / np.sqrt(2))) + xd * np.exp(-0.5 * xd * xd) / np.sqrt(2 * np.pi)
