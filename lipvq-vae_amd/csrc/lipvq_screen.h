@@ -9,7 +9,9 @@
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #define LIPVQ_SCREEN_GAMMA 3.814697265625e-06f   /* 2^-18 */
+#ifndef SCREEN_WAVES
 #define SCREEN_WAVES 8
+#endif
 
 struct PrepLayout {
     int S, Dpad, Kpad, ntiles;
@@ -39,9 +41,13 @@ __host__ __device__ static inline PrepLayout prep_layout(int K, int D) {
 // tile and keeps, per accumulator register (= row) and lane (= code mod 32), the smallest d~, its
 // code, and the second smallest d~.
 //
-// Measured variants that did NOT pay on this loop (A/B builds, scripts/ablate.sh): deferring half the waves'
-// bookkeeping by one tile (helped with register-staged copies, hurt once staging became DMA), reading B
-// fragments one tile ahead, sched_group_barrier interleaving, 3-4 waves per SIMD (spills).
+// Measured (same-box A/B builds, scripts/ablate.sh; LQ_ABL_* macros below are those timing-only builds):
+//  * the bare LDS-read + MFMA chain takes the same ~0.17 ms (cfg2) at 1, 2 or 4 waves per SIMD, with or without
+//    reading B fragments a tile ahead: it is the matrix pipe at ~1.2 PF/s executed (MFMA-dense clocks);
+//  * variants that did NOT pay: book-keeping tile t-1 between the MFMAs of tile t in the same wave (VALU issue
+//    delays the dependent chain; the SIMD's other wave already fills those slots), deferring half the waves by
+//    one tile (helped with register-staged copies, hurt once staging became DMA), sched_group_barrier, 3-4
+//    waves per SIMD in the fused kernel (spills).
 // ------------------------------------------------------------------------------------------
 #ifdef LQ_OPT_TC
 constexpr int screen_default_tc(int S) { return (S <= 4) ? LQ_OPT_TC : (S <= 8) ? 2 : 1; }
@@ -113,45 +119,18 @@ __device__ __forceinline__ void lq_screen_core(const f16x8 (&ah)[S], const f16x8
 #else
         const unsigned char* sb = stage0 + (size_t)(st & 1) * C::STAGE_BYTES;
 #endif
-#ifdef LQ_OPT_PREFETCH
-        // B fragments read one tile ahead of their use (2*S 16-byte LDS reads in flight under the previous chain)
-        f16x8 bq[2][S][2];
-        float e2q[2];
-        auto frag_load = [&](int c, int slot) {
-            const unsigned char* tbq = sb + (size_t)c * C::TILE_BYTES;
-            e2q[slot] = reinterpret_cast<const float*>(tbq + S * 2048)[ln];
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                bq[slot][s][0] = *reinterpret_cast<const f16x8*>(tbq + (((size_t)s * 2 + 0) * 64 + lane) * 16);
-                bq[slot][s][1] = *reinterpret_cast<const f16x8*>(tbq + (((size_t)s * 2 + 1) * 64 + lane) * 16);
-            }
-        };
-        frag_load(0, 0);
-#endif
 #pragma unroll
         for (int c = 0; c < C::TC; ++c) {
             const unsigned char* tb = sb + (size_t)c * C::TILE_BYTES;
             const int code = (st * C::TC + c) * 32 + ln;
-#ifdef LQ_OPT_PREFETCH
-            if (c + 1 < C::TC) frag_load(c + 1, (c + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifdef LQ_OPT_PREFETCH
-            const float e2 = e2q[c & 1];
-#else
             const float e2 = reinterpret_cast<const float*>(tb + S * 2048)[ln];
-#endif
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = e2;
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-#ifdef LQ_OPT_PREFETCH
-                const f16x8 bh = bq[c & 1][s][0], bl = bq[c & 1][s][1];
-#else
                 const f16x8 bh = *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 0) * 64 + lane) * 16);
                 const f16x8 bl = *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 1) * 64 + lane) * 16);
-#endif
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl, acc, 0, 0, 0);
