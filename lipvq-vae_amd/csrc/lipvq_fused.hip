@@ -68,8 +68,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
     float* w_P2 = w_B1 + 32 * T1;                                      // [T2][S2/4][64][4]
     float* w_B2 = w_P2 + T2 * (S2 / 4) * 256;
     float* w_mu = w_B2 + 32 * T2;                                      // [16*S]
-    float* scr_all = w_mu + 16 * S;                                    // [FUSED_WAVES][96]
-    unsigned char* stage0 = reinterpret_cast<unsigned char*>(scr_all + FUSED_WAVES * 96);
+    unsigned char* stage0 = reinterpret_cast<unsigned char*>(w_mu + 16 * S);   // 2 stage buffers (also the
+                                                                                // per-wave transpose slices of the decision)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ln = lane & 31, h = lane >> 5;
@@ -215,9 +215,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { m1[r] = INFINITY; m2[r] = INFINITY; k1[r] = 0; }
         lq_screen_core<S, FUSED_THREADS, fused_tc(S)>(ah, al, tiles, L.ntiles, stage0, tid, m1, m2, k1);
-        lq_screen_merge(m1, m2, k1);
         int my_k;
-        const bool certified = lq_screen_decide(m1, m2, k1, scr_all + wave * 96, hdr, n2, a.gamma, a.K, lane, my_k);
+        const bool certified = lq_screen_decide(m1, m2, k1, stage0 + (size_t)wave * 4096, hdr, n2, a.gamma, a.K, lane, my_k);
         if (h == 0 && row < a.N) {
             if (certified) {
                 a.idx[row] = (int64_t)my_k;
@@ -234,8 +233,7 @@ template <int S>
 static size_t fused_lds_bytes(int A) {
     constexpr int T0 = 2, T1 = 4, T2 = S / 2;
     const int S0q = ((A + 1) / 2 + 3) / 4;
-    size_t fl = (size_t)T0 * S0q * 256 + 32 * T0 + (size_t)T1 * 8 * 256 + 32 * T1 + (size_t)T2 * 16 * 256 + 32 * T2 + 16 * S +
-                FUSED_WAVES * 96;
+    size_t fl = (size_t)T0 * S0q * 256 + 32 * T0 + (size_t)T1 * 8 * 256 + 32 * T1 + (size_t)T2 * 16 * 256 + 32 * T2 + 16 * S;
     return fl * sizeof(float) + 2 * (size_t)ScreenCfg<S, fused_tc(S)>::STAGE_BYTES;
 }
 

@@ -29,6 +29,4 @@ __host__ __device__ static inline PackedLayout packed_layout(int K0, int J0, int
     return L;
 }
 
-int lipvq_mlp3_listed(const float* x, const int* list, const int* count, const float* packed, float* y, int64_t N,
-                      int K0, int J0, int J1, int J2, int act0, int act1, int act2, hipStream_t st);
 #endif

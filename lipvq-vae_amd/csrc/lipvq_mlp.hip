@@ -107,8 +107,6 @@ struct Mlp3Args {
     int64_t N;
     int K0, J0, J1, J2;          // widths of THIS chain (bwd: J2, J1, J0, K0 of the forward stack)
     int act0, act1, act2, act_in;
-    const int* gather_idx32;     // optional int32 row list (used with n_rows_dev by the fused tokenizer)
-    const int* n_rows_dev;       // optional: number of rows lives on the device (N is then the upper bound)
 };
 
 template <int T0, int T1, bool BWD>
@@ -122,18 +120,16 @@ __global__ __launch_bounds__(256) void mlp3_kernel(Mlp3Args a) {
     const float* __restrict__ B2 = a.packed + L.oB2;
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5;
-    const int64_t Neff = a.n_rows_dev ? (int64_t)(*a.n_rows_dev) : a.N;
-    const int64_t ntiles = (Neff + 31) / 32;
+    const int64_t ntiles = (a.N + 31) / 32;
     const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
 
     for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
         const int64_t row = tile * 32 + (lane & 31);
-        const bool valid = row < Neff;
-        const int64_t rowc = valid ? row : Neff - 1;
+        const bool valid = row < a.N;
+        const int64_t rowc = valid ? row : a.N - 1;
         const float* __restrict__ xr =
-            a.gather_idx ? a.x + (size_t)a.gather_idx[rowc] * a.K0
-                         : a.gather_idx32 ? a.x + (size_t)a.gather_idx32[rowc] * a.K0 : a.x + (size_t)rowc * a.K0;
+            a.gather_idx ? a.x + (size_t)a.gather_idx[rowc] * a.K0 : a.x + (size_t)rowc * a.K0;
 
         // ---- layer 0: K0 -> 32*T0 ------------------------------------------------------
         f32x16 acc0[T0];
@@ -269,21 +265,8 @@ extern "C" int lipvq_mlp3_f32(const float* x, const int64_t* gather_idx, const f
     mlp3_fn fn = mlp3_select<false>(J0 / 32, J1 / 32);
     if (!fn) return fail(LIPVQ_EUNSUPPORTED, "mlp3: no kernel instance for hidden widths %d,%d", J0, J1);
     Mlp3Args a{x, gather_idx, packed, y, pre0, pre1, pre2, nullptr, nullptr, nullptr,
-               N, K0, J0, J1, J2, act0, act1, act2, LIPVQ_ACT_NONE, nullptr, nullptr};
+               N, K0, J0, J1, J2, act0, act1, act2, LIPVQ_ACT_NONE};
     return launch_mlp3(fn, a, (hipStream_t)stream, "mlp3");
-}
-
-// internal (lipvq_fused.hip): y[i] = mlp3(x[list[i]]) for i < *count (count <= N lives on the device)
-int lipvq_mlp3_listed(const float* x, const int* list, const int* count, const float* packed, float* y, int64_t N,
-                      int K0, int J0, int J1, int J2, int act0, int act1, int act2, hipStream_t st) {
-    mlp3_fn fn = mlp3_select<false>(J0 / 32, J1 / 32);
-    if (!fn) return fail(LIPVQ_EUNSUPPORTED, "mlp3_listed: no kernel instance for hidden widths %d,%d", J0, J1);
-    Mlp3Args a{x, nullptr, packed, y, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-               N, K0, J0, J1, J2, act0, act1, act2, LIPVQ_ACT_NONE, list, count};
-    int64_t blocks = (N + 127) / 128;
-    if (blocks > 256) blocks = 256;                 // the listed rows are few: a small grid strides over them
-    hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(256), 0, st, a);
-    return check_launch("mlp3_listed");
 }
 
 extern "C" int lipvq_mlp3_bwd_f32(const float* gy, const float* pre0, const float* pre1, const float* pre2,
@@ -299,6 +282,6 @@ extern "C" int lipvq_mlp3_bwd_f32(const float* gy, const float* pre0, const floa
     mlp3_fn fn = mlp3_select<true>(J1 / 32, J0 / 32);
     if (!fn) return fail(LIPVQ_EUNSUPPORTED, "mlp3_bwd: no kernel instance for hidden widths %d,%d", J0, J1);
     Mlp3Args a{gy, nullptr, packed_bwd, gx, g1, g0, g2, (act2 != LIPVQ_ACT_NONE) ? pre2 : nullptr, pre1, pre0,
-               N, J2, J1, J0, K0, act1, act0, LIPVQ_ACT_NONE, act2, nullptr, nullptr};
+               N, J2, J1, J0, K0, act1, act0, LIPVQ_ACT_NONE, act2};
     return launch_mlp3(fn, a, (hipStream_t)stream, "mlp3_bwd");
 }

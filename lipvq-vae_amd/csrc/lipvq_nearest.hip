@@ -12,16 +12,13 @@
 template <int DCH, int DIST>
 __global__ __launch_bounds__(256) void nearest_direct_kernel(
     const float* __restrict__ z, const float* __restrict__ cb, int64_t* __restrict__ idx,
-    float* __restrict__ zq, unsigned long long* __restrict__ usage, float* __restrict__ best_out,
-    const int* __restrict__ row_list, const int* __restrict__ row_count, int64_t N, int K, int KT) {
+    float* __restrict__ zq, unsigned long long* __restrict__ usage, float* __restrict__ best_out, int64_t N, int K,
+    int KT) {
     constexpr int D = DCH * 8;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    int64_t nrows = row_list ? (int64_t)(*row_count) : N;
-    int64_t base = (int64_t)blockIdx.x * blockDim.x;
-    if (base >= nrows) return;
-    int64_t slot = base + threadIdx.x;
-    const bool valid = slot < nrows;
-    int64_t row = valid ? (row_list ? (int64_t)row_list[slot] : slot) : (row_list ? (int64_t)row_list[nrows - 1] : nrows - 1);
+    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = slot < N;
+    const int64_t row = valid ? slot : N - 1;
 
     float zr[D];
     {
@@ -143,10 +140,10 @@ static int launch_nearest_direct(const float* z, const float* cb, int64_t* idx, 
     unsigned blocks = (unsigned)((N + 255) / 256);
     if (dist == LIPVQ_DIST_NORM)
         hipLaunchKernelGGL((nearest_direct_kernel<DCH, LIPVQ_DIST_NORM>), dim3(blocks), dim3(256), lds, st,
-                           z, cb, idx, zq, (unsigned long long*)usage, best, nullptr, nullptr, N, K, KT);
+                           z, cb, idx, zq, (unsigned long long*)usage, best, N, K, KT);
     else
         hipLaunchKernelGGL((nearest_direct_kernel<DCH, LIPVQ_DIST_SQSUM>), dim3(blocks), dim3(256), lds, st,
-                           z, cb, idx, zq, (unsigned long long*)usage, best, nullptr, nullptr, N, K, KT);
+                           z, cb, idx, zq, (unsigned long long*)usage, best, N, K, KT);
     return check_launch("nearest_direct");
 }
 

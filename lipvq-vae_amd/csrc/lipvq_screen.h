@@ -143,61 +143,90 @@ __device__ __forceinline__ void lq_screen_core(const f16x8 (&ah)[S], const f16x8
     }
 }
 
-// merge the 32 lanes of each half: per row the global (min, argmin, second min)
-__device__ __forceinline__ void lq_screen_merge(float (&m1)[16], float (&m2)[16], int (&k1)[16]) {
-#ifdef LQ_ABL_NOMERGE
-    return;
-#endif
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-#pragma unroll
-        for (int o = 1; o < 32; o <<= 1) {
-            const float om1 = __shfl_xor(m1[r], o, 64);
-            const float om2 = __shfl_xor(m2[r], o, 64);
-            const int ok1 = __shfl_xor(k1[r], o, 64);
-            const float hi = fmaxf(m1[r], om1);
-            m2[r] = fminf(fminf(m2[r], om2), hi);
-            const bool take = (om1 < m1[r]) || (om1 == m1[r] && ok1 < k1[r]);
-            k1[r] = take ? ok1 : k1[r];
-            m1[r] = fminf(m1[r], om1);
-        }
-    }
-}
-
-// row i's (m1, m2, k1) -> lane i (i < 32) through a 96-float per-wave LDS scratch; then the decision.
-// Returns certified; my_k valid in lanes < 32.
+// After the last tile: per row, the global (smallest, its code, second smallest) over the 32 lanes of the
+// half-wave that holds the row -- and the certification decision.
+//
+// The 16 x 3 per-lane values are TRANSPOSED through LDS (each wave uses a 4 KiB slice of the stage buffers,
+// which are idle between the loop's last barrier and the next block's first DMA): value of (row i, lane l) goes
+// to [i][l]; then lane L (row L & 31, part L >> 5) reads the 16 entries [row][16*part ..] with four 16-byte
+// reads, reduces them in registers, and one xor-32 shuffle joins the two parts.  ~170 instructions per
+// 32-row tile instead of ~720 for a 5-step shuffle butterfly over 16 registers x 3 values (ablation: the
+// butterfly + its LDS hand-off cost 46 us of a 350 us launch), and no workgroup barrier.
+// Returns certified (valid in every lane, duplicated across the halves); my_k = the row's code.
 __device__ __forceinline__ bool lq_screen_decide(const float (&m1)[16], const float (&m2)[16], const int (&k1)[16],
-                                                 float* scr, const unsigned* hdr, float n2, float gamma, int K,
-                                                 int lane, int& my_k) {
+                                                 unsigned char* wave_lds /* 4 KiB, this wave only */,
+                                                 const unsigned* hdr, float n2, float gamma, int K, int lane,
+                                                 int& my_k) {
     const int ln = lane & 31, h = lane >> 5;
-    if (ln == 0) {
+    float* tv = reinterpret_cast<float*>(wave_lds);           // [32 rows][32 lanes], reused by the three passes
+    // ---- pass 1: m1 -> best value, its position among my 16 entries, second smallest m1 ----------------------
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-            scr[i] = m1[r];
-            scr[32 + i] = m2[r];
-            reinterpret_cast<int*>(scr)[64 + i] = k1[r];
+    for (int r = 0; r < 16; ++r) tv[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + ln] = m1[r];
+    __builtin_amdgcn_s_waitcnt(0xC07F);                       // lgkmcnt(0): this wave's LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+    float best = INFINITY, second = INFINITY;
+    int pos = 0;
+    {
+        const float4* pv = reinterpret_cast<const float4*>(tv + ln * 32 + 16 * h);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v4 = pv[q];
+            const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool take = vv[e] < best;       // equal minima need no tie-break: second == best then, the
+                second = __builtin_amdgcn_fmed3f(vv[e], best, second);   // row is not certified and the exact
+                pos = take ? 4 * q + e : pos;                             // kernel decides it
+                best = take ? vv[e] : best;
+            }
         }
     }
-    __syncthreads();                              // every wave reaches this point (no early exit in callers)
-    bool certified = false;
-    my_k = 0;
-    if (h == 0) {
-        const float a = scr[ln], b = scr[32 + ln];
-        my_k = reinterpret_cast<const int*>(scr)[64 + ln];
-        const float E2max = __uint_as_float(hdr[0]);
-        const float Emax = lq_sqrt(__uint_as_float(hdr[1]));
-        const float twoemax = __uint_as_float(hdr[2]);
-        const float cross = 2.0f * lq_sqrt(n2) * Emax;
-        // screening error + the rounding of the reference's own fp32 distance / square root (2^-20 of
-        // the largest full squared distance the row can see)
-        const float eps = gamma * (E2max + cross) + 9.5367431640625e-07f * (n2 + E2max + cross);
-        // fp16 range guard: -2e' must stay finite in fp16, else nothing is certified
-        certified = (twoemax < 60000.0f) && (b - a > 2.0f * eps) && (my_k < K);
-#ifdef LQ_ABL_CERT_ALL
-        certified = true; my_k = (my_k >= 0 && my_k < K) ? my_k : (lane * 7) % K;
-#endif
+    __builtin_amdgcn_wave_barrier();                          // pass-1 reads are issued before pass 2 overwrites
+    // ---- pass 2: k1 -> the code at that position ------------------------------------------------------------
+    int* tk = reinterpret_cast<int*>(wave_lds);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tk[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + ln] = k1[r];
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    int bk = tk[ln * 32 + 16 * h + pos];
+    __builtin_amdgcn_wave_barrier();
+    // ---- pass 3: m2 -----------------------------------------------------------------------------------------
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tv[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + ln] = m2[r];
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    {
+        const float4* pv = reinterpret_cast<const float4*>(tv + ln * 32 + 16 * h);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v4 = pv[q];
+            second = fminf(second, fminf(fminf(v4.x, v4.y), fminf(v4.z, v4.w)));
+        }
     }
+    // ---- join the two 16-lane parts of the row ---------------------------------------------------------------
+    {
+        const float ob = __shfl_xor(best, 32, 64);
+        const float os = __shfl_xor(second, 32, 64);
+        const int ok = __shfl_xor(bk, 32, 64);
+        second = fminf(fminf(second, os), fmaxf(best, ob));
+        const bool take = ob < best;
+        bk = take ? ok : bk;
+        best = take ? ob : best;
+    }
+    __builtin_amdgcn_wave_barrier();
+    my_k = bk;
+    const float E2max = __uint_as_float(hdr[0]);
+    const float Emax = lq_sqrt(__uint_as_float(hdr[1]));
+    const float twoemax = __uint_as_float(hdr[2]);
+    const float cross = 2.0f * lq_sqrt(n2) * Emax;
+    // screening error + the rounding of the reference's own fp32 distance / square root (2^-20 of the largest
+    // full squared distance the row can see)
+    const float eps = gamma * (E2max + cross) + 9.5367431640625e-07f * (n2 + E2max + cross);
+    // fp16 range guard: -2e' must stay finite in fp16, else nothing is certified
+    bool certified = (twoemax < 60000.0f) && (second - best > 2.0f * eps) && (bk >= 0) && (bk < K);
+#ifdef LQ_ABL_CERT_ALL
+    certified = true; my_k = (my_k >= 0 && my_k < K) ? my_k : (lane * 7) % K;
+#endif
     return certified;
 }
 

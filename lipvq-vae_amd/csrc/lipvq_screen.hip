@@ -177,10 +177,8 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
     } else {
         lq_screen_core<S, SCREEN_WAVES * 64>(ah, al, tiles, L.ntiles, lds, tid, m1, m2, k1);
     }
-    lq_screen_merge(m1, m2, k1);
-    float* scr = reinterpret_cast<float*>(lds + 2 * C::STAGE_BYTES) + wave * 96;
     int my_k;
-    const bool certified = lq_screen_decide(m1, m2, k1, scr, hdr, n2, gamma, K, lane, my_k);
+    const bool certified = lq_screen_decide(m1, m2, k1, lds + (size_t)wave * 4096, hdr, n2, gamma, K, lane, my_k);
     if (h == 0 && row < N) {
         if (certified) {
             idx[row] = (int64_t)my_k;
@@ -282,7 +280,8 @@ static int launch_screen(const float* z, const unsigned char* prep, const float*
                          int64_t* usage, int* amb_list, int* amb_count, float* dbg, int64_t N, int K, int D,
                          float gamma, hipStream_t st) {
     using C = ScreenCfg<S>;
-    const size_t lds = (size_t)2 * C::STAGE_BYTES + SCREEN_WAVES * 96 * sizeof(float);
+    size_t lds = (size_t)2 * C::STAGE_BYTES;
+    if (lds < (size_t)SCREEN_WAVES * 4096) lds = (size_t)SCREEN_WAVES * 4096;      // per-wave transpose slices reuse the stages
     const int64_t rows_per_block = SCREEN_WAVES * 32;
     unsigned blocks = (unsigned)((N + rows_per_block - 1) / rows_per_block);
     auto kfn = dbg ? screen_kernel<S, true> : screen_kernel<S, false>;
