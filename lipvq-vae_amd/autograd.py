@@ -122,3 +122,40 @@ def vq_forward(module, x):
         return _VQFn.apply(module, x, *params)
     with torch.no_grad():
         return _VQFn.forward(_NoCtx(len(params)), module, x, *params)
+
+
+# ---------------------------------------------------------------------------------------------------
+# engine-free forward + backward (used under HIP-graph capture, where the autograd engine's per-parameter
+# AccumulateGrad nodes -- bound to whatever stream first produced a gradient -- must stay out of the way)
+# ---------------------------------------------------------------------------------------------------
+
+class _ManualCtx:
+    def __init__(self, n):
+        self.needs_input_grad = (False, False) + (True,) * n
+        self.saved_tensors = ()
+        self.module = None
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def mark_non_differentiable(self, *a):
+        pass
+
+
+def forward_backward(module, x):
+    """(z_latent, loss, params, grads) with grads = dloss/dparams computed by the library's backward kernels,
+    without touching torch.autograd.  params are in the order of the returned gradients."""
+    from .backward import llfq_backward, vq_backward
+    from .tokenizer import LLFQVAE_V4
+    with torch.no_grad():
+        if isinstance(module, LLFQVAE_V4):
+            params = (*module._enc_params(), module.quantizer.codebook, *module._dec_params())
+            ctx = _ManualCtx(len(params))
+            z, loss = _LLFQFn.forward(ctx, module, x, *params)
+            grads = llfq_backward(module, ctx.saved_tensors, torch.ones((), device=x.device, dtype=x.dtype))
+        else:
+            params = (*module._enc_params(), *module._dec_params(), module.embedding.weight)
+            ctx = _ManualCtx(len(params))
+            z, loss = _VQFn.forward(ctx, module, x, *params)
+            grads = vq_backward(module, ctx.saved_tensors, torch.ones((), device=x.device, dtype=x.dtype))
+    return z, loss, params, grads

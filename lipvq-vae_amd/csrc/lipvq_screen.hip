@@ -27,14 +27,19 @@ extern "C" size_t lipvq_nearest_prep_bytes(int K, int D) {
     return prep_layout(K, D).total;
 }
 
-// column means (double accumulation), one thread per dimension
-__global__ void prep_mean_kernel(const float* __restrict__ cb, float* __restrict__ mu, int K, int D, int Dpad) {
-    int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= Dpad) return;
+// column means: 64 columns x 4 row groups per workgroup, double accumulation in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void prep_mean_kernel(const float* __restrict__ cb, float* __restrict__ mu, int K, int D,
+                                                        int Dpad) {
+    __shared__ double part[4][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int d = blockIdx.x * 64 + c;
     double s = 0.0;
     if (d < D)
-        for (int k = 0; k < K; ++k) s += (double)cb[(size_t)k * D + d];
-    mu[d] = (d < D) ? (float)(s / (double)K) : 0.0f;
+        for (int k = g; k < K; k += 4) s += (double)cb[(size_t)k * D + d];
+    part[g][c] = s;
+    __syncthreads();
+    if (g == 0 && d < Dpad)
+        mu[d] = (d < D) ? (float)((((part[0][c] + part[1][c]) + part[2][c]) + part[3][c]) / (double)K) : 0.0f;
 }
 
 // one thread per (code, step, half): 8 centred, -2-scaled elements -> fp16 hi/lo fragments
@@ -92,7 +97,7 @@ extern "C" int lipvq_nearest_prepare_f32(const float* codebook, void* prep, int 
     hipError_t e = hipMemsetAsync(base, 0, 64, st);
     if (e != hipSuccess) return fail(LIPVQ_EHIP, "nearest_prepare: %s", hipGetErrorString(e));
     float* mu = (float*)(base + L.o_mu);
-    hipLaunchKernelGGL(prep_mean_kernel, dim3((L.Dpad + 63) / 64), dim3(64), 0, st, codebook, mu, K, D, L.Dpad);
+    hipLaunchKernelGGL(prep_mean_kernel, dim3((L.Dpad + 63) / 64), dim3(256), 0, st, codebook, mu, K, D, L.Dpad);
     size_t n = (size_t)L.ntiles * 32 * L.S * 2;
     hipLaunchKernelGGL(prep_frag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, codebook, mu,
                        base + L.o_tiles, K, D, L);
@@ -222,7 +227,8 @@ __global__ __launch_bounds__(256) void nearest_rows_kernel(
     const int per = (K + SL - 1) / SL;
     const int kb = sl * per, ke = (kb + per < K) ? kb + per : K;
     float best_v = INFINITY, best_s = INFINITY;
-    int best_k = 0x7fffffff;
+    int best_k = kb < K ? kb : 0;            // always a valid code, even if every distance is NaN (torch.argmin
+                                             // of an all-NaN row is unspecified; an out-of-range index is not an option)
     for (int k = kb; k < ke; ++k) {
         const float4* c4 = reinterpret_cast<const float4*>(cb + (size_t)k * D);
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;

@@ -42,3 +42,22 @@ def test_action_branch_training_loop_tracks_reference(oracle):
         # 4 AdamW steps move each weight by <= 4e-3; trajectories agree to a small fraction of that
         close = np.isclose(got, ref, rtol=0, atol=2e-5).mean()
         assert close > 0.995, (k, close)
+
+
+def test_engine_free_forward_backward_equals_autograd(oracle):
+    """autograd.forward_backward (no torch.autograd involved) returns the gradients loss.backward() produces."""
+    from lipvq_vae_amd.autograd import forward_backward
+    from lipvq_vae_amd.tokenizer import LLFQVAE_V4, VQVAE
+    for cls, variant, kw in ((LLFQVAE_V4, "llfq", dict(num_codes=256)), (VQVAE, "vq", dict(num_embeddings=256))):
+        A, D, N = 12, 64, 300
+        p = O.make_params(41, A, D, 256, variant=variant, oracle=oracle)
+        m = cls(A, D, **kw).cuda()
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in p.items()})
+        x = torch.from_numpy(O.make_inputs(41, N, A)).cuda()
+        z, loss, params, grads = forward_backward(m, x)
+        z2, loss2 = m(x)
+        loss2.backward()
+        assert torch.equal(z, z2) and torch.equal(loss, loss2.detach())
+        for prm, g in zip(params, grads):
+            scale = float(prm.grad.abs().max()) + 1e-12
+            assert float((prm.grad - g).abs().max()) <= 1e-5 * scale      # codebook scatter-add uses float atomics
