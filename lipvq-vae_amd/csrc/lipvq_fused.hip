@@ -156,7 +156,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
             for (int r = 0; r < 16; ++r) h1[t][r] = FUSED_GELU(acc[r]);
         }
         f16x8 ah[S], al[S];
-        float n2 = 0.0f;
+        float n2 = 0.0f, amax = 0.0f;
+        f32x16 zc[T2];                   // centred z_e (fp32) until the row's scale is known
 #pragma unroll
         for (int t = 0; t < T2; ++t) {
             f32x16 acc;
@@ -174,12 +175,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const float zv = lq_sigmoid(acc[r]);
                 acc[r] = zv;
-                // register r of tile t is feature 32t + 2r + h = screen slot (step 2t + (r >> 3), element r & 7)
                 const float v = zv - w_mu[32 * t + 2 * r + h];
-                const _Float16 vh = (_Float16)v;
-                ah[2 * t + (r >> 3)][r & 7] = vh;
-                al[2 * t + (r >> 3)][r & 7] = (_Float16)(v - (float)vh);
+                zc[t][r] = v;
                 n2 = lq_fma(v, v, n2);
+                amax = fmaxf(amax, lq_abs(v));
             }
             // z_e row store.  Lane (n, h) holds features 32t + 2r + h (r = 0..15) of row n: the even ones in
             // the low half-wave, the odd ones in the high half.  One v_permlane32_swap per register pair
@@ -209,14 +208,30 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
 #endif
         }
         n2 += __shfl_xor(n2, 32, 64);
+        amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+        const int sz = lq_scale_exp(amax);                    // block floating point: see lipvq_screen.h
+        const float fz = lq_pow2f(sz);
+        const float fown = lq_pow2f(sz + (int)hdr[3]);
+#pragma unroll
+        for (int t = 0; t < T2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // register r of tile t is feature 32t + 2r + h = screen slot (step 2t + (r >> 3), element r & 7)
+                const float v = zc[t][r] * fz;
+                const _Float16 vh = (_Float16)v;
+                ah[2 * t + (r >> 3)][r & 7] = vh;
+                al[2 * t + (r >> 3)][r & 7] = (_Float16)(v - (float)vh);
+            }
+        float frow[16];
+        lq_row_factors(fown, lane, frow);
         // ================= phase B: MFMA screen (lq_screen_core, lipvq_screen.h) ==============
         float m1[16], m2[16];
         int k1[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { m1[r] = INFINITY; m2[r] = INFINITY; k1[r] = 0; }
-        lq_screen_core<S, FUSED_THREADS, fused_tc(S)>(ah, al, tiles, L.ntiles, stage0, tid, m1, m2, k1);
+        lq_screen_core<S, FUSED_THREADS, fused_tc(S)>(ah, al, tiles, L.ntiles, stage0, tid, frow, m1, m2, k1);
         int my_k;
-        const bool certified = lq_screen_decide(m1, m2, k1, stage0 + (size_t)wave * 4096, hdr, n2, a.gamma, a.K, lane, my_k);
+        const bool certified = lq_screen_decide(m1, m2, k1, stage0 + (size_t)wave * 4096, hdr, n2, fown, a.gamma, a.K, lane, my_k);
         if (h == 0 && row < a.N) {
             if (certified) {
                 a.idx[row] = (int64_t)my_k;

@@ -24,7 +24,7 @@ __host__ __device__ static inline PrepLayout prep_layout(int K, int D) {
     L.Dpad = L.S * 16;
     L.Kpad = ((K + 31) / 32) * 32;
     L.ntiles = ((L.Kpad / 32 + 7) / 8) * 8;   // whole LDS stages: pad tiles carry e2 = +inf, zero fragments
-    L.o_hdr = 0;                       // 16 floats: [0] E2max bits, [1] Emax^2 bits, [2] max|2e'| bits
+    L.o_hdr = 0;                       // 16 words: [0] E2max bits, [1] Emax^2 bits, [2] max|2e'| bits, [3] se (int)
     L.o_mu = 64;
     L.o_tiles = L.o_mu + sizeof(float) * (size_t)L.Dpad;
     L.o_tiles = (L.o_tiles + 255) & ~(size_t)255;
@@ -49,6 +49,23 @@ __host__ __device__ static inline PrepLayout prep_layout(int K, int D) {
 //    one tile (helped with register-staged copies, hurt once staging became DMA), sched_group_barrier, 3-4
 //    waves per SIMD in the fused kernel (spills).
 // ------------------------------------------------------------------------------------------
+// Block floating point for the fp16 split (tests/test_gpu_screen.py::test_any_magnitude):  x = hi + lo carries 22
+// significant bits only while lo is a NORMAL fp16 number, i.e. |x| >= 2^-3.  So operands are multiplied by exact
+// powers of two before the split: the codebook by 2^se (global, max |-2e'| lands in [2^13, 2^14)), every latent row
+// by its own 2^sz (row max in [2^13, 2^14)).  Elements below 2^-17 of their row/codebook maximum then lose bits,
+// which is 2^-39 of that maximum -- negligible.  The MFMA result is in units of 2^(sz+se); since the argmin only
+// compares values of ONE row, the bookkeeping simply runs in those units (|e'|^2 is scaled on accumulator
+// initialisation) and the certification threshold is scaled the same way.
+__device__ __forceinline__ int lq_scale_exp(float maxabs) {
+    // 2^k with maxabs * 2^k in [2^13, 2^14); clamped so that the factor stays an ordinary float
+    const int e = (int)((__float_as_uint(maxabs) >> 23) & 0xff) - 127;       // floor(log2) for normal numbers
+    int k = 13 - e;
+    k = k < -60 ? -60 : k;
+    k = k > 60 ? 60 : k;
+    return (maxabs > 0.0f && maxabs < INFINITY) ? k : 0;
+}
+__device__ __forceinline__ float lq_pow2f(int k) { return __uint_as_float((unsigned)(k + 127) << 23); }   // k in [-126, 127]
+
 #ifdef LQ_OPT_TC
 constexpr int screen_default_tc(int S) { return (S <= 4) ? LQ_OPT_TC : (S <= 8) ? 2 : 1; }
 #else
@@ -80,8 +97,8 @@ __device__ __forceinline__ void lq_track(const f32x16& acc, int code, float (&m1
 template <int S, int NT, int TC_ = screen_default_tc(S)>
 __device__ __forceinline__ void lq_screen_core(const f16x8 (&ah)[S], const f16x8 (&al)[S],
                                                const unsigned char* __restrict__ tiles, int ntiles,
-                                               unsigned char* stage0, int tid, float (&m1)[16], float (&m2)[16],
-                                               int (&k1)[16]) {
+                                               unsigned char* stage0, int tid, const float (&frow)[16],
+                                               float (&m1)[16], float (&m2)[16], int (&k1)[16]) {
     using C = ScreenCfg<S, TC_>;
     constexpr int VPT = (C::STAGE_VEC + NT - 1) / NT;
     const int lane = tid & 63, ln = lane & 31;
@@ -126,7 +143,7 @@ __device__ __forceinline__ void lq_screen_core(const f16x8 (&ah)[S], const f16x8
             const float e2 = reinterpret_cast<const float*>(tb + S * 2048)[ln];
             f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = e2;
+            for (int r = 0; r < 16; ++r) acc[r] = e2 * frow[r];      // |e'|^2 in the units of row (r, h)
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 const f16x8 bh = *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 0) * 64 + lane) * 16);
@@ -143,6 +160,14 @@ __device__ __forceinline__ void lq_screen_core(const f16x8 (&ah)[S], const f16x8
     }
 }
 
+// frow[r] = factor of row (r, h) = the row this lane's accumulator register r belongs to, fetched from the lane that
+// owns that row (row i lives in lanes i and i + 32, both hold fown)
+__device__ __forceinline__ void lq_row_factors(float fown, int lane, float (&frow)[16]) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) frow[r] = __shfl(fown, (r & 3) + 8 * (r >> 2) + 4 * h, 64);
+}
+
 // After the last tile: per row, the global (smallest, its code, second smallest) over the 32 lanes of the
 // half-wave that holds the row -- and the certification decision.
 //
@@ -155,8 +180,8 @@ __device__ __forceinline__ void lq_screen_core(const f16x8 (&ah)[S], const f16x8
 // Returns certified (valid in every lane, duplicated across the halves); my_k = the row's code.
 __device__ __forceinline__ bool lq_screen_decide(const float (&m1)[16], const float (&m2)[16], const int (&k1)[16],
                                                  unsigned char* wave_lds /* 4 KiB, this wave only */,
-                                                 const unsigned* hdr, float n2, float gamma, int K, int lane,
-                                                 int& my_k) {
+                                                 const unsigned* hdr, float n2, float fown, float gamma, int K,
+                                                 int lane, int& my_k) {
     const int ln = lane & 31, h = lane >> 5;
     float* tv = reinterpret_cast<float*>(wave_lds);           // [32 rows][32 lanes], reused by the three passes
     // ---- pass 1: m1 -> best value, its position among my 16 entries, second smallest m1 ----------------------
@@ -222,8 +247,8 @@ __device__ __forceinline__ bool lq_screen_decide(const float (&m1)[16], const fl
     // screening error + the rounding of the reference's own fp32 distance / square root (2^-20 of the largest
     // full squared distance the row can see)
     const float eps = gamma * (E2max + cross) + 9.5367431640625e-07f * (n2 + E2max + cross);
-    // fp16 range guard: -2e' must stay finite in fp16, else nothing is certified
-    bool certified = (twoemax < 60000.0f) && (second - best > 2.0f * eps) && (bk >= 0) && (bk < K);
+    // best/second are in this row's units (fown = 2^(sz+se)); non-finite inputs make the comparison false
+    bool certified = (twoemax < INFINITY) && (second - best > 2.0f * eps * fown) && (bk >= 0) && (bk < K);
 #ifdef LQ_ABL_CERT_ALL
     certified = true; my_k = (my_k >= 0 && my_k < K) ? my_k : (lane * 7) % K;
 #endif

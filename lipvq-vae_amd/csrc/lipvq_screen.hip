@@ -43,7 +43,11 @@ __global__ __launch_bounds__(256) void prep_mean_kernel(const float* __restrict_
 }
 
 // one thread per (code, step, half): 8 centred, -2-scaled elements -> fp16 hi/lo fragments
-__global__ void prep_frag_kernel(const float* __restrict__ cb, const float* __restrict__ mu,
+__global__ void prep_scale_kernel(unsigned* __restrict__ hdr) {           // after prep_e2_kernel: se from max |-2e'|
+    hdr[3] = (unsigned)lq_scale_exp(__uint_as_float(hdr[2]));
+}
+
+__global__ void prep_frag_kernel(const float* __restrict__ cb, const float* __restrict__ mu, const unsigned* __restrict__ hdr,
                                  unsigned char* __restrict__ tiles, int K, int D, PrepLayout L) {
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t n = (size_t)L.ntiles * 32 * L.S * 2;
@@ -51,12 +55,13 @@ __global__ void prep_frag_kernel(const float* __restrict__ cb, const float* __re
     const int h = (int)(gid & 1);
     const int s = (int)((gid >> 1) % L.S);
     const int k = (int)(gid / (2 * (size_t)L.S));
+    const float fe = lq_pow2f((int)hdr[3]);                      // 2^se, written by prep_scale_kernel
     f16x8 hi, lo;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int d = 16 * s + 2 * j + h;
         float v = 0.0f;
-        if (k < K && d < D) v = -2.0f * (cb[(size_t)k * D + d] - mu[d]);
+        if (k < K && d < D) v = (-2.0f * (cb[(size_t)k * D + d] - mu[d])) * fe;
         const _Float16 vh = (_Float16)v;
         hi[j] = vh;
         lo[j] = (_Float16)(v - (float)vh);
@@ -98,11 +103,12 @@ extern "C" int lipvq_nearest_prepare_f32(const float* codebook, void* prep, int 
     if (e != hipSuccess) return fail(LIPVQ_EHIP, "nearest_prepare: %s", hipGetErrorString(e));
     float* mu = (float*)(base + L.o_mu);
     hipLaunchKernelGGL(prep_mean_kernel, dim3((L.Dpad + 63) / 64), dim3(256), 0, st, codebook, mu, K, D, L.Dpad);
-    size_t n = (size_t)L.ntiles * 32 * L.S * 2;
-    hipLaunchKernelGGL(prep_frag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, codebook, mu,
-                       base + L.o_tiles, K, D, L);
     hipLaunchKernelGGL(prep_e2_kernel, dim3((L.ntiles * 32 + 255) / 256), dim3(256), 0, st, codebook, mu, base + L.o_tiles,
                        (unsigned*)base, K, D, L);
+    hipLaunchKernelGGL(prep_scale_kernel, dim3(1), dim3(1), 0, st, (unsigned*)base);
+    size_t n = (size_t)L.ntiles * 32 * L.S * 2;
+    hipLaunchKernelGGL(prep_frag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, codebook, mu,
+                       (const unsigned*)base, base + L.o_tiles, K, D, L);
     return check_launch("nearest_prepare");
 }
 
@@ -127,26 +133,40 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
     const int64_t row = row0 + ln;
     const int64_t rowc = row < N ? row : N - 1;
 
-    // this wave's 32 rows -> centred fp16 hi/lo A fragments (slot (h, j) of step s = feature 16s + 2j + h)
+    // this wave's 32 rows -> centred, row-scaled fp16 hi/lo A fragments (slot (h, j) of step s = feature 16s + 2j + h)
     f16x8 ah[S], al[S];
-    float n2 = 0.0f;
+    float n2 = 0.0f, fown;
     {
         const float* zr = z + (size_t)rowc * D;
+        float vv[S][8];
+        float amax = 0.0f;
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
+        for (int s = 0; s < S; ++s)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int d = 16 * s + 2 * j + h;
-                float v = 0.0f;
-                if (d < D) v = zr[d] - mu[d];
+                const float v = (d < D) ? zr[d] - mu[d] : 0.0f;
+                vv[s][j] = v;
+                n2 = lq_fma(v, v, n2);
+                amax = fmaxf(amax, lq_abs(v));
+            }
+        n2 += __shfl_xor(n2, 32, 64);                     // |z'|^2 of row `ln`, in both halves
+        amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+        const int sz = lq_scale_exp(amax);
+        const float fz = lq_pow2f(sz);
+        fown = lq_pow2f(sz + (int)hdr[3]);                // units of this row's MFMA results: 2^(sz+se), |sz+se| <= 120
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = vv[s][j] * fz;
                 const _Float16 vh = (_Float16)v;
                 ah[s][j] = vh;
                 al[s][j] = (_Float16)(v - (float)vh);
-                n2 = lq_fma(v, v, n2);
             }
-        }
     }
-    n2 += __shfl_xor(n2, 32, 64);                         // |z'|^2 of row `ln`, in both halves
+    float frow[16];
+    lq_row_factors(fown, lane, frow);
 
     float m1[16], m2[16];
     int k1[16];
@@ -160,7 +180,7 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
             const float e2 = reinterpret_cast<const float*>(tb + S * 2048)[ln];
             f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = e2;
+            for (int r = 0; r < 16; ++r) acc[r] = e2 * frow[r];
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 const f16x8 bh = *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 0) * 64 + lane) * 16);
@@ -174,16 +194,16 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int64_t rr = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (rr < N) dbg[(size_t)rr * L.Kpad + code] = acc[r];
+                    if (rr < N) dbg[(size_t)rr * L.Kpad + code] = acc[r] / frow[r];      // back to unscaled units
                 }
             }
             lq_track(acc, code, m1, m2, k1);
         }
     } else {
-        lq_screen_core<S, SCREEN_WAVES * 64>(ah, al, tiles, L.ntiles, lds, tid, m1, m2, k1);
+        lq_screen_core<S, SCREEN_WAVES * 64>(ah, al, tiles, L.ntiles, lds, tid, frow, m1, m2, k1);
     }
     int my_k;
-    const bool certified = lq_screen_decide(m1, m2, k1, lds + (size_t)wave * 4096, hdr, n2, gamma, K, lane, my_k);
+    const bool certified = lq_screen_decide(m1, m2, k1, lds + (size_t)wave * 4096, hdr, n2, fown, gamma, K, lane, my_k);
     if (h == 0 && row < N) {
         if (certified) {
             idx[row] = (int64_t)my_k;

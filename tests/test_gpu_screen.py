@@ -107,3 +107,41 @@ def test_fp16_overflow_guard(ops, oracle):
     cbd = dev(cb)
     idx, _, ws = ops.nearest_screened(dev(z), cbd, ops.nearest_prepare(cbd), return_workspace=True)
     assert int(ws[0]) == 300 and np.array_equal(idx.cpu().numpy(), idx_ref)
+
+
+@pytest.mark.parametrize("scale", [1e-6, 1e-4, 1e-2, 1.0, 1e2, 1e4, 1e6])
+def test_any_magnitude(ops, oracle, scale):
+    """Block floating point in the fp16 split: results are exact and the error bound holds whatever the operands'
+    magnitude (fp16 'lo' pieces would otherwise go denormal below ~1e-2 and wrong rows would be certified)."""
+    rng = np.random.default_rng(17)
+    K, D, N = 512, 64, 1024
+    cb = (rng.uniform(0, 1, (K, D)) * scale).astype(np.float32)
+    z = (rng.uniform(0, 1, (N, D)) * scale).astype(np.float32)
+    z[::3] *= np.float32(1e-3)                        # rows of very different magnitude in one batch
+    z[1::7] = cb[rng.integers(0, K, len(z[1::7]))] * np.float32(1.0 + 1e-4)
+    idx_ref, zq_ref, _ = oracle.nearest(z, cb)
+    cbd = dev(cb)
+    prep = ops.nearest_prepare(cbd)
+    idx, zq, ws, dt = ops.nearest_screened(dev(z), cbd, prep, return_workspace=True, debug_gamma=GAMMA)
+    assert np.array_equal(idx.cpu().numpy(), idx_ref)
+    assert np.array_equal(zq.cpu().numpy(), zq_ref)
+    dt = dt.cpu().numpy().astype(np.float64)[:, :K]
+    mu = cb.astype(np.float64).mean(0)
+    zc, ec = z.astype(np.float64) - mu, cb.astype(np.float64) - mu
+    d = (ec * ec).sum(1)[None, :] - 2.0 * zc @ ec.T
+    e2max = (ec * ec).sum(1).max()
+    bound = GAMMA * (e2max + 2.0 * np.sqrt((zc * zc).sum(1)) * np.sqrt(e2max))
+    assert (np.abs(dt - d) / bound[:, None]).max() < 0.25
+
+
+def test_zero_rows_and_constant_codebook(ops, oracle):
+    """All-zero latents / a codebook of identical rows: every distance ties, nothing may be certified wrongly."""
+    K, D, N = 64, 32, 100
+    cb = np.full((K, D), 0.25, np.float32)
+    z = np.zeros((N, D), np.float32)
+    z[50:] = 0.25
+    idx_ref, _, _ = oracle.nearest(z, cb)
+    cbd = dev(cb)
+    idx, _, ws = ops.nearest_screened(dev(z), cbd, ops.nearest_prepare(cbd), return_workspace=True)
+    assert np.array_equal(idx.cpu().numpy(), idx_ref) and (idx_ref == 0).all()
+    assert int(ws[0]) == N
