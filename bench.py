@@ -40,6 +40,7 @@ WORKLOADS = {
     "cfg2": (4096, 128, 7, 64, 1024),
     "cfg3": (4096, 128, 7, 128, 8192),
     "cfg1": (64, 16, 7, 32, 256),
+    "encA": (4096, 128, 7, 64, 32),      # dev only: tiny codebook -> the fused kernel is almost pure encoder phase
 }
 PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 vector = fp32-input MFMA peak
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak (the screening kernel's pipe)

@@ -21,12 +21,18 @@
 #else
 #define FUSED_GELU(v) lq_gelu(v)
 #endif
+#ifdef LQ_ABL_NOSIGMOID
+#define FUSED_SIGMOID(v) (v)
+#else
+#define FUSED_SIGMOID(v) lq_sigmoid(v)
+#endif
 
 #ifndef FUSED_WAVES
 #define FUSED_WAVES 8
 #endif
 #define FUSED_THREADS (FUSED_WAVES * 64)
 // LDS budget: the D = 128 instance holds 105 KB of weights, so its codebook stages are one tile deep
+#define FUSED_HIST_MAX 2048
 #ifdef LQ_OPT_TC
 constexpr int fused_tc(int S) { return (S <= 4) ? LQ_OPT_TC : 1; }
 #else
@@ -70,6 +76,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
     float* w_mu = w_B2 + 32 * T2;                                      // [16*S]
     unsigned char* stage0 = reinterpret_cast<unsigned char*>(w_mu + 16 * S);   // 2 stage buffers (also the
                                                                                 // per-wave transpose slices of the decision)
+    // per-workgroup usage histogram (K <= FUSED_HIST_MAX): LDS atomics per row, ONE global atomic per non-empty
+    // bin at the end of this persistent workgroup -- skewed code distributions would otherwise serialise on a
+    // few global addresses (see lq_usage_add)
+    unsigned* hist = reinterpret_cast<unsigned*>(stage0 + 2 * (size_t)ScreenCfg<S, fused_tc(S)>::STAGE_BYTES);
+    const bool use_hist = a.usage && a.K <= FUSED_HIST_MAX;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ln = lane & 31, h = lane >> 5;
@@ -97,6 +108,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
         for (int i = tid; i < 32 * T2; i += FUSED_THREADS) w_B2[i] = a.packed[PL.oB2 + i];
         const float* mu = reinterpret_cast<const float*>(a.prep + L.o_mu);
         for (int i = tid; i < 16 * S; i += FUSED_THREADS) w_mu[i] = mu[i];
+        if (use_hist)
+            for (int i = tid; i < a.K; i += FUSED_THREADS) hist[i] = 0u;
     }
     __syncthreads();
 
@@ -173,7 +186,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float zv = lq_sigmoid(acc[r]);
+                const float zv = FUSED_SIGMOID(acc[r]);
                 acc[r] = zv;
                 const float v = zv - w_mu[32 * t + 2 * r + h];
                 zc[t][r] = v;
@@ -235,26 +248,34 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
         if (h == 0 && row < a.N) {
             if (certified) {
                 a.idx[row] = (int64_t)my_k;
-                if (a.usage) atomicAdd(&a.usage[my_k], 1ull);
+                if (use_hist) atomicAdd(&hist[my_k], 1u);              // LDS atomic
             } else {
                 a.amb_list[atomicAdd(a.amb_count, 1)] = (int)row;
             }
         }
+        if (a.usage && !use_hist) lq_usage_add(a.usage, my_k, h == 0 && row < a.N && certified);
         if (a.zq) lq_screen_gather(a.cb, a.zq, my_k, certified, row0, a.N, a.D, lane);
+    }
+    if (use_hist) {
+        __syncthreads();
+        for (int i = tid; i < a.K; i += FUSED_THREADS) {
+            const unsigned c = hist[i];
+            if (c) atomicAdd(&a.usage[i], (unsigned long long)c);
+        }
     }
 }
 
 template <int S>
-static size_t fused_lds_bytes(int A) {
+static size_t fused_lds_bytes(int A, int K) {
     constexpr int T0 = 2, T1 = 4, T2 = S / 2;
     const int S0q = ((A + 1) / 2 + 3) / 4;
     size_t fl = (size_t)T0 * S0q * 256 + 32 * T0 + (size_t)T1 * 8 * 256 + 32 * T1 + (size_t)T2 * 16 * 256 + 32 * T2 + 16 * S;
-    return fl * sizeof(float) + 2 * (size_t)ScreenCfg<S, fused_tc(S)>::STAGE_BYTES;
+    return fl * sizeof(float) + 2 * (size_t)ScreenCfg<S, fused_tc(S)>::STAGE_BYTES + (K <= FUSED_HIST_MAX ? (size_t)K * 4 : 0);
 }
 
 template <int S>
 static int launch_tokenize(const TokArgs& a, hipStream_t st) {
-    const size_t lds = fused_lds_bytes<S>(a.A);
+    const size_t lds = fused_lds_bytes<S>(a.A, a.K);
     if (lds > 160 * 1024) return fail(LIPVQ_EUNSUPPORTED, "tokenize: %zu B of LDS needed", lds);
     auto kfn = tokenize_kernel<S>;
     static size_t reserved = 0;                 // per instantiation; the attribute call costs ~10 us of host time

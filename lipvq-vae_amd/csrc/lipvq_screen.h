@@ -255,6 +255,25 @@ __device__ __forceinline__ bool lq_screen_decide(const float (&m1)[16], const fl
     return certified;
 }
 
+// usage[k] += 1 for every lane with `active`, with duplicates inside the wave combined first: when many rows map
+// to few codes (the reference's default initialisation maps EVERY row to one code) per-row atomics on one address
+// serialise chip-wide (measured: 1.7 ms instead of 0.57 ms for a 524 288-row batch with 32 codes).  Up to four
+// leader rounds (each: the first active lane's code, a ballot of the lanes that share it, ONE atomic of the count)
+// then plain atomics for whatever is left (the typical well-spread case pays four cheap rounds).
+__device__ __forceinline__ void lq_usage_add(unsigned long long* __restrict__ usage, int k, bool active) {
+#pragma unroll 1
+    for (int round = 0; round < 4; ++round) {
+        const unsigned long long act = __ballot(active);
+        if (act == 0ull) return;                                   // wave-uniform
+        const int leader = __ffsll((long long)act) - 1;
+        const int kl = __shfl(k, leader, 64);
+        const unsigned long long same = __ballot(active && k == kl);
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&usage[kl], (unsigned long long)__popcll(same));
+        active = active && k != kl;
+    }
+    if (active) atomicAdd(&usage[k], 1ull);
+}
+
 // z_q rows of certified rows: 16 lanes copy one codebook row (16 B each), 4 rows per pass
 __device__ __forceinline__ void lq_screen_gather(const float* __restrict__ cb, float* __restrict__ zq, int my_k,
                                                  bool certified, int64_t row0, int64_t N, int D, int lane) {

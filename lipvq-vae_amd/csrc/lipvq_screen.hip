@@ -207,12 +207,12 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
     if (h == 0 && row < N) {
         if (certified) {
             idx[row] = (int64_t)my_k;
-            if (usage) atomicAdd(&usage[my_k], 1ull);
         } else {
             const int slot = atomicAdd(amb_count, 1);
             amb_list[slot] = (int)row;
         }
     }
+    if (usage) lq_usage_add(usage, my_k, h == 0 && row < N && certified);
     if (zq) lq_screen_gather(cb, zq, my_k, certified, row0, N, D, lane);
 }
 
@@ -279,9 +279,9 @@ __global__ __launch_bounds__(256) void nearest_rows_kernel(
         for (int q = 1; q < SL; ++q)
             if (s_v[r][q] < bv) { bv = s_v[r][q]; bk = s_k[r][q]; }
         idx[row] = (int64_t)bk;
-        if (usage) atomicAdd(&usage[bk], 1ull);
         s_k[r][0] = bk;
     }
+    if (usage && threadIdx.x < 64) lq_usage_add(usage, (sl == 0 && valid) ? s_k[r][0] : 0, sl == 0 && valid);
     __syncthreads();
     if (zq && valid) {
         const int bk = s_k[r][0];

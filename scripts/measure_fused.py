@@ -16,6 +16,8 @@ x = torch.randn(B * T, A, device="cuda")
 model.tokenize(x); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(n): model.tokenize(x)
+import os
+cu = os.environ.get('LQ_NO_USAGE') is None
+for _ in range(n): model.tokenize(x, count_usage=cu)
 e1.record(); torch.cuda.synchronize()
 print(f"{wl}: fused tokenize {e0.elapsed_time(e1)/n:.3f} ms/launch, rows to exact kernel {int(model.last_exact_rows[0])}")

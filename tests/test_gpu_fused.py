@@ -76,3 +76,23 @@ def test_config3_shape_matches_oracle(oracle):
     idx2, _, _ = ops.nearest(model.encode(xt), cb)
     assert torch.equal(idx2, idx)
     assert int(model.last_exact_rows[0]) < N // 20
+
+
+def test_skewed_and_degenerate_code_distributions(oracle):
+    """Every row -> one code (the reference's default init) and a 4-code codebook: the usage histogram must be exact
+    (it is aggregated per wave / per workgroup precisely because such distributions hammer a few counters)."""
+    from lipvq_vae_amd import ops
+    from lipvq_vae_amd.tokenizer import LLFQVAE_V4
+    for regime, K in (("default", 256), ("trained", 4)):
+        p = O.make_params(61, 7, 64, K, regime=regime, oracle=oracle)
+        model = LLFQVAE_V4(7, 64, num_codes=K).cuda()
+        model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in p.items()})
+        x = O.make_inputs(61, 20000, 7)
+        ref = oracle.llfq_forward(p, x)
+        xt = torch.from_numpy(x).cuda()
+        idx, _ = model.tokenize(xt)                                # fused launch (LDS histogram)
+        assert np.array_equal(idx.cpu().numpy(), ref["indices"])
+        assert np.array_equal(model.code_usage.cpu().numpy(), ref["usage"])
+        model.reset_usage()
+        idx2, _ = model._quantize(model.encode(xt), model.code_usage)      # stand-alone screen + exact rows (wave aggregation)
+        assert torch.equal(idx2, idx) and np.array_equal(model.code_usage.cpu().numpy(), ref["usage"])
