@@ -5,8 +5,8 @@
 // Replaces reference backbone_lfqvae_v5.py:71-74 (encoder, to_latent, quantizer, z_latent) with the SAME
 // results as lipvq_mlp3_f32 + lipvq_nearest_f32: phase A is mlp3_kernel's arithmetic (one k-ordered fmaf
 // chain per output, lipvq_mlp.hip), phase B is screen_kernel's (lipvq_screen.hip).  z_e never touches HBM
-// as an operand of the screen; it is written once (coalesced 16-byte stores) so that the exact kernel can
-// re-score the <1 % of rows the screen cannot certify, and for the caller when training.
+// as an operand of the screen; it is written (coalesced 16-byte stores) only when the caller asks for it.  The
+// <1 % of rows the screen cannot certify are re-encoded from x by the exact kernel (plain fmaf chains: same bits).
 //
 // Why fused: the two stand-alone kernels are latency bound (rocprofv3 PMC, profiles/r01_b: MFMA pipe 13-18 %
 // busy, half of all wave cycles parked in s_waitcnt/barriers): mlp3 streams its A operands from L2 at one
@@ -38,6 +38,37 @@ constexpr int fused_tc(int S) { return (S <= 4) ? LQ_OPT_TC : 1; }
 #else
 constexpr int fused_tc(int S) { return (S <= 2) ? 8 : (S <= 4) ? 4 : 1; }
 #endif
+
+// lq_gelu_poly for two elements, cut into four stages so that one stage can follow each MFMA of a 4-MFMA group
+// (same operations in the same order as lq_gelu_poly: bit-identical values)
+struct Gelu2 {
+    float x0, x1, t0, t1, u0, u1, s0, s1;
+    __device__ __forceinline__ void stage0(float a, float b) {
+        x0 = a; x1 = b;
+        t0 = a * a; t1 = b * b;
+        u0 = lq_fma(t0, 0.11111111111111111111f, -1.0f); u1 = lq_fma(t1, 0.11111111111111111111f, -1.0f);
+        s0 = lq_fma(0.00012666420661844313f, u0, -0.00043783686123788357f); s1 = lq_fma(0.00012666420661844313f, u1, -0.00043783686123788357f);
+        s0 = lq_fma(s0, u0, 0.0008924771682359278f); s1 = lq_fma(s1, u1, 0.0008924771682359278f);
+    }
+    __device__ __forceinline__ void stage1() {
+        s0 = lq_fma(s0, u0, -0.002175821689888835f); s1 = lq_fma(s1, u1, -0.002175821689888835f);
+        s0 = lq_fma(s0, u0, 0.005515238270163536f); s1 = lq_fma(s1, u1, 0.005515238270163536f);
+        s0 = lq_fma(s0, u0, -0.01217574905604124f); s1 = lq_fma(s1, u1, -0.01217574905604124f);
+        s0 = lq_fma(s0, u0, 0.02415713667869568f); s1 = lq_fma(s1, u1, 0.02415713667869568f);
+    }
+    __device__ __forceinline__ void stage2() {
+        s0 = lq_fma(s0, u0, -0.043842192739248276f); s1 = lq_fma(s1, u1, -0.043842192739248276f);
+        s0 = lq_fma(s0, u0, 0.07253222167491913f); s1 = lq_fma(s1, u1, 0.07253222167491913f);
+        s0 = lq_fma(s0, u0, -0.11009667813777924f); s1 = lq_fma(s1, u1, -0.11009667813777924f);
+        s0 = lq_fma(s0, u0, 0.15749694406986237f); s1 = lq_fma(s1, u1, 0.15749694406986237f);
+    }
+    __device__ __forceinline__ void stage3(float& o0, float& o1) {
+        s0 = lq_fma(s0, u0, -0.2287982553243637f); s1 = lq_fma(s1, u1, -0.2287982553243637f);
+        s0 = lq_fma(s0, u0, 0.4701318144798279f); s1 = lq_fma(s1, u1, 0.4701318144798279f);
+        o0 = lq_fma(t0 * 0.35355339059327376220f, s0, 0.5f * x0);
+        o1 = lq_fma(t1 * 0.35355339059327376220f, s1, 0.5f * x1);
+    }
+};
 
 struct TokArgs {
     const float* x;              // [N][A]
@@ -151,7 +182,23 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) h0[t][r] = FUSED_GELU(h0[t][r]);
         }
+        // ---- layer 1, software pipelined at source level: the GELU of tile t-1 is written between the MFMAs of tile t
+        // (two elements per 4-MFMA group).  A 64-cycle fp32 MFMA leaves ~12 vector issue slots before its dependent
+        // successor can start, so the polynomial (17 instructions per element) runs in the chain's shadow (ablation:
+        // GELU cost 87 us of a 407 us encoder-only launch when it ran after each chain).  The rare |x| >= sqrt(18)
+        // elements are fixed up behind a wave-uniform branch so that the pipelined region stays straight-line code.
         f32x16 h1[T1];
+        f32x16 pend;                      // pre-activations of the previous tile, GELU pending
+        auto gelu_fixup = [&](f32x16& out, const f32x16& pre) {
+            bool slow = false;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) slow |= !(pre[r] * pre[r] < 18.0f);
+            if (__builtin_amdgcn_ballot_w64(slow) != 0ull) {          // wave-uniform, practically never taken
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (!(pre[r] * pre[r] < 18.0f)) out[r] = lq_gelu_tail(pre[r]);
+            }
+        };
 #pragma unroll
         for (int t = 0; t < T1; ++t) {
             f32x16 acc;
@@ -160,14 +207,30 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
 #pragma unroll
             for (int sq = 0; sq < S1 / 4; ++sq) {
                 const float4 av = *reinterpret_cast<const float4*>(w_P1 + ((t * (S1 / 4) + sq) * 64 + lane) * 4);
+                Gelu2 g;
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, h0[(4 * sq + 0) / 16][(4 * sq + 0) % 16], acc, 0, 0, 0);
+                if (t > 0) g.stage0(pend[2 * sq], pend[2 * sq + 1]);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, h0[(4 * sq + 1) / 16][(4 * sq + 1) % 16], acc, 0, 0, 0);
+                if (t > 0) g.stage1();
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, h0[(4 * sq + 2) / 16][(4 * sq + 2) % 16], acc, 0, 0, 0);
+                if (t > 0) g.stage2();
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, h0[(4 * sq + 3) / 16][(4 * sq + 3) % 16], acc, 0, 0, 0);
+                if (t > 0) {
+#ifndef LQ_ABL_NOGELU
+                    float o0, o1;
+                    g.stage3(o0, o1);
+                    h1[t - 1][2 * sq] = o0; h1[t - 1][2 * sq + 1] = o1;
+#else
+                    h1[t - 1][2 * sq] = pend[2 * sq]; h1[t - 1][2 * sq + 1] = pend[2 * sq + 1];
+#endif
+                }
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) h1[t][r] = FUSED_GELU(acc[r]);
+#ifndef LQ_ABL_NOGELU
+            if (t > 0) gelu_fixup(h1[t - 1], pend);
+#endif
+            pend = acc;
         }
+        // the last tile's GELU runs inside the first layer-2 chain: steps 0 .. 47 of that chain only read h1[0..2]
         f16x8 ah[S], al[S];
         float n2 = 0.0f, amax = 0.0f;
         f32x16 zc[T2];                   // centred z_e (fp32) until the row's scale is known
@@ -178,11 +241,31 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
             for (int r = 0; r < 16; ++r) acc[r] = w_B2[32 * t + 2 * r + h];
 #pragma unroll
             for (int sq = 0; sq < S2 / 4; ++sq) {
+                if (t == 0 && sq == 3 * (S2 / 16)) {
+                    // h1[T1-1] is needed from here on (k-steps 48..63 of a 128-wide layer): finish its GELU
+#ifndef LQ_ABL_NOGELU
+                    gelu_fixup(h1[T1 - 1], pend);
+#endif
+                }
                 const float4 av = *reinterpret_cast<const float4*>(w_P2 + ((t * (S2 / 4) + sq) * 64 + lane) * 4);
+                const bool pg = (t == 0 && sq < 8);          // the 16 pending GELUs ride on groups 0..7 (< 12: they only read h1[0..2])
+                Gelu2 g;
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, h1[(4 * sq + 0) / 16][(4 * sq + 0) % 16], acc, 0, 0, 0);
+                if (pg) g.stage0(pend[(2 * sq) & 15], pend[(2 * sq + 1) & 15]);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, h1[(4 * sq + 1) / 16][(4 * sq + 1) % 16], acc, 0, 0, 0);
+                if (pg) g.stage1();
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, h1[(4 * sq + 2) / 16][(4 * sq + 2) % 16], acc, 0, 0, 0);
+                if (pg) g.stage2();
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, h1[(4 * sq + 3) / 16][(4 * sq + 3) % 16], acc, 0, 0, 0);
+                if (pg) {
+#ifndef LQ_ABL_NOGELU
+                    float o0, o1;
+                    g.stage3(o0, o1);
+                    h1[T1 - 1][(2 * sq) & 15] = o0; h1[T1 - 1][(2 * sq + 1) & 15] = o1;
+#else
+                    h1[T1 - 1][(2 * sq) & 15] = pend[(2 * sq) & 15]; h1[T1 - 1][(2 * sq + 1) & 15] = pend[(2 * sq + 1) & 15];
+#endif
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -296,20 +379,23 @@ extern "C" int lipvq_tokenize_supported(int A, int J0, int J1, int D, int K) {
 
 extern "C" size_t lipvq_tokenize_workspace_bytes(int64_t N, int D) {
     if (N <= 0 || D <= 0) return 0;
-    return 64 + (((sizeof(int) * (size_t)N) + 63) & ~(size_t)63) + sizeof(float) * (size_t)N * D;
+    return 64 + (((sizeof(int) * (size_t)N) + 63) & ~(size_t)63);       // uncertified-row counter + list
 }
 
 // Fused encode + quantize (reference v5:71-74).  packed: lipvq_mlp3_pack_f32 of the encoder stack
-// (A -> 64 -> 128 -> D with the Lipschitz-normalised W2, activations gelu, gelu, sigmoid); prep:
+// (A -> 64 -> 128 -> D with the Lipschitz-normalised W2, activations gelu, gelu, sigmoid); raw6: the same six
+// tensors unpacked, {W0, b0, W1, b1, W2, b2} (device pointers; the array itself is host memory); prep:
 // lipvq_nearest_prepare_f32 of the codebook; workspace: lipvq_tokenize_workspace_bytes(N, D).
 // Outputs exactly as lipvq_mlp3_f32 + lipvq_nearest_f32(LIPVQ_DIST_NORM): idx, zq (may be NULL),
 // usage (may be NULL, accumulated), ze_out (may be NULL).  workspace[0] (int) = rows decided by the exact kernel.
-extern "C" int lipvq_tokenize_f32(const float* x, const float* packed, const float* codebook, const void* prep,
-                                  int64_t* idx, float* zq, int64_t* usage, float* ze_out, void* workspace, int64_t N,
-                                  int A, int J0, int J1, int D, int K, void* stream) {
+extern "C" int lipvq_tokenize_f32(const float* x, const float* packed, const float* const* raw6, const float* codebook,
+                                  const void* prep, int64_t* idx, float* zq, int64_t* usage, float* ze_out,
+                                  void* workspace, int64_t N, int A, int J0, int J1, int D, int K, void* stream) {
     if (N < 0) return fail(LIPVQ_EINVAL, "tokenize: N < 0");
     if (N == 0) return LIPVQ_OK;
-    if (!x || !packed || !codebook || !prep || !idx || !workspace) return fail(LIPVQ_EINVAL, "tokenize: null pointer");
+    if (!x || !packed || !raw6 || !codebook || !prep || !idx || !workspace) return fail(LIPVQ_EINVAL, "tokenize: null pointer");
+    for (int i = 0; i < 6; ++i)
+        if (!raw6[i]) return fail(LIPVQ_EINVAL, "tokenize: raw encoder weight %d is null", i);
     if (!lipvq_tokenize_supported(A, J0, J1, D, K))
         return fail(LIPVQ_EUNSUPPORTED, "tokenize: unsupported shape A=%d J0=%d J1=%d D=%d K=%d", A, J0, J1, D, K);
     if (N > 2147483647LL) return fail(LIPVQ_EUNSUPPORTED, "tokenize: N too large");
@@ -319,9 +405,9 @@ extern "C" int lipvq_tokenize_f32(const float* x, const float* packed, const flo
     unsigned char* ws = (unsigned char*)workspace;
     int* amb_count = (int*)ws;
     int* amb_list = (int*)(ws + 64);
-    // z_e is always materialised (coalesced 16-byte stores, ~134 MB at BASELINE config 2): the exact kernel
-    // reads the rows it needs from it; the caller's buffer is used when one is given
-    float* ze_buf = ze_out ? ze_out : (float*)(ws + 64 + (((sizeof(int) * (size_t)N) + 63) & ~(size_t)63));
+    // z_e is written only when the caller wants it (training); otherwise the exact kernel recomputes it for the few
+    // rows it has to decide (saves a 134 MB write per 524 288-row launch at BASELINE config 2)
+    float* ze_buf = ze_out;
     hipError_t e = hipMemsetAsync(amb_count, 0, 64, st);
     if (e != hipSuccess) return fail(LIPVQ_EHIP, "tokenize: %s", hipGetErrorString(e));
     TokArgs a{x, packed, (const unsigned char*)prep, codebook, idx, zq, (unsigned long long*)usage, ze_buf,
@@ -333,6 +419,7 @@ extern "C" int lipvq_tokenize_f32(const float* x, const float* packed, const flo
         default: rc = launch_tokenize<8>(a, st); break;
     }
     if (rc) return rc;
-    // uncertified rows (count on the device) are decided exactly from their stored z_e rows
-    return lipvq_launch_rows(a.ze_out, 0, codebook, idx, zq, usage, amb_list, amb_count, N, K, D, st);
+    // uncertified rows (count on the device): exact decision, from the stored z_e rows or from x
+    if (ze_out) return lipvq_launch_rows(ze_out, 0, codebook, idx, zq, usage, amb_list, amb_count, N, K, D, st);
+    return lipvq_launch_rows_encode(x, raw6, A, codebook, idx, zq, usage, amb_list, amb_count, N, K, D, st);
 }

@@ -114,27 +114,29 @@ LQ_HD float lq_erff(float x) {
  *   gelu(x) = 0.5 x + (x^2 / sqrt 8) s(x^2/9 - 1)            for |x| < 3 sqrt 2
  * -- the same polynomial as lq_erff, but no |x| / sign handling: 17 instructions on the path that practically
  * every GPU wavefront takes.  Outside, the textbook form with lq_erff (which then takes its exp branch). */
-LQ_HD float lq_gelu(float x) {
+/* the polynomial branch of lq_gelu, valid for x*x < 18 (straight-line: the fused kernel interleaves it with MFMAs) */
+LQ_HD float lq_gelu_poly(float x) {
     float t = x * x;
-    if (t < 18.0f) {
-        float u = lq_fma(t, 0.11111111111111111111f, -1.0f);
-        float s = 0.00012666420661844313f;
-        s = lq_fma(s, u, -0.00043783686123788357f);
-        s = lq_fma(s, u, 0.0008924771682359278f);
-        s = lq_fma(s, u, -0.002175821689888835f);
-        s = lq_fma(s, u, 0.005515238270163536f);
-        s = lq_fma(s, u, -0.01217574905604124f);
-        s = lq_fma(s, u, 0.02415713667869568f);
-        s = lq_fma(s, u, -0.043842192739248276f);
-        s = lq_fma(s, u, 0.07253222167491913f);
-        s = lq_fma(s, u, -0.11009667813777924f);
-        s = lq_fma(s, u, 0.15749694406986237f);
-        s = lq_fma(s, u, -0.2287982553243637f);
-        s = lq_fma(s, u, 0.4701318144798279f);
-        return lq_fma(t * 0.35355339059327376220f, s, 0.5f * x);
-    }
-    return (0.5f * x) * (1.0f + lq_erff(x * 0.70710678118654752440f));    /* also propagates NaN */
+    float u = lq_fma(t, 0.11111111111111111111f, -1.0f);
+    float s = 0.00012666420661844313f;
+    s = lq_fma(s, u, -0.00043783686123788357f);
+    s = lq_fma(s, u, 0.0008924771682359278f);
+    s = lq_fma(s, u, -0.002175821689888835f);
+    s = lq_fma(s, u, 0.005515238270163536f);
+    s = lq_fma(s, u, -0.01217574905604124f);
+    s = lq_fma(s, u, 0.02415713667869568f);
+    s = lq_fma(s, u, -0.043842192739248276f);
+    s = lq_fma(s, u, 0.07253222167491913f);
+    s = lq_fma(s, u, -0.11009667813777924f);
+    s = lq_fma(s, u, 0.15749694406986237f);
+    s = lq_fma(s, u, -0.2287982553243637f);
+    s = lq_fma(s, u, 0.4701318144798279f);
+    return lq_fma(t * 0.35355339059327376220f, s, 0.5f * x);
 }
+/* the other branch: the textbook form with lq_erff (which then takes its exp branch); also propagates NaN */
+LQ_HD float lq_gelu_tail(float x) { return (0.5f * x) * (1.0f + lq_erff(x * 0.70710678118654752440f)); }
+
+LQ_HD float lq_gelu(float x) { return (x * x < 18.0f) ? lq_gelu_poly(x) : lq_gelu_tail(x); }
 
 /* d/dx gelu(x) = Phi(x) + x phi(x) */
 LQ_HD float lq_gelu_grad(float x) {

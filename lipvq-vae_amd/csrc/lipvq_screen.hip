@@ -294,6 +294,139 @@ __global__ __launch_bounds__(256) void nearest_rows_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// exact decision for listed rows WITHOUT a stored z_e: the workgroup first recomputes z_e of its 4 rows from x
+// (encoder + Lipschitz layer as plain fp32 fmaf chains in natural k order, bias first, odd fan-in padded with one
+// zero term -- the canonical arithmetic, hence the same bits the MFMA path produced), then runs the search above.
+// This is what lets the fused tokenize launch skip the 134 MB z_e write when the caller does not want z_e.
+// Encoder widths are the reference's (A -> 64 -> 128 -> D).
+// ------------------------------------------------------------------------------------------
+struct RawEncoder { const float *W0, *b0, *W1, *b1, *W2, *b2; };
+
+template <int DCH>
+__global__ __launch_bounds__(256) void nearest_rows_encode_kernel(
+    const float* __restrict__ x, RawEncoder w, int A, const float* __restrict__ cb, int64_t* __restrict__ idx,
+    float* __restrict__ zq, unsigned long long* __restrict__ usage, const int* __restrict__ row_list,
+    const int* __restrict__ row_count, int K) {
+    constexpr int D = DCH * 8;
+    constexpr int RB = 4, SL = 64;
+    __shared__ float s_x[RB][64];
+    __shared__ float s_h0[RB][64];
+    __shared__ float s_h1[RB][128];
+    __shared__ __attribute__((aligned(16))) float s_z[RB][D];
+    __shared__ float s_v[RB][SL];
+    __shared__ int s_k[RB][SL];
+    const int count = *row_count;
+    const int tid = threadIdx.x;
+  for (int base = blockIdx.x * RB; base < count; base += gridDim.x * RB) {
+    // ---- encoder for the 4 rows -------------------------------------------------------------------------------
+    for (int o = tid; o < RB * A; o += 256) {
+        const int r = o / A, k = o - r * A;
+        const int sl_ = base + r < count ? base + r : count - 1;
+        s_x[r][k] = x[(size_t)row_list[sl_] * A + k];
+    }
+    __syncthreads();
+    {
+        const int r = tid >> 6, j = tid & 63;
+        float acc = w.b0[j];
+        for (int k = 0; k < A; ++k) acc = lq_fma(s_x[r][k], w.W0[(size_t)j * A + k], acc);
+        if (A & 1) acc = lq_fma(0.0f, 0.0f, acc);
+        s_h0[r][j] = lq_gelu(acc);
+    }
+    __syncthreads();
+    for (int o = tid; o < RB * 128; o += 256) {
+        const int r = o >> 7, j = o & 127;
+        float acc = w.b1[j];
+        const float* wr = w.W1 + (size_t)j * 64;
+        for (int k = 0; k < 64; ++k) acc = lq_fma(s_h0[r][k], wr[k], acc);
+        s_h1[r][j] = lq_gelu(acc);
+    }
+    __syncthreads();
+    for (int o = tid; o < RB * D; o += 256) {
+        const int r = o / D, j = o - r * D;
+        float acc = w.b2[j];
+        const float* wr = w.W2 + (size_t)j * 128;
+        for (int k = 0; k < 128; ++k) acc = lq_fma(s_h1[r][k], wr[k], acc);
+        s_z[r][j] = lq_sigmoid(acc);
+    }
+    __syncthreads();
+    // ---- exact search (same as nearest_rows_kernel, z from LDS) ---------------------------------------------------
+    const int r = tid & (RB - 1), sl = tid / RB;
+    const int slot = base + r;
+    const bool valid = slot < count;
+    const int64_t row = row_list[valid ? slot : count - 1];
+    float zr[D];
+#pragma unroll
+    for (int i = 0; i < D / 4; ++i) {
+        const float4 v = reinterpret_cast<const float4*>(&s_z[r][0])[i];
+        zr[4 * i + 0] = v.x; zr[4 * i + 1] = v.y; zr[4 * i + 2] = v.z; zr[4 * i + 3] = v.w;
+    }
+    const int per = (K + SL - 1) / SL;
+    const int kb = sl * per, ke = (kb + per < K) ? kb + per : K;
+    float best_v = INFINITY, best_s = INFINITY;
+    int best_k = kb < K ? kb : 0;
+    for (int k = kb; k < ke; ++k) {
+        const float4* c4 = reinterpret_cast<const float4*>(cb + (size_t)k * D);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+#pragma unroll
+        for (int i = 0; i < DCH; ++i) {
+            const float4 lo = c4[2 * i], hi = c4[2 * i + 1];
+            const float d0 = zr[8 * i + 0] - lo.x, d1 = zr[8 * i + 1] - lo.y;
+            const float d2 = zr[8 * i + 2] - lo.z, d3 = zr[8 * i + 3] - lo.w;
+            const float d4 = zr[8 * i + 4] - hi.x, d5 = zr[8 * i + 5] - hi.y;
+            const float d6 = zr[8 * i + 6] - hi.z, d7 = zr[8 * i + 7] - hi.w;
+            a0 = lq_fma(d0, d0, a0); a1 = lq_fma(d1, d1, a1);
+            a2 = lq_fma(d2, d2, a2); a3 = lq_fma(d3, d3, a3);
+            a4 = lq_fma(d4, d4, a4); a5 = lq_fma(d5, d5, a5);
+            a6 = lq_fma(d6, d6, a6); a7 = lq_fma(d7, d7, a7);
+        }
+        const float s = ((((((a0 + a1) + a2) + a3) + a4) + a5) + a6) + a7;
+        if (s < best_s) {
+            const float v = lq_sqrt(s);
+            if (v < best_v) { best_v = v; best_s = s; best_k = k; }
+        }
+    }
+    s_v[r][sl] = best_v; s_k[r][sl] = best_k;
+    __syncthreads();
+    if (sl == 0 && valid) {
+        float bv = s_v[r][0];
+        int bk = s_k[r][0];
+        for (int q = 1; q < SL; ++q)
+            if (s_v[r][q] < bv) { bv = s_v[r][q]; bk = s_k[r][q]; }
+        idx[row] = (int64_t)bk;
+        s_k[r][0] = bk;
+    }
+    if (usage && tid < 64) lq_usage_add(usage, (sl == 0 && valid) ? s_k[r][0] : 0, sl == 0 && valid);
+    __syncthreads();
+    if (zq && valid) {
+        const int bk = s_k[r][0];
+        const float4* src = reinterpret_cast<const float4*>(cb + (size_t)bk * D);
+        float4* dst = reinterpret_cast<float4*>(zq + (size_t)row * D);
+        for (int v = sl; v < D / 4; v += SL) dst[v] = src[v];
+    }
+    __syncthreads();
+  }
+}
+
+int lipvq_launch_rows_encode(const float* x, const float* const* raw6, int A, const float* cb, int64_t* idx, float* zq,
+                             int64_t* usage, const int* amb_list, const int* amb_count, int64_t N, int K, int D,
+                             hipStream_t st) {
+    RawEncoder w{raw6[0], raw6[1], raw6[2], raw6[3], raw6[4], raw6[5]};
+    int64_t blocks = (N + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    auto go = [&](auto kfn) {
+        hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(256), 0, st, x, w, A, cb, idx, zq,
+                           (unsigned long long*)usage, amb_list, amb_count, K);
+    };
+    switch (D) {
+        case 32: go(nearest_rows_encode_kernel<4>); break;
+        case 64: go(nearest_rows_encode_kernel<8>); break;
+        case 128: go(nearest_rows_encode_kernel<16>); break;
+        default: return fail(LIPVQ_EUNSUPPORTED, "nearest_rows_encode: D=%d has no instance", D);
+    }
+    return check_launch("nearest_rows_encode");
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 extern "C" size_t lipvq_nearest_workspace_bytes(int64_t N) {

@@ -7,6 +7,8 @@ product; the CPU restatement lives in oracle/ and is test infrastructure).
 """
 from __future__ import annotations
 
+import ctypes as _C
+
 import torch
 
 from . import _capi
@@ -295,9 +297,12 @@ def tokenize_workspace(N: int, D: int, device) -> torch.Tensor:
     return torch.empty(max(16, (lib.lipvq_tokenize_workspace_bytes(N, D) + 3) // 4), device=device, dtype=torch.int32)
 
 
-def tokenize(x, packed: PackedMlp3, codebook, prep: PreparedCodebook, usage=None, want_zq=True, want_ze=False,
+def tokenize(x, packed: PackedMlp3, raw, codebook, prep: PreparedCodebook, usage=None, want_zq=True, want_ze=False,
              workspace=None):
-    """(idx, zq, ze, workspace) of the fused encode + quantize launch (lipvq_tokenize_f32)."""
+    """(idx, zq, ze, workspace) of the fused encode + quantize launch (lipvq_tokenize_f32).  raw = the encoder's six
+    unpacked tensors (W0, b0, W1, b1, W2 normalised, b2): the exact kernel re-encodes uncertified rows with them."""
+    raw = tuple(_chk(t, f"raw[{i}]") for i, t in enumerate(raw))
+    raw_arr = (_C.c_void_p * 6)(*[t.data_ptr() for t in raw])
     x, codebook = _chk(x, "x"), _chk(codebook, "codebook")
     N, A = x.shape
     K, D = codebook.shape
@@ -311,7 +316,7 @@ def tokenize(x, packed: PackedMlp3, codebook, prep: PreparedCodebook, usage=None
     ze = torch.empty((N, D), device=dev, dtype=torch.float32) if want_ze else None
     ws = workspace if workspace is not None else tokenize_workspace(N, D, dev)
     with torch.cuda.device(dev):
-        check(lib.lipvq_tokenize_f32(_ptr(x), _ptr(packed.buf), _ptr(codebook), _ptr(prep.buf), _ptr(idx), _ptr(zq),
+        check(lib.lipvq_tokenize_f32(_ptr(x), _ptr(packed.buf), raw_arr, _ptr(codebook), _ptr(prep.buf), _ptr(idx), _ptr(zq),
                                      _ptr(usage), _ptr(ze), _ptr(ws), N, A, packed.J0, packed.J1, D, K, _stream()),
               "lipvq_tokenize_f32")
     return idx, zq, ze, ws

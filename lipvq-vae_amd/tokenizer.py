@@ -167,12 +167,14 @@ class LLFQVAE_V4(_TokenizerBase):
         cb = self.quantizer.codebook.detach()
         if x.shape[0] > 0 and ops.tokenize_supported(self.feature_dim, 64, self.hidden_dim, self.latent_dim, self.num_codes):
             # one persistent launch: z_e never leaves registers (csrc/lipvq_fused.hip)
-            packed, _, _ = self._packed_encoder()
+            packed, _, Wn = self._packed_encoder()
+            w0, b0, w1, b1, _, b2, _ = (t.detach() for t in self._enc_params())
             prep = self._cb_cache.get((self.quantizer.codebook,), lambda: ops.nearest_prepare(cb))
             key = (x.shape[0], x.device)
             if getattr(self, "_tok_ws_key", None) != key:        # the scratch (row list + z_e) is reused across calls
                 self._tok_ws, self._tok_ws_key = ops.tokenize_workspace(x.shape[0], self.latent_dim, x.device), key
-            idx, zq, _, ws = ops.tokenize(x, packed, cb, prep, usage=usage, workspace=self._tok_ws)
+            idx, zq, _, ws = ops.tokenize(x, packed, (w0, b0, w1, b1, Wn, b2), cb, prep, usage=usage,
+                                          workspace=self._tok_ws)
             self.last_exact_rows = ws
         else:
             idx, zq = self._quantize(self.encode(x), usage)

@@ -27,11 +27,17 @@ def test_fused_equals_oracle_and_unfused(oracle, N, A, D, K):
     xt = torch.from_numpy(x).cuda()
     ze_ref = oracle.llfq_encode(p, x)
     idx_ref, zq_ref, usage_ref = oracle.nearest(ze_ref, p["quantizer.codebook"])
-    packed, _, _ = model._packed_encoder()
+    packed, _, Wn = model._packed_encoder()
+    w0, b0, w1, b1, _, b2, _ = (t.detach() for t in model._enc_params())
+    raw = (w0, b0, w1, b1, Wn, b2)
     cb = model.quantizer.codebook.detach()
     prep = ops.nearest_prepare(cb)
     usage = torch.zeros(K, dtype=torch.int64, device="cuda")
-    idx, zq, ze, ws = ops.tokenize(xt, packed, cb, prep, usage=usage, want_ze=True)
+    idx, zq, ze, ws = ops.tokenize(xt, packed, raw, cb, prep, usage=usage, want_ze=True)
+    # without ze_out: z_e is never stored, uncertified rows are re-encoded by the exact kernel -- same answers
+    usage_b = torch.zeros(K, dtype=torch.int64, device="cuda")
+    idx_b, zq_b, ze_b, _ = ops.tokenize(xt, packed, raw, cb, prep, usage=usage_b)
+    assert ze_b is None and torch.equal(idx_b, idx) and torch.equal(zq_b, zq) and torch.equal(usage_b, usage)
     assert np.array_equal(ze.cpu().numpy(), ze_ref)
     assert np.array_equal(idx.cpu().numpy(), idx_ref)
     assert np.array_equal(zq.cpu().numpy(), zq_ref)
@@ -47,12 +53,14 @@ def test_fused_without_optional_outputs(oracle):
     from lipvq_vae_amd import ops
     p, model = _setup(3, 7, 64, 256, oracle)
     x = torch.from_numpy(O.make_inputs(3, 999, 7)).cuda()
-    packed, _, _ = model._packed_encoder()
+    packed, _, Wn = model._packed_encoder()
+    w0, b0, w1, b1, _, b2, _ = (t.detach() for t in model._enc_params())
+    raw = (w0, b0, w1, b1, Wn, b2)
     cb = model.quantizer.codebook.detach()
     prep = ops.nearest_prepare(cb)
-    idx, zq, ze, _ = ops.tokenize(x, packed, cb, prep, want_zq=False)
+    idx, zq, ze, _ = ops.tokenize(x, packed, raw, cb, prep, want_zq=False)
     assert zq is None and ze is None
-    idx2, _, _, _ = ops.tokenize(x, packed, cb, prep)
+    idx2, _, _, _ = ops.tokenize(x, packed, raw, cb, prep)
     assert torch.equal(idx, idx2)
 
 
