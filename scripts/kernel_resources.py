@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Print a per-kernel resource table (VGPR/AGPR/SGPR/spill/occupancy/LDS) from hipcc remarks."""
 import re, subprocess, sys
-out = subprocess.run(["make", "-s", "-C", sys.argv[1] if len(sys.argv) > 1 else "lipvq-vae_amd/csrc", "resources"],
+out = subprocess.run(["make", "-s", "-C", sys.argv[1] if len(sys.argv) > 1 else str(__import__("pathlib").Path(__file__).resolve().parent.parent / "lipvq-vae_amd" / "csrc"), "resources"],
                      capture_output=True, text=True).stderr
 rows, cur = [], None
 for line in out.splitlines():
