@@ -4,22 +4,25 @@
 // Idea.  argmin_k |z - e_k| only needs the exact (torch-order, fp32) distance for codes that can
 // possibly win.  A cheap approximation  d~(n,k) = |e'_k|^2 - 2 z'_n . e'_k  (centred operands
 // z' = z - mu, e' = e - mu; the row constant |z'|^2 is dropped) is computed on the matrix cores:
-// every operand is split into two fp16 pieces (x = hi + lo, 22 significant bits) and three
-// products hi*hi + lo*hi + hi*lo are accumulated in fp32 by v_mfma_f32_32x32x16_f16.  Each lane
+// every operand is scaled by an exact power of two (block floating point, see lipvq_screen.h), split
+// into two fp16 pieces (x = hi + lo, 22 significant bits) and three products hi*hi + lo*hi + hi*lo
+// are accumulated in fp32 by v_mfma_f32_32x32x16_f16.  Each lane
 // tracks, per row, the smallest and second smallest d~ it has seen and the code of the smallest.
 // If, after all codes, the second smallest exceeds the smallest by more than W_n = 2 eps_n (eps_n
 // bounds |d~ - d| for the row, see "error bound"), the approximate argmin IS the exact argmin in
 // real arithmetic with a margin that also covers the rounding of the reference's own fp32
 // distance, hence it is the reference's index.  Otherwise the row is appended to a list and the
-// exact kernel (nearest_rows_kernel: torch's 8-accumulator order, sqrt comparison, first-minimum
-// rule) decides it.  No row is ever decided by the approximation alone unless it is certified.
+// exact kernel (nearest_rows_kernel, or nearest_rows_encode_kernel when z_e was never stored: torch's
+// 8-accumulator order, sqrt comparison, first-minimum rule) decides it.  No row is ever decided by
+// the approximation alone unless it is certified.
 //
 // Error bound.  |d~ - d| <= eps_n = gamma * (E2max + 2 |z'_n| Emax), with E2max = max_k |e'_k|^2,
 // Emax = max_k |e'_k|.  Analytically the fp16 split leaves 3 * 2^-22 * sum|z'e'| per dot product;
 // hence at most 2^-20.4 of (E2max + 2 |z'| Emax); the fp32 accumulation inside the MFMA and the rounding of
-// |e'|^2 add a few 2^-24 of the partial sums' magnitude.  Measured over 2*10^7 pairs of all supported widths
-// (scripts/measure_bound.py): 2^-20.8.  gamma (LIPVQ_SCREEN_GAMMA) is 2^-18: 5x the analytic split bound, 7x the
-// largest error observed; tests/test_gpu_screen.py::test_error_bound_holds asserts a >= 4x margin on every run.
+// |e'|^2 add a few 2^-24 of the partial sums' magnitude.  Measured over 2*10^7 pairs of all supported widths and
+// operand magnitudes from 1e-6 to 1e6 (scripts/measure_bound.py, measure_bound_scales.py): 2^-22.  gamma
+// (LIPVQ_SCREEN_GAMMA) is 2^-18: 5x the analytic split bound, 16x the largest error observed;
+// tests/test_gpu_screen.py (test_error_bound_holds, test_any_magnitude) assert a >= 4x margin on every run.
 #include "lipvq_screen.h"
 
 extern "C" size_t lipvq_nearest_prep_bytes(int K, int D) {
