@@ -160,6 +160,42 @@ int lipvq_lipschitz_bwd_f32(const float* W, const float* ci, const float* gWn, f
 int lipvq_scaled_diff_f32(const float* a, const float* b, const float* c, float alpha, const float* gscale,
                           float* out, int64_t n, void* stream);
 
+/* ---- the step after the tokenizer: input embedding + interleave, lipvq-vae_amd/csrc/lipvq_embed.hip ----
+ * ob = robomimic/models/obs_nets.py.  ob:2525-2543 input_embedding():
+ *     e = embed_drop(embed_ln(embed_encoder(inputs) + time_embeddings))
+ * ob:2580-2596: stack/view/cat of the three streams into transformer_embeddings [B][3T][E]
+ *     (context_obs at 2t, context_actions at 2t+1, obs at 2T+t).
+ * Dropout (ob:2541) is left to the caller: identity in eval, torch's own RNG in training. */
+
+/* ob:2536  y [N][E] = x [N][Kin] . W [E][Kin]^T + b [E] (b may be NULL) -- the canonical Linear (one k-ordered fmaf
+ * chain per output, fp32 MFMA).  Used (i) once per parameter update on the codebook
+ * (x = codebook, N = K) to build the [K][E] table that replaces the Linear over the tokenizer's output rows, since
+ * z_latent[n] = codebook[idx[n]] (v5:47,84); (ii) on rows that are not codebook rows (observation streams). */
+int lipvq_linear_f32(const float* x, const float* W, const float* b, float* y, int64_t N, int Kin, int E,
+                     void* stream);
+
+/* ob:2537-2540 + ob:2584-2596  For n = b*T + t (n < N):
+ *     out[b*out_batch_stride + t*out_t_stride + out_offset + e] =
+ *         LayerNorm_e(src[idx ? idx[n] : n][e] + (pos ? pos[t][e] : 0)) * ln_w[e] + ln_b[e]
+ * src [src_rows][E] is the table (idx = the tokenizer's int64 indices) or dense pre-LayerNorm rows (idx NULL).
+ * pos [T][E] is the time embedding the reference adds (ob:2485-2523: nn.Parameter [1][T][E], nn.Embedding rows 0..T-1
+ * or the sinusoidal table).  The strides/offset (in floats, multiples of 4) place each row directly in its interleaved
+ * slot: context_actions use (3T*E, 2E, E), context_obs (3T*E, 2E, 0), obs (3T*E, E, 2T*E).  stats [N][2] (may be
+ * NULL) receives (mean, rstd) for the backward.  E: multiple of 4, <= 1024.  An index outside [0, src_rows) yields a
+ * NaN row (no fault). */
+int lipvq_embed_rows_f32(const float* src, const int64_t* idx, const float* pos, const float* ln_w, const float* ln_b,
+                         float eps, float* out, float* stats, int64_t N, int T, int E, int64_t src_rows,
+                         int64_t out_batch_stride, int64_t out_t_stride, int64_t out_offset, void* stream);
+
+/* Backward of lipvq_embed_rows_f32 (what autograd derives from ob:2536-2540).  gout is addressed like out.
+ * ACCUMULATES (caller zero-fills): g_src [src_rows][E] (gradient of the table rows; with idx NULL it is written, not
+ * accumulated), g_pos [T][E], g_lnw [E], g_lnb [E]; any of them may be NULL.  The Linear's own gradients follow from
+ * g_src with lipvq_wgrad_f32 (g_src^T . codebook) and lipvq_linear_f32 (g_src . W). */
+int lipvq_embed_rows_bwd_f32(const float* gout, const float* src, const int64_t* idx, const float* pos,
+                             const float* stats, const float* ln_w, float* g_src, float* g_pos, float* g_lnw,
+                             float* g_lnb, int64_t N, int T, int E, int64_t src_rows, int64_t out_batch_stride,
+                             int64_t out_t_stride, int64_t out_offset, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

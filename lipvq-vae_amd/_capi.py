@@ -54,6 +54,9 @@ SIGNATURES = {
     "lipvq_scatter_add_f32": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
     "lipvq_lipschitz_bwd_f32": (_i, [_vp] * 5 + [_i, _i, _vp]),
     "lipvq_scaled_diff_f32": (_i, [_vp, _vp, _vp, C.c_float, _vp, _vp, _i64, _vp]),
+    "lipvq_linear_f32": (_i, [_vp] * 4 + [_i64, _i, _i, _vp]),
+    "lipvq_embed_rows_f32": (_i, [_vp] * 5 + [C.c_float, _vp, _vp, _i64, _i, _i] + [_i64] * 4 + [_vp]),
+    "lipvq_embed_rows_bwd_f32": (_i, [_vp] * 10 + [_i64, _i, _i] + [_i64] * 4 + [_vp]),
 }
 
 

@@ -1,0 +1,371 @@
+// lipvq_embed.hip -- the step right after the tokenizer: the reference's
+// ICLTransformer.input_embedding() + the interleave of (context_obs, context_actions, obs)
+// (reference robomimic/models/obs_nets.py:2525-2543 and :2580-2596):
+//     e = LayerNorm(Linear(z_latent) + time_embedding[t])          dropout is the caller's (identity in eval)
+//     transformer_embeddings[b, 2t] = e(context_obs), [b, 2t+1] = e(context_actions), [b, 2T+t] = e(obs)
+//
+// MI355X design.  For the LipVQ tokenizer z_latent[n] IS codebook[idx[n]] (v5:47,84), so
+//     Linear(z_latent)[n] = (codebook . W^T + b)[idx[n]]
+// and the Linear over N rows collapses into a [K][E] table computed once per parameter update
+// (linear_kernel, fp32 MFMA, k-ordered chain from the bias = the canonical Linear).  The per-action work
+// is then a gather of one table row + the time embedding + LayerNorm, written straight into its interleaved
+// slot of the [B][3T][E] transformer input: one launch (embed_rows_kernel), HBM-write bound
+// (4 E bytes per action; the table and the time embeddings stay in L2), and z_latent itself never
+// exists in HBM -- the tokenizer hands over 8-byte indices.  Rows that are not codebook rows (the
+// observation streams, the VQVAE's straight-through value) take linear_kernel over their N rows and
+// then the same embed_rows_kernel with idx = NULL.
+//
+// Canonical LayerNorm (shared with oracle/lipvq_oracle.c, bit for bit): the row is owned by 64 lanes,
+// lane l holding the float4 groups q = l, l+64, ...;  lane sums run in that order, the 64 lane sums are
+// combined by an xor butterfly (32,16,8,4,2,1);  mean = s/E, var = sum((v-mean)^2)/E (fmaf chain, same
+// order), rstd = 1/sqrt(var+eps), y = fmaf((v-mean)*rstd, w, b).
+// ABI: include/lipvq.h.
+#include "lipvq_common.h"
+
+// ---------------------------------------------------------------------------------------------------
+// y[N][E] = x[N][Kin] . W[E][Kin]^T + b      (nn.Linear; obs_nets.py:2536 `embed_encoder`)
+// WG = 4 waves; tile = 32 rows x 128 columns, one 32x32 MFMA tile per wave; K staged 32 at a time.
+//   A operand: lane (m = lane & 31, kh = lane >> 5) = x[row0 + m][k0 + 2s + kh]
+//   B operand: lane (n = lane & 31, kh)             = W[e0 + n][k0 + 2s + kh]
+//   D[m][n]  : col n = lane & 31, row m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+// ---------------------------------------------------------------------------------------------------
+#define LIN_ROWS 32
+#define LIN_KC 32
+
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                     const float* __restrict__ bias, float* __restrict__ y,
+                                                     int64_t N, int Kin, int E) {
+    __shared__ float xs[LIN_ROWS][LIN_KC + 1];
+    __shared__ float ws[128][LIN_KC + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * LIN_ROWS;
+    const int e0 = blockIdx.y * 128;
+    const int ecol = e0 + wave * 32 + li;
+    const bool tile_ok = (e0 + wave * 32) < E;          // wave-uniform; a ragged last tile computes on zero rows of W
+    f32x16 acc;
+    const float b0 = (ecol < E && bias) ? bias[ecol] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = b0;
+    for (int k0 = 0; k0 < Kin; k0 += LIN_KC) {
+        // stage x: 32 x 32 floats, 4 per thread;  W: 128 x 32 floats, 16 per thread (zero beyond the edges)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + 256 * i, r = f >> 5, k = f & 31;
+            const int64_t row = row0 + r;
+            xs[r][k] = (row < N && k0 + k < Kin) ? x[(size_t)row * Kin + k0 + k] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int f = tid + 256 * i, r = f >> 5, k = f & 31;
+            const int e = e0 + r;
+            ws[r][k] = (e < E && k0 + k < Kin) ? W[(size_t)e * Kin + k0 + k] : 0.0f;
+        }
+        __syncthreads();
+        if (tile_ok) {
+            const int kend = (Kin - k0 < LIN_KC) ? ((Kin - k0 + 1) >> 1) : (LIN_KC / 2);
+            for (int s = 0; s < kend; ++s) {
+                const float a = xs[li][2 * s + kh];
+                const float b = ws[wave * 32 + li][2 * s + kh];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    if (ecol >= E) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (row < N) y[(size_t)row * E + ecol] = acc[r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// out[slot(n)][:] = LayerNorm(src[idx ? idx[n] : n][:] + pos[n % T][:])
+// One wave per row, 4 rows per workgroup, grid-stride.  NJ = float4 groups per lane = ceil(E / 256).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lq_wave_allsum(float s) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s = s + __shfl_xor(s, off, 64);
+    return s;
+}
+
+struct EmbedRowsArgs {
+    const float* src;
+    const int64_t* idx;
+    const float* pos;
+    const float* ln_w;
+    const float* ln_b;
+    float* out;
+    float* stats;
+    int64_t N, src_rows, out_bstride, out_tstride, out_offset;
+    int T, E;
+    float eps;
+};
+
+template <int NJ>
+__global__ __launch_bounds__(256) void embed_rows_kernel(const EmbedRowsArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int E4 = a.E >> 2;
+    const float fE = (float)a.E;
+    const float qnan = __builtin_nanf("");
+    float4 w[NJ], bb[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int q = lane + 64 * j;
+        if (q < E4) {
+            w[j] = reinterpret_cast<const float4*>(a.ln_w)[q];
+            bb[j] = reinterpret_cast<const float4*>(a.ln_b)[q];
+        }
+    }
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t n = wave0; n < a.N; n += nwaves) {
+        const int64_t k = a.idx ? a.idx[n] : n;
+        const bool ok = k >= 0 && k < a.src_rows;       // a bad index poisons its row instead of faulting
+        const int64_t b = n / a.T;
+        const int t = (int)(n - b * a.T);
+        const float4* srow = reinterpret_cast<const float4*>(a.src + (size_t)(ok ? k : 0) * a.E);
+        const float4* prow = a.pos ? reinterpret_cast<const float4*>(a.pos + (size_t)t * a.E) : nullptr;
+        float4 v[NJ];
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int q = lane + 64 * j;
+            if (q < E4) {
+                float4 c = srow[q];
+                if (prow) {
+                    const float4 p = prow[q];
+                    c.x = c.x + p.x; c.y = c.y + p.y; c.z = c.z + p.z; c.w = c.w + p.w;
+                }
+                v[j] = c;
+                s = s + c.x; s = s + c.y; s = s + c.z; s = s + c.w;
+            }
+        }
+        const float mean = lq_wave_allsum(s) / fE;
+        float ss = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int q = lane + 64 * j;
+            if (q < E4) {
+                float4 d = v[j];
+                d.x = d.x - mean; d.y = d.y - mean; d.z = d.z - mean; d.w = d.w - mean;
+                v[j] = d;
+                ss = lq_fma(d.x, d.x, ss); ss = lq_fma(d.y, d.y, ss);
+                ss = lq_fma(d.z, d.z, ss); ss = lq_fma(d.w, d.w, ss);
+            }
+        }
+        const float var = lq_wave_allsum(ss) / fE;
+        const float rstd = 1.0f / lq_sqrt(var + a.eps);
+        float4* orow = reinterpret_cast<float4*>(a.out + (size_t)(b * a.out_bstride + t * a.out_tstride + a.out_offset));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int q = lane + 64 * j;
+            if (q < E4) {
+                float4 o;
+                o.x = lq_fma(v[j].x * rstd, w[j].x, bb[j].x);
+                o.y = lq_fma(v[j].y * rstd, w[j].y, bb[j].y);
+                o.z = lq_fma(v[j].z * rstd, w[j].z, bb[j].z);
+                o.w = lq_fma(v[j].w * rstd, w[j].w, bb[j].w);
+                if (!ok) o = make_float4(qnan, qnan, qnan, qnan);
+                orow[q] = o;
+            }
+        }
+        if (a.stats && lane == 0) {
+            a.stats[2 * n] = mean;
+            a.stats[2 * n + 1] = rstd;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Backward of embed_rows_kernel.  gout is addressed like out.  Per row:
+//   xhat = (src[k] + pos[t] - mean) * rstd,  gh = gout * w,
+//   gv   = rstd * (gh - mean_e(gh) - xhat * mean_e(gh * xhat))
+//   g_src[k] += gv (atomic; = gradient of the table / of the dense pre-LayerNorm rows),  g_pos[t] += gv,
+//   g_lnw += gout * xhat,  g_lnb += gout   (kept in registers across the wave's rows, flushed once).
+// ---------------------------------------------------------------------------------------------------
+struct EmbedBwdArgs {
+    const float* gout;
+    const float* src;
+    const int64_t* idx;
+    const float* pos;
+    const float* stats;
+    const float* ln_w;
+    float* g_src;
+    float* g_pos;
+    float* g_lnw;
+    float* g_lnb;
+    int64_t N, src_rows, out_bstride, out_tstride, out_offset;
+    int T, E;
+};
+
+template <int NJ>
+__global__ __launch_bounds__(256) void embed_rows_bwd_kernel(const EmbedBwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int E4 = a.E >> 2;
+    const float fE = (float)a.E;
+    float4 w[NJ], aw[NJ], ab[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int q = lane + 64 * j;
+        aw[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ab[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < E4) w[j] = reinterpret_cast<const float4*>(a.ln_w)[q];
+    }
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t n = wave0; n < a.N; n += nwaves) {
+        const int64_t k = a.idx ? a.idx[n] : n;
+        if (k < 0 || k >= a.src_rows) continue;          // wave-uniform
+        const int64_t b = n / a.T;
+        const int t = (int)(n - b * a.T);
+        const float mean = a.stats[2 * n], rstd = a.stats[2 * n + 1];
+        const float4* srow = reinterpret_cast<const float4*>(a.src + (size_t)k * a.E);
+        const float4* prow = a.pos ? reinterpret_cast<const float4*>(a.pos + (size_t)t * a.E) : nullptr;
+        const float4* grow =
+            reinterpret_cast<const float4*>(a.gout + (size_t)(b * a.out_bstride + t * a.out_tstride + a.out_offset));
+        float4 xh[NJ], gh[NJ];
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int q = lane + 64 * j;
+            if (q < E4) {
+                float4 c = srow[q];
+                if (prow) {
+                    const float4 p = prow[q];
+                    c.x = c.x + p.x; c.y = c.y + p.y; c.z = c.z + p.z; c.w = c.w + p.w;
+                }
+                c.x = (c.x - mean) * rstd; c.y = (c.y - mean) * rstd;
+                c.z = (c.z - mean) * rstd; c.w = (c.w - mean) * rstd;
+                const float4 g = grow[q];
+                aw[j].x += g.x * c.x; aw[j].y += g.y * c.y; aw[j].z += g.z * c.z; aw[j].w += g.w * c.w;
+                ab[j].x += g.x; ab[j].y += g.y; ab[j].z += g.z; ab[j].w += g.w;
+                float4 h;
+                h.x = g.x * w[j].x; h.y = g.y * w[j].y; h.z = g.z * w[j].z; h.w = g.w * w[j].w;
+                s1 += (h.x + h.y) + (h.z + h.w);
+                s2 += (h.x * c.x + h.y * c.y) + (h.z * c.z + h.w * c.w);
+                xh[j] = c;
+                gh[j] = h;
+            }
+        }
+        const float c1 = lq_wave_allsum(s1) / fE, c2 = lq_wave_allsum(s2) / fE;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int q = lane + 64 * j;
+            if (q < E4) {
+                float4 gv;
+                gv.x = rstd * (gh[j].x - c1 - xh[j].x * c2);
+                gv.y = rstd * (gh[j].y - c1 - xh[j].y * c2);
+                gv.z = rstd * (gh[j].z - c1 - xh[j].z * c2);
+                gv.w = rstd * (gh[j].w - c1 - xh[j].w * c2);
+                if (a.g_src) {
+                    float* d = a.g_src + (size_t)k * a.E + 4 * q;
+                    if (a.idx) {
+                        atomicAdd(d + 0, gv.x); atomicAdd(d + 1, gv.y); atomicAdd(d + 2, gv.z); atomicAdd(d + 3, gv.w);
+                    } else {                                  // one row, one writer
+                        reinterpret_cast<float4*>(d)[0] = gv;
+                    }
+                }
+                if (a.g_pos) {
+                    float* d = a.g_pos + (size_t)t * a.E + 4 * q;
+                    atomicAdd(d + 0, gv.x); atomicAdd(d + 1, gv.y); atomicAdd(d + 2, gv.z); atomicAdd(d + 3, gv.w);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int q = lane + 64 * j;
+        if (q < E4) {
+            if (a.g_lnw) {
+                float* d = a.g_lnw + 4 * q;
+                atomicAdd(d + 0, aw[j].x); atomicAdd(d + 1, aw[j].y); atomicAdd(d + 2, aw[j].z); atomicAdd(d + 3, aw[j].w);
+            }
+            if (a.g_lnb) {
+                float* d = a.g_lnb + 4 * q;
+                atomicAdd(d + 0, ab[j].x); atomicAdd(d + 1, ab[j].y); atomicAdd(d + 2, ab[j].z); atomicAdd(d + 3, ab[j].w);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------
+static int embed_grid(int64_t N) {
+    int64_t g = (N + 3) / 4;
+    if (g > 2048) g = 2048;              // 8 workgroups per CU, grid-stride beyond
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+static int embed_check(const char* what, int64_t N, int T, int E, int64_t src_rows, int64_t bstride, int64_t tstride,
+                       int64_t offset) {
+    if (N < 0 || T <= 0 || src_rows <= 0) return fail(LIPVQ_EINVAL, "%s: bad sizes N=%lld T=%d src_rows=%lld", what,
+                                                      (long long)N, T, (long long)src_rows);
+    if (E <= 0 || (E & 3) || E > 1024) return fail(LIPVQ_EUNSUPPORTED, "%s: E=%d (need a multiple of 4, <= 1024)", what, E);
+    if ((bstride & 3) || (tstride & 3) || (offset & 3) || bstride < 0 || tstride < 0 || offset < 0)
+        return fail(LIPVQ_EINVAL, "%s: output strides/offset must be non-negative multiples of 4 floats", what);
+    return LIPVQ_OK;
+}
+
+extern "C" {
+
+int lipvq_linear_f32(const float* x, const float* W, const float* b, float* y, int64_t N, int Kin, int E,
+                     void* stream) {
+    if (!x || !W || !y) return fail(LIPVQ_EINVAL, "lipvq_linear_f32: null pointer");
+    if (N < 0 || Kin <= 0 || E <= 0) return fail(LIPVQ_EINVAL, "lipvq_linear_f32: bad sizes");
+    if (N == 0) return LIPVQ_OK;
+    const int64_t gx = (N + LIN_ROWS - 1) / LIN_ROWS;
+    if (gx > 0x7fffffffLL) return fail(LIPVQ_EUNSUPPORTED, "lipvq_linear_f32: N too large");
+    dim3 grid((unsigned)gx, (unsigned)((E + 127) / 128));
+    hipLaunchKernelGGL(linear_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, W, b, y, N, Kin, E);
+    return check_launch("linear_kernel");
+}
+
+int lipvq_embed_rows_f32(const float* src, const int64_t* idx, const float* pos, const float* ln_w, const float* ln_b,
+                         float eps, float* out, float* stats, int64_t N, int T, int E, int64_t src_rows,
+                         int64_t out_batch_stride, int64_t out_t_stride, int64_t out_offset, void* stream) {
+    if (!src || !ln_w || !ln_b || !out) return fail(LIPVQ_EINVAL, "lipvq_embed_rows_f32: null pointer");
+    const int rc = embed_check("lipvq_embed_rows_f32", N, T, E, src_rows, out_batch_stride, out_t_stride, out_offset);
+    if (rc) return rc;
+    if (!idx && src_rows < N) return fail(LIPVQ_EINVAL, "lipvq_embed_rows_f32: src has fewer rows than N");
+    if (N == 0) return LIPVQ_OK;
+    EmbedRowsArgs a{src, idx, pos, ln_w, ln_b, out, stats, N, src_rows, out_batch_stride, out_t_stride, out_offset, T, E, eps};
+    const dim3 grid(embed_grid(N)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch ((E + 255) / 256) {
+        case 1: hipLaunchKernelGGL(embed_rows_kernel<1>, grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL(embed_rows_kernel<2>, grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL(embed_rows_kernel<3>, grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL(embed_rows_kernel<4>, grid, block, 0, st, a); break;
+    }
+    return check_launch("embed_rows_kernel");
+}
+
+int lipvq_embed_rows_bwd_f32(const float* gout, const float* src, const int64_t* idx, const float* pos,
+                             const float* stats, const float* ln_w, float* g_src, float* g_pos, float* g_lnw,
+                             float* g_lnb, int64_t N, int T, int E, int64_t src_rows, int64_t out_batch_stride,
+                             int64_t out_t_stride, int64_t out_offset, void* stream) {
+    if (!gout || !src || !stats || !ln_w) return fail(LIPVQ_EINVAL, "lipvq_embed_rows_bwd_f32: null pointer");
+    const int rc = embed_check("lipvq_embed_rows_bwd_f32", N, T, E, src_rows, out_batch_stride, out_t_stride, out_offset);
+    if (rc) return rc;
+    if (!idx && src_rows < N) return fail(LIPVQ_EINVAL, "lipvq_embed_rows_bwd_f32: src has fewer rows than N");
+    if (N == 0) return LIPVQ_OK;
+    EmbedBwdArgs a{gout, src, idx, pos, stats, ln_w, g_src, g_pos, g_lnw, g_lnb, N, src_rows,
+                   out_batch_stride, out_t_stride, out_offset, T, E};
+    int g = embed_grid(N);
+    if (g > 512) g = 512;                 // fewer waves = fewer final flushes of the LayerNorm gradients
+    const dim3 grid(g), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch ((E + 255) / 256) {
+        case 1: hipLaunchKernelGGL(embed_rows_bwd_kernel<1>, grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL(embed_rows_bwd_kernel<2>, grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL(embed_rows_bwd_kernel<3>, grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL(embed_rows_bwd_kernel<4>, grid, block, 0, st, a); break;
+    }
+    return check_launch("embed_rows_bwd_kernel");
+}
+
+}  // extern "C"

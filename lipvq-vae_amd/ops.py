@@ -320,3 +320,72 @@ def tokenize(x, packed: PackedMlp3, raw, codebook, prep: PreparedCodebook, usage
                                      _ptr(usage), _ptr(ze), _ptr(ws), N, A, packed.J0, packed.J1, D, K, _stream()),
               "lipvq_tokenize_f32")
     return idx, zq, ze, ws
+
+
+# ---------------------------------------------------------------------------------------------------
+# the step after the tokenizer: input embedding + interleave (csrc/lipvq_embed.hip)
+# ---------------------------------------------------------------------------------------------------
+
+def linear(x, W, b=None):
+    """y = x . W^T + b (nn.Linear), canonical fp32 (reference obs_nets.py:2536 `embed_encoder`)."""
+    x, W = _chk(x, "x"), _chk(W, "W")
+    if x.dim() != 2 or W.dim() != 2 or W.shape[1] != x.shape[1]:
+        raise ValueError(f"linear: x {tuple(x.shape)} and W {tuple(W.shape)} do not match")
+    if b is not None:
+        b = _chk(b, "b")
+        if b.shape != (W.shape[0],):
+            raise ValueError("linear: bias shape")
+    N, Kin = x.shape
+    E = W.shape[0]
+    y = torch.empty((N, E), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        check(lib.lipvq_linear_f32(_ptr(x), _ptr(W), _ptr(b), _ptr(y), N, Kin, E, _stream()), "lipvq_linear_f32")
+    return y
+
+
+def _embed_args(src, idx, pos, N, T, E):
+    if src.dim() != 2 or src.shape[1] != E:
+        raise ValueError(f"embed_rows: src {tuple(src.shape)} is not [rows, {E}]")
+    if idx is not None:
+        idx = _chk(idx, "idx", torch.int64).reshape(-1)
+        if idx.numel() != N:
+            raise ValueError("embed_rows: idx must hold one index per row")
+    if pos is not None:
+        pos = _chk(pos, "pos")
+        if pos.shape != (T, E):
+            raise ValueError(f"embed_rows: pos {tuple(pos.shape)} is not [{T}, {E}]")
+    return idx, pos
+
+
+def embed_rows(src, idx, pos, ln_w, ln_b, eps, out, N, T, bstride, tstride, offset, want_stats=False):
+    """out[slot(n)] = LayerNorm(src[idx[n] | n] + pos[n % T]) * ln_w + ln_b, slot(b*T+t) = b*bstride + t*tstride + offset
+    floats into ``out`` (reference obs_nets.py:2537-2540 and the interleave of :2584-2596).  Returns stats [N,2] or None."""
+    src, ln_w, ln_b, out = _chk(src, "src"), _chk(ln_w, "ln_w"), _chk(ln_b, "ln_b"), _chk(out, "out")
+    E = ln_w.numel()
+    idx, pos = _embed_args(src, idx, pos, N, T, E)
+    if N:
+        B = (N + T - 1) // T
+        last = (B - 1) * bstride + (min(T, N) - 1) * tstride + offset + E
+        if last > out.numel():
+            raise ValueError("embed_rows: the output slots do not fit in `out`")
+    stats = torch.empty((N, 2), device=src.device, dtype=torch.float32) if want_stats else None
+    with torch.cuda.device(src.device):
+        check(lib.lipvq_embed_rows_f32(_ptr(src), _ptr(idx), _ptr(pos), _ptr(ln_w), _ptr(ln_b), float(eps), _ptr(out),
+                                       _ptr(stats), N, T, E, src.shape[0], bstride, tstride, offset, _stream()),
+              "lipvq_embed_rows_f32")
+    return stats
+
+
+def embed_rows_bwd(gout, src, idx, pos, stats, ln_w, g_src, g_pos, g_lnw, g_lnb, N, T, bstride, tstride, offset):
+    """Backward of embed_rows; accumulates into g_src / g_pos / g_lnw / g_lnb (each may be None)."""
+    gout, src, stats, ln_w = _chk(gout, "gout"), _chk(src, "src"), _chk(stats, "stats"), _chk(ln_w, "ln_w")
+    E = ln_w.numel()
+    idx, pos = _embed_args(src, idx, pos, N, T, E)
+    for name, t, shape in (("g_src", g_src, tuple(src.shape)), ("g_pos", g_pos, (T, E)), ("g_lnw", g_lnw, (E,)),
+                           ("g_lnb", g_lnb, (E,))):
+        if t is not None and (tuple(t.shape) != shape or not t.is_contiguous() or t.dtype != torch.float32):
+            raise ValueError(f"embed_rows_bwd: {name} must be a contiguous fp32 tensor of shape {shape}")
+    with torch.cuda.device(src.device):
+        check(lib.lipvq_embed_rows_bwd_f32(_ptr(gout), _ptr(src), _ptr(idx), _ptr(pos), _ptr(stats), _ptr(ln_w),
+                                           _ptr(g_src), _ptr(g_pos), _ptr(g_lnw), _ptr(g_lnb), N, T, E, src.shape[0],
+                                           bstride, tstride, offset, _stream()), "lipvq_embed_rows_bwd_f32")

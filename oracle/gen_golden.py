@@ -199,12 +199,76 @@ def run_nearest_edge(ref, name, D=64, K=96, N=160):
     print(f"{name}: N={N} K={K} D={D}")
 
 
+def run_embed(name, seed, B, T, Din, E, K, mode):
+    """Fixture for the step after the tokenizer (obs_nets.py:2525-2543, 2580-2596).  ICLTransformer itself cannot be
+    imported here (its module needs torchvision/robosuite/...), so the fixture is produced by the same stock
+    torch MODULES its constructor builds (obs_nets.py:2425-2450: nn.Linear, nn.Parameter | nn.Embedding | the
+    sinusoidal formula of transformers.py:58-77, nn.LayerNorm, nn.Dropout in eval) run in the order of its
+    input_embedding()/forward(); oracle.lipvq_oracle.torch_transformer_embeddings must agree bit for bit."""
+    ep = O.make_embed_params(seed, Din, E, T, mode)
+    rng = np.random.Generator(np.random.PCG64(seed + 15485863))
+    codebook = rng.uniform(0.0, 1.0, (K, Din)).astype(np.float32)
+    idx = rng.integers(0, K, (B, T)).astype(np.int64)
+    obs = rng.standard_normal((B, T, Din)).astype(np.float32)
+    cobs = rng.standard_normal((B, T, Din)).astype(np.float32)
+    nets, params = torch.nn.ModuleDict(), torch.nn.ParameterDict()
+    nets["embed_encoder"] = torch.nn.Linear(Din, E)
+    if mode == "parameter":
+        params["embed_timestep"] = torch.nn.Parameter(torch.zeros(1, T, E))
+    elif mode == "embedding":
+        nets["embed_timestep"] = torch.nn.Embedding(T, E)
+    nets["embed_ln"] = torch.nn.LayerNorm(E)
+    nets["embed_drop"] = torch.nn.Dropout(0.1)
+    nets.eval()
+    tp = O.to_torch(ep)
+    with torch.no_grad():
+        nets["embed_encoder"].weight.copy_(tp["embed_encoder.weight"]); nets["embed_encoder"].bias.copy_(tp["embed_encoder.bias"])
+        nets["embed_ln"].weight.copy_(tp["embed_ln.weight"]); nets["embed_ln"].bias.copy_(tp["embed_ln.bias"])
+        if mode == "parameter":
+            params["embed_timestep"].copy_(tp["embed_timestep"])
+        elif mode == "embedding":
+            nets["embed_timestep"].weight.copy_(tp["embed_timestep.weight"])
+
+    def input_embedding(inputs):
+        emb = nets["embed_encoder"](inputs)
+        ts = torch.arange(0, emb.shape[1], dtype=emb.dtype).unsqueeze(0).repeat(emb.shape[0], 1)
+        if mode == "parameter":
+            te = params["embed_timestep"]
+        elif mode == "embedding":
+            te = nets["embed_timestep"](ts.long())
+        else:
+            te = O.torch_sinusoidal(ts, E)
+        return nets["embed_drop"](nets["embed_ln"](emb + te))
+
+    with torch.no_grad():
+        actions = torch.from_numpy(codebook[idx])           # z_latent rows of the LipVQ tokenizer = codebook rows
+        o, co, ca = input_embedding(torch.from_numpy(obs)), input_embedding(torch.from_numpy(cobs)), input_embedding(actions)
+        inter = torch.stack([co, ca], dim=2).view(B, -1, E)
+        out = torch.cat([inter, o], dim=1)
+        mine = O.torch_transformer_embeddings(tp, torch.from_numpy(obs), torch.from_numpy(cobs), actions)
+    assert torch.equal(out, mine), "oracle torch restatement drifted from the stock-module sequence"
+    np.savez_compressed(GOLD / f"{name}.npz", meta=meta_of(name=name, seed=seed, B=B, T=T, Din=Din, E=E, K=K, mode=mode),
+                        digest=np.array(O.params_digest(ep)), codebook=codebook, indices=idx.astype(np.int32), obs=obs,
+                        context_obs=cobs, embeddings=out.numpy())
+    print(f"{name}: B={B} T={T} Din={Din} E={E} mode={mode}")
+
+
+def run_embed_all():
+    run_embed("embed_parameter", 301, 3, 10, 64, 512, 1024, "parameter")      # the reference defaults (icl_config.py:133-160)
+    run_embed("embed_embedding", 302, 2, 7, 32, 256, 256, "embedding")
+    run_embed("embed_sinusoidal", 303, 2, 5, 208, 384, 128, "sinusoidal")     # E not a multiple of 256, D = 208
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--only-init", action="store_true")
     ap.add_argument("--only-edge", action="store_true")
+    ap.add_argument("--only-embed", action="store_true")
     args = ap.parse_args()
+    if args.only_embed:
+        GOLD.mkdir(parents=True, exist_ok=True)
+        return run_embed_all()
     ref_root = Path(args.ref)
     v5 = load_ref(ref_root, "robomimic/models/vq_vae/backbone_lfqvae_v5.py", "_ref_v5")
     vq = load_ref(ref_root, "robomimic/models/vq_vae/backbone.py", "_ref_vq")
@@ -237,6 +301,7 @@ def main():
     run_vq(vq, "vq_default_init", 203, 128, 7, 32, 128, regime="default", oracle=orc)
     run_nearest_edge(v5, "llfq_nearest_edge")
     run_init(v5, vq)
+    run_embed_all()
 
 
 def run_init(v5, vq):

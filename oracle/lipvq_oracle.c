@@ -272,6 +272,87 @@ LQ_EXPORT void lq_ref_scatter_add(const float* g, const int64_t* idx, float* gC,
     free(acc);
 }
 
+/* ---- the step after the tokenizer: input_embedding + interleave --------------------
+ * ob = /root/reference/robomimic/models/obs_nets.py */
+
+/* ob:2536  y = x . W^T + b, the canonical Linear (nn.Linear `embed_encoder`). */
+LQ_EXPORT void lq_ref_linear(const float* x, const float* W, const float* b, float* y, int64_t N,
+                             int Kin, int E) {
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < N; ++n)
+        for (int e = 0; e < E; ++e)
+            y[(size_t)n * E + e] = chain(x + (size_t)n * Kin, W + (size_t)e * Kin, b ? b[e] : 0.0f, Kin);
+}
+
+/* Sum of E-float row pieces the way one 64-lane wavefront does it: lane l owns the float4 groups
+ * q = l, l+64, ... (sequential), the 64 lane values are then combined by an xor butterfly. */
+static float wave_allsum(float* lane) {
+    for (int off = 32; off >= 1; off >>= 1) {
+        float t[64];
+        for (int l = 0; l < 64; ++l) t[l] = lane[l] + lane[l ^ off];
+        memcpy(lane, t, sizeof(t));
+    }
+    return lane[0];
+}
+
+/* ob:2537-2540 + ob:2584-2596  out[slot(n)] = LayerNorm(src[idx ? idx[n] : n] + pos[n % T]) * w + b, with
+ * slot(n = b*T + t) = b*bstride + t*tstride + offset (floats).  stats (nullable) [N][2] = (mean, rstd).
+ * An index outside [0, src_rows) gives a NaN row. */
+LQ_EXPORT void lq_ref_embed_rows(const float* src, const int64_t* idx, const float* pos, const float* ln_w,
+                                 const float* ln_b, float eps, float* out, float* stats, int64_t N, int T,
+                                 int E, int64_t src_rows, int64_t bstride, int64_t tstride, int64_t offset) {
+    const int E4 = E / 4;
+#pragma omp parallel
+    {
+        float* v = (float*)malloc(sizeof(float) * (size_t)E);
+#pragma omp for schedule(static)
+        for (int64_t n = 0; n < N; ++n) {
+            const int64_t k = idx ? idx[n] : n;
+            const int64_t b = n / T;
+            const int t = (int)(n - b * T);
+            float* o = out + (size_t)(b * bstride + t * tstride + offset);
+            if (k < 0 || k >= src_rows) {
+                for (int e = 0; e < E; ++e) o[e] = NAN;
+                if (stats) stats[2 * n] = stats[2 * n + 1] = NAN;
+                continue;
+            }
+            float lane[64];
+            for (int l = 0; l < 64; ++l) {
+                float s = 0.0f;
+                for (int q = l; q < E4; q += 64)
+                    for (int c = 0; c < 4; ++c) {
+                        const int e = 4 * q + c;
+                        float val = src[(size_t)k * E + e];
+                        if (pos) val = val + pos[(size_t)t * E + e];
+                        v[e] = val;
+                        s = s + val;
+                    }
+                lane[l] = s;
+            }
+            const float mean = wave_allsum(lane) / (float)E;
+            for (int l = 0; l < 64; ++l) {
+                float ss = 0.0f;
+                for (int q = l; q < E4; q += 64)
+                    for (int c = 0; c < 4; ++c) {
+                        const int e = 4 * q + c;
+                        const float d = v[e] - mean;
+                        v[e] = d;
+                        ss = lq_fma(d, d, ss);
+                    }
+                lane[l] = ss;
+            }
+            const float var = wave_allsum(lane) / (float)E;
+            const float rstd = 1.0f / lq_sqrt(var + eps);
+            for (int e = 0; e < E; ++e) o[e] = lq_fma(v[e] * rstd, ln_w[e], ln_b[e]);
+            if (stats) {
+                stats[2 * n] = mean;
+                stats[2 * n + 1] = rstd;
+            }
+        }
+        free(v);
+    }
+}
+
 /* Probes for tests/test_oracle_math.py */
 LQ_EXPORT void lq_ref_math_probe(const float* x, float* out, int64_t n, int fn) {
     for (int64_t i = 0; i < n; ++i) {

@@ -235,6 +235,48 @@ class CanonicalOracle:
                 "decoder.2.weight": gd["W1"], "decoder.2.bias": gd["b1"], "to_output.weight": gd["W2"],
                 "to_output.bias": gd["b2"]}
 
+    # -- the step after the tokenizer: input embedding + interleave (obs_nets.py:2525-2543, 2580-2596) -----
+    def linear(self, x, W, b=None):
+        x, W = _f32(x), _f32(W)
+        N, Kin = x.shape
+        E = W.shape[0]
+        assert W.shape[1] == Kin
+        b = None if b is None else _f32(b)
+        y = np.empty((N, E), np.float32)
+        self.lib.lq_ref_linear(_p(x), _p(W), _p(b), _p(y), C.c_int64(N), C.c_int(Kin), C.c_int(E))
+        return y
+
+    def embed_rows(self, src, idx, pos, ln_w, ln_b, eps, out, T, bstride, tstride, offset, N=None, want_stats=False):
+        """Writes into ``out`` (a float32 C-contiguous numpy array, addressed flat); returns stats or None."""
+        src, ln_w, ln_b = _f32(src), _f32(ln_w), _f32(ln_b)
+        E = src.shape[1]
+        idx = None if idx is None else np.ascontiguousarray(idx, np.int64)
+        pos = None if pos is None else _f32(pos).reshape(-1, E)
+        if N is None:
+            N = src.shape[0] if idx is None else idx.size
+        assert out.dtype == np.float32 and out.flags.c_contiguous
+        stats = np.empty((N, 2), np.float32) if want_stats else None
+        self.lib.lq_ref_embed_rows(_p(src), _p(idx, C.c_int64), _p(pos), _p(ln_w), _p(ln_b), C.c_float(eps), _p(out),
+                                   _p(stats), C.c_int64(N), C.c_int(T), C.c_int(E), C.c_int64(src.shape[0]),
+                                   C.c_int64(bstride), C.c_int64(tstride), C.c_int64(offset))
+        return stats
+
+    def transformer_embeddings(self, ep, obs, context_obs, codebook, idx, eps=1e-5):
+        """[B][3T][E] input of the transformer backbone: the observation streams through the dense Linear, the
+        context actions through the codebook table (idx [B][T] = the tokenizer's indices)."""
+        obs, context_obs = _f32(obs), _f32(context_obs)
+        B, T, Din = obs.shape
+        W, b = ep["embed_encoder.weight"], ep["embed_encoder.bias"]
+        E = W.shape[0]
+        pos = embed_time_table(ep, T)
+        out = np.empty((B, 3 * T, E), np.float32)
+        lw, lb = ep["embed_ln.weight"], ep["embed_ln.bias"]
+        table = self.linear(codebook, W, b)
+        self.embed_rows(self.linear(context_obs.reshape(B * T, Din), W, b), None, pos, lw, lb, eps, out, T, 3 * T * E, 2 * E, 0)
+        self.embed_rows(table, np.asarray(idx).reshape(-1), pos, lw, lb, eps, out, T, 3 * T * E, 2 * E, E)
+        self.embed_rows(self.linear(obs.reshape(B * T, Din), W, b), None, pos, lw, lb, eps, out, T, 3 * T * E, E, 2 * T * E)
+        return out
+
     def vq_grads(self, p, x, commitment_cost=0.25, fwd=None):
         f = fwd or self.vq_forward(p, x, commitment_cost)
         x = _f32(x)
@@ -335,6 +377,84 @@ def torch_vq_forward(p, x, commitment_cost=0.25):
     recon = F.mse_loss(h, x)
     return z_latent, recon + q_loss, dict(z_e=z_e, indices=idx, x_recon=h, recon_loss=recon,
                                           quantization_loss=q_loss)
+
+
+# --- the step after the tokenizer (reference robomimic/models/obs_nets.py = "ob") ---------------------
+# The reference class (ICLTransformer, ob:2330-2640) cannot be imported in the build container (its module pulls
+# torchvision / robosuite / ...), so these functions restate ob:2485-2543 and ob:2580-2596 with the same stock torch
+# ops on a dict keyed like its state_dict ("nets.embed_encoder.weight" -> "embed_encoder.weight", ...).
+
+EMBED_MODES = ("parameter", "embedding", "sinusoidal")     # ob:2431-2445: nn.Parameter | nn.Embedding | sinusoidal
+
+
+def embed_time_table(ep, T):
+    """[T][E] float32 rows the reference adds to the embeddings of timesteps 0..T-1 (ob:2485-2523)."""
+    if "embed_timestep" in ep:                              # nn.Parameter [1][max_timestep][E], ob:2437-2439
+        tab = np.asarray(ep["embed_timestep"], np.float32)[0]
+        assert tab.shape[0] == T, "nn.Parameter time embeddings broadcast only when T == context_length"
+        return tab
+    if "embed_timestep.weight" in ep:                       # nn.Embedding(max_timestep, E), ob:2441-2443
+        return np.asarray(ep["embed_timestep.weight"], np.float32)[:T]
+    import torch
+    E = ep["embed_encoder.weight"].shape[0]
+    return torch_sinusoidal(torch.arange(T, dtype=torch.float32)[None], E)[0].numpy()
+
+
+def torch_sinusoidal(timesteps, E):
+    """PositionalEncoding.forward (reference robomimic/models/transformers.py:58-77) on float timesteps [B][T]."""
+    import math
+    import torch
+    div = torch.exp(torch.arange(0, E, 2) * (-math.log(10000.0) / E))[None, None].repeat(timesteps.shape[0], timesteps.shape[1], 1)
+    pe = torch.zeros((timesteps.shape[0], timesteps.shape[1], E))
+    pe[:, :, 0::2] = torch.sin(timesteps.unsqueeze(-1) * div)
+    pe[:, :, 1::2] = torch.cos(timesteps.unsqueeze(-1) * div)
+    return pe.detach()
+
+
+def torch_input_embedding(ep, inputs, eps=1e-5):
+    """ob:2525-2543 in eval mode (embed_drop = identity): LayerNorm(Linear(inputs) + time_embeddings)."""
+    import torch
+    import torch.nn.functional as F
+    emb = F.linear(inputs, ep["embed_encoder.weight"], ep["embed_encoder.bias"])          # ob:2536
+    B, T, E = emb.shape
+    timesteps = torch.arange(0, T, dtype=emb.dtype).unsqueeze(0).repeat(B, 1)             # ob:2493-2502
+    if "embed_timestep" in ep:
+        time_emb = ep["embed_timestep"]                                                     # ob:2509-2510
+    elif "embed_timestep.weight" in ep:
+        time_emb = F.embedding(timesteps.long(), ep["embed_timestep.weight"])              # ob:2507,2512
+    else:
+        time_emb = torch_sinusoidal(timesteps, E)
+    emb = emb + time_emb                                                                    # ob:2538
+    return F.layer_norm(emb, (E,), ep["embed_ln.weight"], ep["embed_ln.bias"], eps)         # ob:2539
+
+
+def torch_transformer_embeddings(ep, obs, context_obs, context_actions):
+    """ob:2580-2596: embed the three streams, interleave the context pairs, append the observations."""
+    import torch
+    o = torch_input_embedding(ep, obs)
+    co = torch_input_embedding(ep, context_obs)
+    ca = torch_input_embedding(ep, context_actions)
+    bs, _, D = o.shape
+    inter = torch.stack([co, ca], dim=2).view(bs, -1, D)
+    return torch.cat([inter, o], dim=1)
+
+
+def make_embed_params(seed, Din, E, T, mode="parameter"):
+    """Seeded parameters of the embedding stage keyed like the reference state_dict (minus the nets./params. prefix).
+    The reference initialises the nn.Parameter time embedding and LayerNorm trivially (zeros / ones); a trained-like
+    draw is used instead so that every term of the formula is exercised."""
+    rng = np.random.Generator(np.random.PCG64(seed + 104729))
+    W, b = _linear_init(rng, E, Din)
+    ep = {"embed_encoder.weight": W, "embed_encoder.bias": b,
+          "embed_ln.weight": (1.0 + 0.1 * rng.standard_normal(E)).astype(np.float32),
+          "embed_ln.bias": (0.1 * rng.standard_normal(E)).astype(np.float32)}
+    if mode == "parameter":
+        ep["embed_timestep"] = (0.02 * rng.standard_normal((1, T, E))).astype(np.float32)
+    elif mode == "embedding":
+        ep["embed_timestep.weight"] = rng.standard_normal((T, E)).astype(np.float32)
+    elif mode != "sinusoidal":
+        raise ValueError(mode)
+    return ep
 
 
 # ---------------------------------------------------------------------------------------------
