@@ -15,10 +15,10 @@
 // observation streams, the VQVAE's straight-through value) take linear_kernel over their N rows and
 // then the same embed_rows_kernel with idx = NULL.
 //
-// Canonical LayerNorm (shared with oracle/lipvq_oracle.c, bit for bit): the row is owned by 64 lanes,
-// lane l holding the float4 groups q = l, l+64, ...;  lane sums run in that order, the 64 lane sums are
-// combined by an xor butterfly (32,16,8,4,2,1);  mean = s/E, var = sum((v-mean)^2)/E (fmaf chain, same
-// order), rstd = 1/sqrt(var+eps), y = fmaf((v-mean)*rstd, w, b).
+// Canonical LayerNorm (shared with oracle/lipvq_oracle.c, bit for bit): a row is owned by 16 lanes, lane l holding the
+// float4 groups q = l, l+16, ...;  lane sums run in that order and the 16 lane sums are combined by a butterfly with
+// partners l^1, l^2, l^7, l^15 (four DPP adds);  mean = s*(1/E), var = sum((v-mean)^2)*(1/E) (fmaf chain, same order),
+// rstd = 1/sqrt(var+eps), y = fmaf((v-mean)*rstd, w, b).
 // ABI: include/lipvq.h.
 #include "lipvq_common.h"
 
@@ -82,8 +82,31 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
 
 // ---------------------------------------------------------------------------------------------------
 // out[slot(n)][:] = LayerNorm(src[idx ? idx[n] : n][:] + pos[n % T][:])
-// One wave per row, 4 rows per workgroup, grid-stride.  NJ = float4 groups per lane = ceil(E / 256).
+// 16 lanes own one row (4 rows per wavefront step): the per-row work that every lane repeats (the two reductions --
+// four DPP adds each --, the reciprocal square root, address arithmetic) is shared by four rows per instruction, which
+// is what keeps the VALU under the store stream.  NJ = float4 groups per lane (16 NJ >= E / 4).
+// A workgroup takes 16*chunk consecutive rows per grid-stride step (step r: wave w, lane group g -> row n0 + 16 r + 4 w + g),
+// so its stores sweep one contiguous span of the output; each wave fetches its indices for all steps with one vector
+// load; ln_w / ln_b sit in LDS; the [T][E] time table is read through the vector L1 (20 KiB at the reference's T = 10).
 // ---------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float lq_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+// all-reduce over the 16 lanes of a DPP row; partner order l^1, l^2, l^7, l^15 (the oracle's row_allsum)
+__device__ __forceinline__ float lq_row_allsum(float s) {
+#ifdef LQ_EMB_NORED
+    return s;               // ablation only (wrong results)
+#endif
+    s = s + lq_dpp<0xB1>(s);        // quad_perm [1,0,3,2]
+    s = s + lq_dpp<0x4E>(s);        // quad_perm [2,3,0,1]
+    s = s + lq_dpp<0x141>(s);       // row_half_mirror
+    s = s + lq_dpp<0x140>(s);       // row_mirror
+    return s;
+}
+
+// 64-lane butterfly (backward kernel only; no canonical order attached)
 __device__ __forceinline__ float lq_wave_allsum(float s) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s = s + __shfl_xor(s, off, 64);
@@ -99,81 +122,104 @@ struct EmbedRowsArgs {
     float* out;
     float* stats;
     int64_t N, src_rows, out_bstride, out_tstride, out_offset;
-    int T, E;
+    int T, E, chunk;
     float eps;
 };
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define EMB_CHUNK 16        // most steps per workgroup item (4 indices per step and wave: 64 lanes fetch 16 steps)
+
 template <int NJ>
 __global__ __launch_bounds__(256) void embed_rows_kernel(const EmbedRowsArgs a) {
-    const int lane = threadIdx.x & 63;
+    extern __shared__ float4 emb_lds[];                      // [ln_w: E4][ln_b: E4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l = lane & 15;
     const int E4 = a.E >> 2;
-    const float fE = (float)a.E;
-    const float qnan = __builtin_nanf("");
-    float4 w[NJ], bb[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int q = lane + 64 * j;
-        if (q < E4) {
-            w[j] = reinterpret_cast<const float4*>(a.ln_w)[q];
-            bb[j] = reinterpret_cast<const float4*>(a.ln_b)[q];
-        }
+    float4* sw = emb_lds;
+    float4* sb = sw + E4;
+    for (int q = tid; q < E4; q += 256) {
+        sw[q] = reinterpret_cast<const float4*>(a.ln_w)[q];
+        sb[q] = reinterpret_cast<const float4*>(a.ln_b)[q];
     }
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
-    for (int64_t n = wave0; n < a.N; n += nwaves) {
-        const int64_t k = a.idx ? a.idx[n] : n;
-        const bool ok = k >= 0 && k < a.src_rows;       // a bad index poisons its row instead of faulting
-        const int64_t b = n / a.T;
-        const int t = (int)(n - b * a.T);
-        const float4* srow = reinterpret_cast<const float4*>(a.src + (size_t)(ok ? k : 0) * a.E);
-        const float4* prow = a.pos ? reinterpret_cast<const float4*>(a.pos + (size_t)t * a.E) : nullptr;
-        float4 v[NJ];
-        float s = 0.0f;
+    __syncthreads();
+    const float invE = 1.0f / (float)a.E;
+    const float qnan = __builtin_nanf("");
+    const int q16 = 16 / a.T, r16 = 16 - q16 * a.T;
+    const int64_t per_item = 16 * (int64_t)a.chunk;
+    for (int64_t n0 = (int64_t)blockIdx.x * per_item; n0 < a.N; n0 += (int64_t)gridDim.x * per_item) {
+        // this wave's indices for all steps of the item in one vector load: lane (r = lane >> 2, g = lane & 3)
+        int64_t kv = n0 + (lane >> 2) * 16 + wave * 4 + (lane & 3);
+        if (a.idx && kv < a.N && (lane >> 2) < a.chunk) kv = a.idx[kv];
+        int64_t n = n0 + wave * 4 + g;
+        int64_t b = n / a.T;
+        int t = (int)(n - b * a.T);
+        for (int r = 0; r < a.chunk; ++r) {
+            const bool live = n < a.N;
+            const int64_t k = __shfl(kv, 4 * r + g, 64);
+            const bool ok = k >= 0 && k < a.src_rows;          // a bad index poisons its row instead of faulting
+            const float4* srow = reinterpret_cast<const float4*>(a.src + (size_t)((ok && live) ? k : 0) * a.E);
+            const float4* prow = a.pos ? reinterpret_cast<const float4*>(a.pos + (size_t)(live ? t : 0) * a.E) : nullptr;
+            float4 v[NJ];
+            float s = 0.0f;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int q = lane + 64 * j;
-            if (q < E4) {
-                float4 c = srow[q];
-                if (prow) {
-                    const float4 p = prow[q];
-                    c.x = c.x + p.x; c.y = c.y + p.y; c.z = c.z + p.z; c.w = c.w + p.w;
+            for (int j = 0; j < NJ; ++j) {
+                const int q = l + 16 * j;
+                if (q < E4) {
+#ifdef LQ_EMB_NOLOAD
+                    float4 c = make_float4((float)k, (float)q, 1.0f, 2.0f);      // ablation only (wrong results)
+#else
+                    float4 c = srow[q];
+#endif
+                    if (a.pos) {
+                        const float4 p = prow[q];
+                        c.x = c.x + p.x; c.y = c.y + p.y; c.z = c.z + p.z; c.w = c.w + p.w;
+                    }
+                    v[j] = c;
+                    s = s + c.x; s = s + c.y; s = s + c.z; s = s + c.w;
                 }
-                v[j] = c;
-                s = s + c.x; s = s + c.y; s = s + c.z; s = s + c.w;
             }
-        }
-        const float mean = lq_wave_allsum(s) / fE;
-        float ss = 0.0f;
+            const float mean = lq_row_allsum(s) * invE;
+            float ss = 0.0f;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int q = lane + 64 * j;
-            if (q < E4) {
-                float4 d = v[j];
-                d.x = d.x - mean; d.y = d.y - mean; d.z = d.z - mean; d.w = d.w - mean;
-                v[j] = d;
-                ss = lq_fma(d.x, d.x, ss); ss = lq_fma(d.y, d.y, ss);
-                ss = lq_fma(d.z, d.z, ss); ss = lq_fma(d.w, d.w, ss);
-            }
-        }
-        const float var = lq_wave_allsum(ss) / fE;
-        const float rstd = 1.0f / lq_sqrt(var + a.eps);
-        float4* orow = reinterpret_cast<float4*>(a.out + (size_t)(b * a.out_bstride + t * a.out_tstride + a.out_offset));
+            for (int j = 0; j < NJ; ++j)
+                if (l + 16 * j < E4) {
+                    float4 d = v[j];
+                    d.x = d.x - mean; d.y = d.y - mean; d.z = d.z - mean; d.w = d.w - mean;
+                    v[j] = d;
+                    ss = lq_fma(d.x, d.x, ss); ss = lq_fma(d.y, d.y, ss);
+                    ss = lq_fma(d.z, d.z, ss); ss = lq_fma(d.w, d.w, ss);
+                }
+            const float var = lq_row_allsum(ss) * invE;
+            const float rstd = 1.0f / lq_sqrt(var + a.eps);
+            float4* orow = reinterpret_cast<float4*>(a.out + (size_t)(b * a.out_bstride + t * a.out_tstride + a.out_offset));
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int q = lane + 64 * j;
-            if (q < E4) {
-                float4 o;
-                o.x = lq_fma(v[j].x * rstd, w[j].x, bb[j].x);
-                o.y = lq_fma(v[j].y * rstd, w[j].y, bb[j].y);
-                o.z = lq_fma(v[j].z * rstd, w[j].z, bb[j].z);
-                o.w = lq_fma(v[j].w * rstd, w[j].w, bb[j].w);
-                if (!ok) o = make_float4(qnan, qnan, qnan, qnan);
-                orow[q] = o;
+            for (int j = 0; j < NJ; ++j) {
+                const int q = l + 16 * j;
+                if (q < E4 && live) {
+                    const float4 w = sw[q], bb = sb[q];
+                    f32x4 o;
+                    o.x = lq_fma(v[j].x * rstd, w.x, bb.x);
+                    o.y = lq_fma(v[j].y * rstd, w.y, bb.y);
+                    o.z = lq_fma(v[j].z * rstd, w.z, bb.z);
+                    o.w = lq_fma(v[j].w * rstd, w.w, bb.w);
+                    if (!ok) o = f32x4{qnan, qnan, qnan, qnan};
+#ifdef LQ_EMB_NOSTORE
+                    if (o.x == 12345.678f) *reinterpret_cast<f32x4*>(orow + q) = o;     // ablation only
+#elif defined(LQ_EMB_NO_NT)
+                    *reinterpret_cast<f32x4*>(orow + q) = o;
+#else
+                    __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(orow + q));   // written once, read by a later launch
+#endif
+                }
             }
-        }
-        if (a.stats && lane == 0) {
-            a.stats[2 * n] = mean;
-            a.stats[2 * n + 1] = rstd;
+            if (a.stats && live && l == 0) {
+                a.stats[2 * n] = ok ? mean : qnan;
+                a.stats[2 * n + 1] = ok ? rstd : qnan;
+            }
+            n += 16;
+            t += r16;
+            b += q16;
+            if (t >= a.T) { t -= a.T; ++b; }
         }
     }
 }
@@ -293,11 +339,20 @@ __global__ __launch_bounds__(256) void embed_rows_bwd_kernel(const EmbedBwdArgs 
 // ---------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------
-static int embed_grid(int64_t N) {
-    int64_t g = (N + 3) / 4;
-    if (g > 2048) g = 2048;              // 8 workgroups per CU, grid-stride beyond
+static int embed_grid(int64_t rows_per_wg_step, int64_t N) {
+    int64_t g = (N + rows_per_wg_step - 1) / rows_per_wg_step;
+#ifndef LQ_EMB_GRID
+#define LQ_EMB_GRID 2048
+#endif
+    if (g > LQ_EMB_GRID) g = LQ_EMB_GRID;              // 8 workgroups per CU, grid-stride beyond
     if (g < 1) g = 1;
     return (int)g;
+}
+
+// small batches (a training step) spread 16 rows per workgroup; large ones up to 16 * EMB_CHUNK consecutive rows
+static int embed_chunk(int64_t N) {
+    const int64_t c = N / (16 * 2048);
+    return c < 1 ? 1 : (c > EMB_CHUNK ? EMB_CHUNK : (int)c);
 }
 
 static int embed_check(const char* what, int64_t N, int T, int E, int64_t src_rows, int64_t bstride, int64_t tstride,
@@ -332,15 +387,17 @@ int lipvq_embed_rows_f32(const float* src, const int64_t* idx, const float* pos,
     if (rc) return rc;
     if (!idx && src_rows < N) return fail(LIPVQ_EINVAL, "lipvq_embed_rows_f32: src has fewer rows than N");
     if (N == 0) return LIPVQ_OK;
-    EmbedRowsArgs a{src, idx, pos, ln_w, ln_b, out, stats, N, src_rows, out_batch_stride, out_t_stride, out_offset, T, E, eps};
-    const dim3 grid(embed_grid(N)), block(256);
+    const int chunk = embed_chunk(N);
+    EmbedRowsArgs a{src, idx, pos, ln_w, ln_b, out, stats, N, src_rows, out_batch_stride, out_t_stride, out_offset, T, E,
+                    chunk, eps};
+    const dim3 grid(embed_grid(16 * chunk, N)), block(256);
+    const size_t lds = (size_t)2 * E * sizeof(float);       // ln_w, ln_b
     hipStream_t st = (hipStream_t)stream;
-    switch ((E + 255) / 256) {
-        case 1: hipLaunchKernelGGL(embed_rows_kernel<1>, grid, block, 0, st, a); break;
-        case 2: hipLaunchKernelGGL(embed_rows_kernel<2>, grid, block, 0, st, a); break;
-        case 3: hipLaunchKernelGGL(embed_rows_kernel<3>, grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL(embed_rows_kernel<4>, grid, block, 0, st, a); break;
-    }
+    const int nj = (E / 4 + 15) / 16;
+    if (nj <= 2) hipLaunchKernelGGL(embed_rows_kernel<2>, grid, block, lds, st, a);
+    else if (nj <= 4) hipLaunchKernelGGL(embed_rows_kernel<4>, grid, block, lds, st, a);
+    else if (nj <= 8) hipLaunchKernelGGL(embed_rows_kernel<8>, grid, block, lds, st, a);
+    else hipLaunchKernelGGL(embed_rows_kernel<16>, grid, block, lds, st, a);
     return check_launch("embed_rows_kernel");
 }
 
@@ -355,7 +412,7 @@ int lipvq_embed_rows_bwd_f32(const float* gout, const float* src, const int64_t*
     if (N == 0) return LIPVQ_OK;
     EmbedBwdArgs a{gout, src, idx, pos, stats, ln_w, g_src, g_pos, g_lnw, g_lnb, N, src_rows,
                    out_batch_stride, out_t_stride, out_offset, T, E};
-    int g = embed_grid(N);
+    int g = embed_grid(4, N);
     if (g > 512) g = 512;                 // fewer waves = fewer final flushes of the LayerNorm gradients
     const dim3 grid(g), block(256);
     hipStream_t st = (hipStream_t)stream;

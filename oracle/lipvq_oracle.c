@@ -284,12 +284,12 @@ LQ_EXPORT void lq_ref_linear(const float* x, const float* W, const float* b, flo
             y[(size_t)n * E + e] = chain(x + (size_t)n * Kin, W + (size_t)e * Kin, b ? b[e] : 0.0f, Kin);
 }
 
-/* Sum of E-float row pieces the way one 64-lane wavefront does it: lane l owns the float4 groups
- * q = l, l+64, ... (sequential), the 64 lane values are then combined by an xor butterfly. */
-static float wave_allsum(float* lane) {
-    for (int off = 32; off >= 1; off >>= 1) {
-        float t[64];
-        for (int l = 0; l < 64; ++l) t[l] = lane[l] + lane[l ^ off];
+/* Sum of 16 lane values the way the kernel's 16-lane DPP butterfly does it: partners l^1, l^2, l^7, l^15. */
+static float row_allsum(float* lane) {
+    static const int partner[4] = {1, 2, 7, 15};
+    for (int st = 0; st < 4; ++st) {
+        float t[16];
+        for (int l = 0; l < 16; ++l) t[l] = lane[l] + lane[l ^ partner[st]];
         memcpy(lane, t, sizeof(t));
     }
     return lane[0];
@@ -302,6 +302,7 @@ LQ_EXPORT void lq_ref_embed_rows(const float* src, const int64_t* idx, const flo
                                  const float* ln_b, float eps, float* out, float* stats, int64_t N, int T,
                                  int E, int64_t src_rows, int64_t bstride, int64_t tstride, int64_t offset) {
     const int E4 = E / 4;
+    const float invE = 1.0f / (float)E;
 #pragma omp parallel
     {
         float* v = (float*)malloc(sizeof(float) * (size_t)E);
@@ -316,10 +317,10 @@ LQ_EXPORT void lq_ref_embed_rows(const float* src, const int64_t* idx, const flo
                 if (stats) stats[2 * n] = stats[2 * n + 1] = NAN;
                 continue;
             }
-            float lane[64];
-            for (int l = 0; l < 64; ++l) {
+            float lane[16];                                  /* lane l owns the float4 groups q = l, l+16, ... */
+            for (int l = 0; l < 16; ++l) {
                 float s = 0.0f;
-                for (int q = l; q < E4; q += 64)
+                for (int q = l; q < E4; q += 16)
                     for (int c = 0; c < 4; ++c) {
                         const int e = 4 * q + c;
                         float val = src[(size_t)k * E + e];
@@ -329,10 +330,10 @@ LQ_EXPORT void lq_ref_embed_rows(const float* src, const int64_t* idx, const flo
                     }
                 lane[l] = s;
             }
-            const float mean = wave_allsum(lane) / (float)E;
-            for (int l = 0; l < 64; ++l) {
+            const float mean = row_allsum(lane) * invE;
+            for (int l = 0; l < 16; ++l) {
                 float ss = 0.0f;
-                for (int q = l; q < E4; q += 64)
+                for (int q = l; q < E4; q += 16)
                     for (int c = 0; c < 4; ++c) {
                         const int e = 4 * q + c;
                         const float d = v[e] - mean;
@@ -341,7 +342,7 @@ LQ_EXPORT void lq_ref_embed_rows(const float* src, const int64_t* idx, const flo
                     }
                 lane[l] = ss;
             }
-            const float var = wave_allsum(lane) / (float)E;
+            const float var = row_allsum(lane) * invE;
             const float rstd = 1.0f / lq_sqrt(var + eps);
             for (int e = 0; e < E; ++e) o[e] = lq_fma(v[e] * rstd, ln_w[e], ln_b[e]);
             if (stats) {

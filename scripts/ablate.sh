@@ -8,6 +8,6 @@ for abl in "$@"; do
   make -s -C lipvq-vae_amd/csrc clean
   make -s -j8 -C lipvq-vae_amd/csrc FLAGS="$BASE $abl" 2>&1 | grep -E "error" || true
   echo "=== build: [$abl]"
-  python scripts/${ABL_SCRIPT:-measure_screen.py} ${ABL_WL:-cfg2} 2>&1 | grep -E "equal|screened|fused" || true
+  python scripts/${ABL_SCRIPT:-measure_screen.py} ${ABL_WL-cfg2} 2>&1 | grep -E "${ABL_GREP:-equal|screened|fused}" || true
 done
 make -s -C lipvq-vae_amd/csrc clean; make -s -j8 -C lipvq-vae_amd/csrc 2>&1 | grep error || true

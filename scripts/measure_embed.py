@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--K", type=int, default=1024)
     ap.add_argument("--D", type=int, default=64)
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--contig", action="store_true", help="write [N][E] contiguously instead of into the 2t+1 slots")
     a = ap.parse_args()
     N = a.rows // a.T * a.T
     dev = "cuda"
@@ -52,13 +53,20 @@ def main():
     out = torch.empty((N // a.T, 3 * a.T, a.E), device=dev)
     table = ops.linear(cb, W, b)
     t_table = timed(lambda: ops.linear(cb, W, b), a.iters)
-    t_rows = timed(lambda: ops.embed_rows(table, idx, pos, lw, lb, 1e-5, out, N, a.T, 3 * a.T * a.E, 2 * a.E, a.E), a.iters)
+    if a.contig:
+        t_rows = timed(lambda: ops.embed_rows(table, idx, pos, lw, lb, 1e-5, out, N, a.T, a.T * a.E, a.E, 0), a.iters)
+    else:
+        t_rows = timed(lambda: ops.embed_rows(table, idx, pos, lw, lb, 1e-5, out, N, a.T, 3 * a.T * a.E, 2 * a.E, a.E), a.iters)
     bytes_rows = N * (4 * a.E + 8)
-    print(json.dumps({"kernel": "embed_rows_kernel", "rows": N, "E": a.E, "T": a.T, "K": a.K, "us": t_rows * 1e6,
+    print(json.dumps({"kernel": "embed_rows_kernel", "contig": a.contig, "rows": N, "E": a.E, "T": a.T, "K": a.K, "us": t_rows * 1e6,
                       "actions_per_s": N / t_rows, "algorithmic_GBps": bytes_rows / t_rows / 1e9,
                       "frac_of_hbm_peak": bytes_rows / t_rows / 1e9 / HBM_PEAK_GBS}))
     print(json.dumps({"kernel": "linear_kernel(table)", "K": a.K, "D": a.D, "E": a.E, "us": t_table * 1e6,
                       "TFLOPs": 2.0 * a.K * a.D * a.E / t_table / 1e12}))
+    flat = out.view(-1)[:N * a.E]
+    t_fill = timed(lambda: flat.fill_(1.0), a.iters)
+    print(json.dumps({"kernel": "torch fill_ of the same bytes (store-bandwidth calibration)", "us": t_fill * 1e6,
+                      "GBps": N * a.E * 4 / t_fill / 1e9}))
     # what the reference does instead: gather z_q rows, cuBLAS-style Linear over N rows, add, LayerNorm, stack/view/cat
     zq = cb[idx].view(N // a.T, a.T, a.D)
     ln = torch.nn.LayerNorm(a.E).to(dev)

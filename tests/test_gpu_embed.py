@@ -70,7 +70,7 @@ def test_embed_rows_bad_index_and_errors():
     with pytest.raises(ValueError):
         ops.embed_rows(table, idx, None, w, b, 1e-5, out, 4, T, 3 * T * E, E, 0)       # does not fit
     with pytest.raises(LipvqLibraryError):
-        ops.embed_rows(table, idx, None, w, b, 1e-5, out, 4, T, T * E, E + 2, 0)       # stride not a multiple of 4
+        ops.embed_rows(table, idx, None, w, b, 1e-5, torch.zeros(1024, device="cuda"), 4, T, T * E, E + 2, 0)   # stride % 4
     with pytest.raises(RuntimeError):
         ops.linear(torch.randn(3, 4), torch.randn(5, 4))                                # CPU tensors: no fallback
 
