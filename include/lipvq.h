@@ -196,6 +196,39 @@ int lipvq_embed_rows_bwd_f32(const float* gout, const float* src, const int64_t*
                              float* g_lnb, int64_t N, int T, int E, int64_t src_rows, int64_t out_batch_stride,
                              int64_t out_t_stride, int64_t out_offset, void* stream);
 
+/* lipvq_linear_f32 with an activation epilogue: y = act(x . W^T + b); pre (may be NULL) receives the pre-activation
+ * for the backward.  bin:29-30 (second Linear + GELU of AdaptiveBinActionEmbedding.output_layer). */
+int lipvq_linear_act_f32(const float* x, const float* W, const float* b, float* y, float* pre, int64_t N, int Kin,
+                         int E, int act, void* stream);
+
+/* ---- the sibling tokenizer behind `bin_enabled` (obs_nets.py:1214-1217): AdaptiveBinActionEmbedding,
+ *      bin = robomimic/models/bin_action/backbone.py; lipvq-vae_amd/csrc/lipvq_bin.hip ---- */
+
+/* bin:37-40 update_running_stats(): running_min[i] = min(running_min[i], min_n actions[n][i]), running_max likewise,
+ * updated IN PLACE (actions [N][A], buffers [A]). */
+int lipvq_bin_minmax_f32(const float* actions, float* running_min, float* running_max, int64_t N, int A, void* stream);
+
+/* bin:42-66 compute_bins() + discretize(): bins[i][n] = clamp(bucketize(actions[n][i], linspace(running_min[i],
+ * running_max[i], num_bins + 1)) - 1, 0, num_bins - 1).  bins is int64 [A][N] (dimension-major: each dimension's
+ * indices are contiguous; the reference's [N][A] stack is its transpose).  Bit-exact restatement of torch's linspace
+ * rounding and lower-bound search.  A * (num_bins + 1) <= 4096. */
+int lipvq_bin_discretize_f32(const float* actions, const float* running_min, const float* running_max, int64_t* bins,
+                             int64_t N, int A, int num_bins, void* stream);
+
+/* bin:42-53 compute_bins() alone: boundaries [A][num_bins + 1] = linspace(running_min[i], running_max[i], num_bins + 1). */
+int lipvq_bin_boundaries_f32(const float* running_min, const float* running_max, float* boundaries, int A, int num_bins,
+                             void* stream);
+
+/* bin:77-86 embeddings + cat + output_layer[0..1]:  pre1[n][j] = b1[j] + sum_i P[i][bins[i][n]][j], h = gelu(pre1).
+ * P [A][num_bins][H] = per-dimension product of the embedding table with its 64-column block of the first Linear's
+ * weight (lipvq_linear_f32(emb_i, W1[:, 64 i : 64 i + 64], NULL)), rebuilt when a parameter changes.  h [N][H];
+ * pre1 [N][H] may be NULL. */
+int lipvq_bin_hidden_f32(const int64_t* bins, const float* P, const float* b1, float* h, float* pre1, int64_t N, int A,
+                         int num_bins, int H, void* stream);
+
+/* out = g * act'(pre), elementwise over n floats (backward of the GELUs of bin:28,30). */
+int lipvq_act_bwd_f32(const float* g, const float* pre, float* out, int64_t n, int act, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,7 +34,7 @@
 
 __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                      const float* __restrict__ bias, float* __restrict__ y,
-                                                     int64_t N, int Kin, int E) {
+                                                     float* __restrict__ pre, int act, int64_t N, int Kin, int E) {
     __shared__ float xs[LIN_ROWS][LIN_KC + 1];
     __shared__ float ws[128][LIN_KC + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -76,7 +76,10 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (row < N) y[(size_t)row * E + ecol] = acc[r];
+        if (row < N) {
+            if (pre) pre[(size_t)row * E + ecol] = acc[r];
+            y[(size_t)row * E + ecol] = lq_act_apply(acc[r], act);
+        }
     }
 }
 
@@ -367,16 +370,22 @@ static int embed_check(const char* what, int64_t N, int T, int E, int64_t src_ro
 
 extern "C" {
 
-int lipvq_linear_f32(const float* x, const float* W, const float* b, float* y, int64_t N, int Kin, int E,
-                     void* stream) {
-    if (!x || !W || !y) return fail(LIPVQ_EINVAL, "lipvq_linear_f32: null pointer");
-    if (N < 0 || Kin <= 0 || E <= 0) return fail(LIPVQ_EINVAL, "lipvq_linear_f32: bad sizes");
+int lipvq_linear_act_f32(const float* x, const float* W, const float* b, float* y, float* pre, int64_t N, int Kin,
+                         int E, int act, void* stream) {
+    if (!x || !W || !y) return fail(LIPVQ_EINVAL, "lipvq_linear_act_f32: null pointer");
+    if (N < 0 || Kin <= 0 || E <= 0) return fail(LIPVQ_EINVAL, "lipvq_linear_act_f32: bad sizes");
+    if (act < LIPVQ_ACT_NONE || act > LIPVQ_ACT_RELU) return fail(LIPVQ_EINVAL, "lipvq_linear_act_f32: bad activation %d", act);
     if (N == 0) return LIPVQ_OK;
     const int64_t gx = (N + LIN_ROWS - 1) / LIN_ROWS;
-    if (gx > 0x7fffffffLL) return fail(LIPVQ_EUNSUPPORTED, "lipvq_linear_f32: N too large");
+    if (gx > 0x7fffffffLL) return fail(LIPVQ_EUNSUPPORTED, "lipvq_linear_act_f32: N too large");
     dim3 grid((unsigned)gx, (unsigned)((E + 127) / 128));
-    hipLaunchKernelGGL(linear_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, W, b, y, N, Kin, E);
+    hipLaunchKernelGGL(linear_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, W, b, y, pre, act, N, Kin, E);
     return check_launch("linear_kernel");
+}
+
+int lipvq_linear_f32(const float* x, const float* W, const float* b, float* y, int64_t N, int Kin, int E,
+                     void* stream) {
+    return lipvq_linear_act_f32(x, W, b, y, nullptr, N, Kin, E, LIPVQ_ACT_NONE, stream);
 }
 
 int lipvq_embed_rows_f32(const float* src, const int64_t* idx, const float* pos, const float* ln_w, const float* ln_b,

@@ -227,4 +227,27 @@ LQ_HD float lq_sqdist32(const float* z, const float* c, int D) {
     return s;
 }
 
+/* ---- AdaptiveBinActionEmbedding (reference robomimic/models/bin_action/backbone.py = "bin") -------------
+ * bin:47-49 torch.linspace(min, max, steps) in fp32 as torch's CPU kernel rounds it (probed for 2..257 steps):
+ * step = (end - start) / (steps - 1);  element i = fma(step, i, start) below the midpoint, fma(-step, steps-1-i, end)
+ * from it on. */
+LQ_HD float lq_linspace(float start, float end, int steps, int i) {
+    const float step = (end - start) / (float)(steps - 1);
+    return (i < steps / 2) ? lq_fma(step, (float)i, start) : lq_fma(-step, (float)(steps - i - 1), end);
+}
+
+/* bin:60-63 torch.bucketize(v, boundaries) (right = False) followed by clamp(idx - 1, 0, nb - 1): the same binary
+ * search as torch's lower bound (the test is !(mid >= v), so a NaN lands in the last bin), over the nb + 1 boundaries. */
+LQ_HD int lq_bin_index(float v, const float* boundaries, int nb) {
+    int lo = 0, hi = nb + 1;
+    while (lo < hi) {
+        const int mid = lo + ((hi - lo) >> 1);
+        if (!(boundaries[mid] >= v)) lo = mid + 1; else hi = mid;
+    }
+    int b = lo - 1;
+    if (b < 0) b = 0;
+    if (b > nb - 1) b = nb - 1;
+    return b;
+}
+
 #endif /* LIPVQ_MATH_H_ */

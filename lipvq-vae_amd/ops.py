@@ -326,8 +326,9 @@ def tokenize(x, packed: PackedMlp3, raw, codebook, prep: PreparedCodebook, usage
 # the step after the tokenizer: input embedding + interleave (csrc/lipvq_embed.hip)
 # ---------------------------------------------------------------------------------------------------
 
-def linear(x, W, b=None):
-    """y = x . W^T + b (nn.Linear), canonical fp32 (reference obs_nets.py:2536 `embed_encoder`)."""
+def linear(x, W, b=None, act=ACT_NONE, save_pre=False):
+    """y = act(x . W^T + b) (nn.Linear), canonical fp32 (reference obs_nets.py:2536 `embed_encoder`; with act = GELU the
+    second half of AdaptiveBinActionEmbedding.output_layer).  save_pre=True returns (y, pre-activation)."""
     x, W = _chk(x, "x"), _chk(W, "W")
     if x.dim() != 2 or W.dim() != 2 or W.shape[1] != x.shape[1]:
         raise ValueError(f"linear: x {tuple(x.shape)} and W {tuple(W.shape)} do not match")
@@ -338,9 +339,11 @@ def linear(x, W, b=None):
     N, Kin = x.shape
     E = W.shape[0]
     y = torch.empty((N, E), device=x.device, dtype=torch.float32)
+    pre = torch.empty_like(y) if save_pre else None
     with torch.cuda.device(x.device):
-        check(lib.lipvq_linear_f32(_ptr(x), _ptr(W), _ptr(b), _ptr(y), N, Kin, E, _stream()), "lipvq_linear_f32")
-    return y
+        check(lib.lipvq_linear_act_f32(_ptr(x), _ptr(W), _ptr(b), _ptr(y), _ptr(pre), N, Kin, E, int(act), _stream()),
+              "lipvq_linear_act_f32")
+    return (y, pre) if save_pre else y
 
 
 def _embed_args(src, idx, pos, N, T, E):
@@ -389,3 +392,67 @@ def embed_rows_bwd(gout, src, idx, pos, stats, ln_w, g_src, g_pos, g_lnw, g_lnb,
         check(lib.lipvq_embed_rows_bwd_f32(_ptr(gout), _ptr(src), _ptr(idx), _ptr(pos), _ptr(stats), _ptr(ln_w),
                                            _ptr(g_src), _ptr(g_pos), _ptr(g_lnw), _ptr(g_lnb), N, T, E, src.shape[0],
                                            bstride, tstride, offset, _stream()), "lipvq_embed_rows_bwd_f32")
+
+
+# ---------------------------------------------------------------------------------------------------
+# AdaptiveBinActionEmbedding (csrc/lipvq_bin.hip; reference robomimic/models/bin_action/backbone.py)
+# ---------------------------------------------------------------------------------------------------
+
+def bin_minmax(actions, running_min, running_max):
+    """In-place running min/max update (backbone.py:37-40)."""
+    actions = _chk(actions, "actions")
+    for name, t in (("running_min", running_min), ("running_max", running_max)):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.shape == (actions.shape[1],)):
+            raise ValueError(f"bin_minmax: {name} must be a contiguous fp32 CUDA tensor of shape [{actions.shape[1]}]")
+    N, A = actions.shape
+    with torch.cuda.device(actions.device):
+        check(lib.lipvq_bin_minmax_f32(_ptr(actions), _ptr(running_min), _ptr(running_max), N, A, _stream()),
+              "lipvq_bin_minmax_f32")
+
+
+def bin_discretize(actions, running_min, running_max, num_bins):
+    """bins [A, N] int64 (backbone.py:42-66; the reference's [N, A] stack is bins.t())."""
+    actions, running_min, running_max = _chk(actions, "actions"), _chk(running_min, "running_min"), _chk(running_max, "running_max")
+    N, A = actions.shape
+    bins = torch.empty((A, N), device=actions.device, dtype=torch.int64)
+    with torch.cuda.device(actions.device):
+        check(lib.lipvq_bin_discretize_f32(_ptr(actions), _ptr(running_min), _ptr(running_max), _ptr(bins), N, A,
+                                           int(num_bins), _stream()), "lipvq_bin_discretize_f32")
+    return bins
+
+
+def bin_boundaries(running_min, running_max, num_bins):
+    """[A, num_bins + 1] bin boundaries (backbone.py:42-53)."""
+    running_min, running_max = _chk(running_min, "running_min"), _chk(running_max, "running_max")
+    A = running_min.numel()
+    out = torch.empty((A, num_bins + 1), device=running_min.device, dtype=torch.float32)
+    with torch.cuda.device(out.device):
+        check(lib.lipvq_bin_boundaries_f32(_ptr(running_min), _ptr(running_max), _ptr(out), A, int(num_bins), _stream()),
+              "lipvq_bin_boundaries_f32")
+    return out
+
+
+def bin_hidden(bins, P, b1, save_pre=False):
+    """h = gelu(b1 + sum_i P[i][bins[i]]) (backbone.py:77-86 up to the first GELU).  P [A, num_bins, H]."""
+    bins, P, b1 = _chk(bins, "bins", torch.int64), _chk(P, "P"), _chk(b1, "b1")
+    A, N = bins.shape
+    if P.dim() != 3 or P.shape[0] != A or b1.shape != (P.shape[2],):
+        raise ValueError("bin_hidden: P must be [A, num_bins, H] and b1 [H]")
+    nb, H = P.shape[1], P.shape[2]
+    h = torch.empty((N, H), device=P.device, dtype=torch.float32)
+    pre = torch.empty_like(h) if save_pre else None
+    with torch.cuda.device(P.device):
+        check(lib.lipvq_bin_hidden_f32(_ptr(bins), _ptr(P), _ptr(b1), _ptr(h), _ptr(pre), N, A, nb, H, _stream()),
+              "lipvq_bin_hidden_f32")
+    return (h, pre) if save_pre else h
+
+
+def act_bwd(g, pre, act):
+    """g * act'(pre), elementwise."""
+    g, pre = _chk(g, "g"), _chk(pre, "pre")
+    if g.shape != pre.shape:
+        raise ValueError("act_bwd: shapes differ")
+    out = torch.empty_like(g)
+    with torch.cuda.device(g.device):
+        check(lib.lipvq_act_bwd_f32(_ptr(g), _ptr(pre), _ptr(out), g.numel(), int(act), _stream()), "lipvq_act_bwd_f32")
+    return out

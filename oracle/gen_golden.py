@@ -259,17 +259,62 @@ def run_embed_all():
     run_embed("embed_sinusoidal", 303, 2, 5, 208, 384, 128, "sinusoidal")     # E not a multiple of 256, D = 208
 
 
+def run_bin(binmod, name, seed, N, A, D, nb=20):
+    """Fixture of the sibling tokenizer (AdaptiveBinActionEmbedding, bin_action/backbone.py), produced by the
+    REFERENCE CLASS ITSELF (the module imports only torch): two forward calls that update the running statistics, a
+    third with the statistics frozen on wider-range actions (out-of-range values clamp into the edge bins), and the
+    parameter gradients of sum(out * R) of the third call."""
+    bp = O.make_bin_params(seed, A, D, nb)
+    m = binmod.AdaptiveBinActionEmbedding(A, D, num_bins=nb)
+    sd = {k: torch.from_numpy(v.copy()) for k, v in bp.items()}
+    sd["running_min"], sd["running_max"] = m.running_min.clone(), m.running_max.clone()
+    m.load_state_dict(sd, strict=True)
+    tp = O.to_torch(bp)
+    xs = [O.make_inputs(seed + 1, N, A), O.make_inputs(seed + 2, N, A, clamp=True), 1.5 * O.make_inputs(seed + 3, N, A)]
+    rmin, rmax = torch.full((A,), float("inf")), torch.full((A,), float("-inf"))
+    out = {}
+    for step, x in enumerate(xs):
+        xt = torch.from_numpy(x)
+        if step == 2:
+            m._update_enabled = False                      # what num_step_stop does (bin:71-74)
+        y = m(xt)
+        idx = m.discretize(xt)
+        mine, midx, rmin, rmax = O.torch_bin_forward(tp, xt, rmin, rmax, update=step < 2)
+        assert torch.equal(y, mine) and torch.equal(idx, midx), "torch restatement drifted from the reference"
+        assert torch.equal(rmin, m.running_min) and torch.equal(rmax, m.running_max)
+        out[f"x{step}"], out[f"out{step}"], out[f"bins{step}"] = x, y.detach().numpy(), idx.numpy().astype(np.int32)
+        out[f"rmin{step}"], out[f"rmax{step}"] = m.running_min.numpy().copy(), m.running_max.numpy().copy()
+    R = np.random.Generator(np.random.PCG64(seed + 9)).standard_normal(out["out2"].shape).astype(np.float32)
+    m.zero_grad()
+    (m(torch.from_numpy(xs[2])) * torch.from_numpy(R)).sum().backward()
+    grads = {"grad/" + k: v.grad.numpy().copy() for k, v in m.named_parameters()}
+    np.savez_compressed(GOLD / f"{name}.npz", meta=meta_of(name=name, seed=seed, N=N, A=A, D=D, nb=nb),
+                        digest=np.array(O.params_digest(bp)), R=R, **out, **grads)
+    print(f"{name}: N={N} A={A} D={D} nb={nb}")
+
+
+def run_bin_all(ref_root):
+    binmod = load_ref(ref_root, "robomimic/models/bin_action/backbone.py", "_ref_bin")
+    run_bin(binmod, "bin_icrt", 401, 80, 12, 208)           # the ICRT step shape (obs_nets.py:2411: A = 12)
+    run_bin(binmod, "bin_a7", 402, 333, 7, 64)              # BASELINE's action width, ragged N
+    run_bin(binmod, "bin_nb5", 403, 64, 3, 32, nb=5)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--only-init", action="store_true")
     ap.add_argument("--only-edge", action="store_true")
     ap.add_argument("--only-embed", action="store_true")
+    ap.add_argument("--only-bin", action="store_true")
     args = ap.parse_args()
     if args.only_embed:
         GOLD.mkdir(parents=True, exist_ok=True)
         return run_embed_all()
     ref_root = Path(args.ref)
+    if args.only_bin:
+        GOLD.mkdir(parents=True, exist_ok=True)
+        return run_bin_all(ref_root)
     v5 = load_ref(ref_root, "robomimic/models/vq_vae/backbone_lfqvae_v5.py", "_ref_v5")
     vq = load_ref(ref_root, "robomimic/models/vq_vae/backbone.py", "_ref_vq")
     GOLD.mkdir(parents=True, exist_ok=True)
@@ -302,6 +347,7 @@ def main():
     run_nearest_edge(v5, "llfq_nearest_edge")
     run_init(v5, vq)
     run_embed_all()
+    run_bin_all(ref_root)
 
 
 def run_init(v5, vq):

@@ -354,6 +354,58 @@ LQ_EXPORT void lq_ref_embed_rows(const float* src, const int64_t* idx, const flo
     }
 }
 
+/* ---- the sibling tokenizer behind `bin_enabled`: AdaptiveBinActionEmbedding ------------
+ * bin = /root/reference/robomimic/models/bin_action/backbone.py */
+
+/* ob:2536 / bin:29-30  y = act(x . W^T + b); pre (nullable) = the pre-activation. */
+LQ_EXPORT void lq_ref_linear_act(const float* x, const float* W, const float* b, float* y, float* pre, int64_t N,
+                                 int Kin, int E, int act) {
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < N; ++n)
+        for (int e = 0; e < E; ++e) {
+            const float a = chain(x + (size_t)n * Kin, W + (size_t)e * Kin, b ? b[e] : 0.0f, Kin);
+            if (pre) pre[(size_t)n * E + e] = a;
+            y[(size_t)n * E + e] = act_apply(a, act);
+        }
+}
+
+/* bin:37-40 update_running_stats(), in place. */
+LQ_EXPORT void lq_ref_bin_minmax(const float* actions, float* rmin, float* rmax, int64_t N, int A) {
+    for (int64_t n = 0; n < N; ++n)
+        for (int i = 0; i < A; ++i) {
+            const float v = actions[(size_t)n * A + i];
+            if (v < rmin[i]) rmin[i] = v;
+            if (v > rmax[i]) rmax[i] = v;
+        }
+}
+
+/* bin:42-66 compute_bins() + discretize(); bins [A][N] int64; boundaries (nullable) [A][nb+1]. */
+LQ_EXPORT void lq_ref_bin_discretize(const float* actions, const float* rmin, const float* rmax, int64_t* bins,
+                                     float* boundaries, int64_t N, int A, int nb) {
+    float* bd = (float*)malloc(sizeof(float) * (size_t)A * (nb + 1));
+    for (int i = 0; i < A; ++i)
+        for (int j = 0; j <= nb; ++j) bd[i * (nb + 1) + j] = lq_linspace(rmin[i], rmax[i], nb + 1, j);
+    if (boundaries) memcpy(boundaries, bd, sizeof(float) * (size_t)A * (nb + 1));
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < N; ++n)
+        for (int i = 0; i < A; ++i)
+            bins[(size_t)i * N + n] = lq_bin_index(actions[(size_t)n * A + i], bd + i * (nb + 1), nb);
+    free(bd);
+}
+
+/* bin:77-86 through the P table: pre1[n][j] = b1[j] + sum_i P[i][bins[i][n]][j] (i ascending), h = gelu(pre1). */
+LQ_EXPORT void lq_ref_bin_hidden(const int64_t* bins, const float* P, const float* b1, float* h, float* pre1,
+                                 int64_t N, int A, int nb, int H) {
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < N; ++n)
+        for (int j = 0; j < H; ++j) {
+            float acc = b1[j];
+            for (int i = 0; i < A; ++i) acc = acc + P[((size_t)i * nb + bins[(size_t)i * N + n]) * H + j];
+            if (pre1) pre1[(size_t)n * H + j] = acc;
+            h[(size_t)n * H + j] = lq_gelu(acc);
+        }
+}
+
 /* Probes for tests/test_oracle_math.py */
 LQ_EXPORT void lq_ref_math_probe(const float* x, float* out, int64_t n, int fn) {
     for (int64_t i = 0; i < n; ++i) {

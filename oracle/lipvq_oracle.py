@@ -277,6 +277,61 @@ class CanonicalOracle:
         self.embed_rows(self.linear(obs.reshape(B * T, Din), W, b), None, pos, lw, lb, eps, out, T, 3 * T * E, E, 2 * T * E)
         return out
 
+    # -- AdaptiveBinActionEmbedding (reference robomimic/models/bin_action/backbone.py) ---------------------
+    def linear_act(self, x, W, b, act, save_pre=False):
+        x, W = _f32(x), _f32(W)
+        N, Kin = x.shape
+        E = W.shape[0]
+        b = None if b is None else _f32(b)
+        y = np.empty((N, E), np.float32)
+        pre = np.empty((N, E), np.float32) if save_pre else None
+        self.lib.lq_ref_linear_act(_p(x), _p(W), _p(b), _p(y), _p(pre), C.c_int64(N), C.c_int(Kin), C.c_int(E), C.c_int(act))
+        return (y, pre) if save_pre else y
+
+    def bin_minmax(self, actions, rmin, rmax):
+        actions = _f32(actions)
+        rmin, rmax = _f32(rmin).copy(), _f32(rmax).copy()
+        self.lib.lq_ref_bin_minmax(_p(actions), _p(rmin), _p(rmax), C.c_int64(actions.shape[0]), C.c_int(actions.shape[1]))
+        return rmin, rmax
+
+    def bin_discretize(self, actions, rmin, rmax, nb, want_boundaries=False):
+        actions, rmin, rmax = _f32(actions), _f32(rmin), _f32(rmax)
+        N, A = actions.shape
+        bins = np.empty((A, N), np.int64)
+        bd = np.empty((A, nb + 1), np.float32) if want_boundaries else None
+        self.lib.lq_ref_bin_discretize(_p(actions), _p(rmin), _p(rmax), _p(bins, C.c_int64), _p(bd), C.c_int64(N),
+                                       C.c_int(A), C.c_int(nb))
+        return (bins, bd) if want_boundaries else bins
+
+    def bin_table(self, bp):
+        """P [A][nb][H]: per-dimension product of the embedding table with its block of output_layer.0.weight."""
+        W1 = _f32(bp["output_layer.0.weight"])
+        A = sum(1 for k in bp if k.startswith("embedding_layers.") and k.endswith(".weight"))
+        ed = bp["embedding_layers.0.weight"].shape[1]
+        return np.stack([self.linear(bp[f"embedding_layers.{i}.weight"], np.ascontiguousarray(W1[:, ed * i:ed * (i + 1)]))
+                         for i in range(A)])
+
+    def bin_hidden(self, bins, P, b1, save_pre=False):
+        bins = np.ascontiguousarray(bins, np.int64)
+        P, b1 = _f32(P), _f32(b1)
+        A, N = bins.shape
+        nb, H = P.shape[1], P.shape[2]
+        h = np.empty((N, H), np.float32)
+        pre = np.empty((N, H), np.float32) if save_pre else None
+        self.lib.lq_ref_bin_hidden(_p(bins, C.c_int64), _p(P), _p(b1), _p(h), _p(pre), C.c_int64(N), C.c_int(A),
+                                   C.c_int(nb), C.c_int(H))
+        return (h, pre) if save_pre else h
+
+    def bin_forward(self, bp, actions, rmin, rmax, update=True):
+        """AdaptiveBinActionEmbedding.forward (backbone.py:68-89): returns dict(out, bins [A][N], running_min/max)."""
+        nb = bp["embedding_layers.0.weight"].shape[0]
+        if update:
+            rmin, rmax = self.bin_minmax(actions, rmin, rmax)
+        bins = self.bin_discretize(actions, rmin, rmax, nb)
+        h = self.bin_hidden(bins, self.bin_table(bp), bp["output_layer.0.bias"])
+        out = self.linear_act(h, bp["output_layer.2.weight"], bp["output_layer.2.bias"], ACT_GELU)
+        return {"out": out, "bins": bins, "running_min": rmin, "running_max": rmax, "hidden": h}
+
     def vq_grads(self, p, x, commitment_cost=0.25, fwd=None):
         f = fwd or self.vq_forward(p, x, commitment_cost)
         x = _f32(x)
@@ -455,6 +510,39 @@ def make_embed_params(seed, Din, E, T, mode="parameter"):
     elif mode != "sinusoidal":
         raise ValueError(mode)
     return ep
+
+
+# --- AdaptiveBinActionEmbedding (reference robomimic/models/bin_action/backbone.py = "bin") -----------------
+
+def torch_bin_forward(bp, actions, rmin, rmax, update=True):
+    """bin:68-89 with the stock torch ops of the reference on a dict keyed like its state_dict; returns
+    (out [N, D], bin_indices [N, A] int64, running_min, running_max)."""
+    import torch
+    import torch.nn.functional as F
+    A = actions.shape[1]
+    nb = bp["embedding_layers.0.weight"].shape[0]
+    if update:                                                                        # bin:37-40
+        rmin = torch.minimum(rmin, actions.min(dim=0)[0])
+        rmax = torch.maximum(rmax, actions.max(dim=0)[0])
+    idx = []
+    for i in range(A):                                                                # bin:42-66
+        boundaries = torch.linspace(rmin[i], rmax[i], nb + 1)
+        idx.append(torch.clamp(torch.bucketize(actions[:, i], boundaries) - 1, 0, nb - 1))
+    idx = torch.stack(idx, dim=1)
+    emb = torch.cat([F.embedding(idx[:, i], bp[f"embedding_layers.{i}.weight"]) for i in range(A)], dim=-1)   # bin:77-83
+    h = F.gelu(F.linear(emb, bp["output_layer.0.weight"], bp["output_layer.0.bias"]))                          # bin:26-31
+    out = F.gelu(F.linear(h, bp["output_layer.2.weight"], bp["output_layer.2.bias"]))
+    return out, idx, rmin, rmax
+
+
+def make_bin_params(seed, A, D, nb=20, ed=64):
+    """Seeded parameters keyed like AdaptiveBinActionEmbedding.state_dict() (minus the two buffers): nn.Embedding
+    N(0,1), nn.Linear defaults."""
+    rng = np.random.Generator(np.random.PCG64(seed + 32452843))
+    bp = {f"embedding_layers.{i}.weight": rng.standard_normal((nb, ed)).astype(np.float32) for i in range(A)}
+    bp["output_layer.0.weight"], bp["output_layer.0.bias"] = _linear_init(rng, ed * A // 2, ed * A)
+    bp["output_layer.2.weight"], bp["output_layer.2.bias"] = _linear_init(rng, D, ed * A // 2)
+    return bp
 
 
 # ---------------------------------------------------------------------------------------------
