@@ -111,6 +111,8 @@ struct BinHiddenArgs {
     int A, nb, H, SW;
 };
 
+#define BINH_ROWS 4          // rows per wave step (independent gather chains in flight)
+
 __global__ __launch_bounds__(1024) void bin_hidden_kernel(const BinHiddenArgs a) {
     extern __shared__ float pl[];                                // [A * nb][SW]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -123,15 +125,30 @@ __global__ __launch_bounds__(1024) void bin_hidden_kernel(const BinHiddenArgs a)
     }
     __syncthreads();
     const int64_t nw = (int64_t)gridDim.x * 16;
-    for (int64_t n = (int64_t)blockIdx.x * 16 + wave; n < a.N; n += nw) {
+    for (int64_t n0 = ((int64_t)blockIdx.x * 16 + wave) * BINH_ROWS; n0 < a.N; n0 += nw * BINH_ROWS) {
+        // lane i < A holds the LDS row offset (i * nb + bin) * SW of dimension i for each of the step's rows
+        int off[BINH_ROWS];
+#pragma unroll
+        for (int r = 0; r < BINH_ROWS; ++r) {
+            off[r] = 0;
+            if (lane < a.A && n0 + r < a.N) off[r] = (lane * a.nb + (int)a.bins[(size_t)lane * a.N + n0 + r]) * a.SW;
+        }
         for (int c = lane; c < sw; c += 64) {
-            float acc = a.b1[s0 + c];
+            const float b1 = a.b1[s0 + c];
+            float acc[BINH_ROWS];
+#pragma unroll
+            for (int r = 0; r < BINH_ROWS; ++r) acc[r] = b1;
             for (int i = 0; i < a.A; ++i) {
-                const int b = (int)a.bins[(size_t)i * a.N + n];            // wave-uniform: scalar load
-                acc = acc + pl[(i * a.nb + b) * a.SW + c];
+#pragma unroll
+                for (int r = 0; r < BINH_ROWS; ++r) acc[r] = acc[r] + pl[__builtin_amdgcn_readlane(off[r], i) + c];
             }
-            if (a.pre1) a.pre1[(size_t)n * a.H + s0 + c] = acc;
-            a.h[(size_t)n * a.H + s0 + c] = lq_gelu(acc);
+#pragma unroll
+            for (int r = 0; r < BINH_ROWS; ++r) {
+                if (n0 + r < a.N) {
+                    if (a.pre1) a.pre1[(size_t)(n0 + r) * a.H + s0 + c] = acc[r];
+                    a.h[(size_t)(n0 + r) * a.H + s0 + c] = lq_gelu(acc[r]);
+                }
+            }
         }
     }
 }
@@ -190,9 +207,10 @@ int lipvq_bin_hidden_f32(const int64_t* bins, const float* P, const float* b1, f
     if (!bins || !P || !b1 || !h) return fail(LIPVQ_EINVAL, "lipvq_bin_hidden_f32: null pointer");
     if (N < 0 || A <= 0 || num_bins < 1 || H <= 0) return fail(LIPVQ_EINVAL, "lipvq_bin_hidden_f32: bad sizes");
     if (N == 0) return LIPVQ_OK;
-    // widest column slice (a multiple of 64) whose part of P fits in 128 KiB of LDS
+    // widest column slice (a multiple of 64) whose part of P lets two workgroups share a CU's LDS
     const int64_t rowsP = (int64_t)A * num_bins;
-    int64_t SW = (128 * 1024 / 4) / rowsP / 64 * 64;
+    int64_t SW = (80 * 1024 / 4) / rowsP / 64 * 64;       // <= 80 KiB: two 16-wave workgroups per CU
+    if (SW < 64) SW = (150 * 1024 / 4) / rowsP / 64 * 64;   // large A * num_bins: one workgroup per CU
     if (SW < 64) return fail(LIPVQ_EUNSUPPORTED, "lipvq_bin_hidden_f32: A * num_bins = %lld is too large for the LDS table slice",
                              (long long)rowsP);
     const int Hpad = (H + 63) / 64 * 64;
@@ -205,9 +223,9 @@ int lipvq_bin_hidden_f32(const int64_t* bins, const float* P, const float* b1, f
             return fail(LIPVQ_EHIP, "lipvq_bin_hidden_f32: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
-    int gx = 256 / slices;                               // one 16-wave workgroup per CU (the LDS slice is ~120 KiB)
+    int gx = 512 / slices;                               // two 16-wave workgroups per CU
     if (gx < 1) gx = 1;
-    const int64_t need = (N + 15) / 16;
+    const int64_t need = (N + 16 * BINH_ROWS - 1) / (16 * BINH_ROWS);
     if (gx > need) gx = (int)need;
     BinHiddenArgs a{bins, P, b1, h, pre1, N, A, num_bins, H, (int)SW};
     hipLaunchKernelGGL(bin_hidden_kernel, dim3(gx, slices), dim3(1024), lds, (hipStream_t)stream, a);

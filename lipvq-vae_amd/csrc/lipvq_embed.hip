@@ -83,6 +83,93 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
     }
 }
 
+// Large-N variant of linear_kernel: 128 x 128 (or 256 x 64) tile per workgroup, each of the 4 waves owns 64 x 64 (2 x 2 MFMA tiles, so
+// every LDS operand feeds two MFMAs), K staged 32 at a time with the next chunk's global loads in flight (registers)
+// while the current chunk is multiplied.  Same k-ordered chains as linear_kernel: bit-identical results.
+#define LINB_KC 32
+
+// WR x WC waves, each owning a 64 x 64 block: (2, 2) = 128 x 128 tile; (4, 1) = 256 x 64 tile for narrow outputs (E <= 64)
+template <int WR, int WC>
+__global__ __launch_bounds__(256) void linear_big_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, float* __restrict__ y,
+                                                         float* __restrict__ pre, int act, int64_t N, int Kin, int E) {
+    constexpr int TR = 64 * WR, TC = 64 * WC;
+    __shared__ float xs[TR][LINB_KC + 1];
+    __shared__ float ws[TC][LINB_KC + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int wr = wave / WC, wc = wave % WC;
+    const int64_t row0 = (int64_t)blockIdx.x * TR;
+    const int e0 = blockIdx.y * TC;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ecol = e0 + (2 * wc + j) * 32 + li;
+        const float b0 = (ecol < E && bias) ? bias[ecol] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = b0;
+    }
+    // staging: thread -> (row r = tid >> 3 (+32 i), 4 consecutive k at 4 (tid & 7)): 128 B per row and instruction
+    float4 xr[2 * WR], wrg[2 * WC];
+    const int sr = tid >> 3, sk = 4 * (tid & 7);
+    auto fetch = [&](int k0) {
+        const bool kin = k0 + sk < Kin;                          // Kin is a multiple of 4 on this path
+#pragma unroll
+        for (int i = 0; i < 2 * WR; ++i) {
+            const int64_t row = row0 + sr + 32 * i;
+            xr[i] = (row < N && kin) ? *reinterpret_cast<const float4*>(x + (size_t)row * Kin + k0 + sk) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * WC; ++i) {
+            const int e = e0 + sr + 32 * i;
+            wrg[i] = (e < E && kin) ? *reinterpret_cast<const float4*>(W + (size_t)e * Kin + k0 + sk) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < Kin; k0 += LINB_KC) {
+#pragma unroll
+        for (int i = 0; i < 2 * WR; ++i) {
+            float* xd = &xs[sr + 32 * i][sk];
+            xd[0] = xr[i].x; xd[1] = xr[i].y; xd[2] = xr[i].z; xd[3] = xr[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * WC; ++i) {
+            float* wd = &ws[sr + 32 * i][sk];
+            wd[0] = wrg[i].x; wd[1] = wrg[i].y; wd[2] = wrg[i].z; wd[3] = wrg[i].w;
+        }
+        __syncthreads();
+        if (k0 + LINB_KC < Kin) fetch(k0 + LINB_KC);            // in flight during the MFMAs below
+        const int kend = (Kin - k0 < LINB_KC) ? ((Kin - k0 + 1) >> 1) : (LINB_KC / 2);
+        for (int s2 = 0; s2 < kend; ++s2) {
+            const int k = 2 * s2 + kh;
+            const float a0 = xs[(2 * wr) * 32 + li][k], a1 = xs[(2 * wr + 1) * 32 + li][k];
+            const float b0 = ws[(2 * wc) * 32 + li][k], b1 = ws[(2 * wc + 1) * 32 + li][k];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ecol = e0 + (2 * wc + j) * 32 + li;
+            if (ecol >= E) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = row0 + (2 * wr + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (row < N) {
+                    if (pre) pre[(size_t)row * E + ecol] = acc[i][j][r];
+                    y[(size_t)row * E + ecol] = lq_act_apply(acc[i][j][r], act);
+                }
+            }
+        }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // out[slot(n)][:] = LayerNorm(src[idx ? idx[n] : n][:] + pos[n % T][:])
 // 16 lanes own one row (4 rows per wavefront step): the per-row work that every lane repeats (the two reductions --
@@ -378,6 +465,20 @@ int lipvq_linear_act_f32(const float* x, const float* W, const float* b, float* 
     if (N == 0) return LIPVQ_OK;
     const int64_t gx = (N + LIN_ROWS - 1) / LIN_ROWS;
     if (gx > 0x7fffffffLL) return fail(LIPVQ_EUNSUPPORTED, "lipvq_linear_act_f32: N too large");
+#ifndef LQ_LIN_BIG_MIN
+#define LQ_LIN_BIG_MIN 512          // workgroups of the 128 x 128 tiling needed before it pays (2 per CU)
+#endif
+    const bool narrow = E <= 64;                                  // 256 x 64 tiles instead of 128 x 128
+    const int TR = narrow ? 256 : 128, TC = narrow ? 64 : 128;
+    const int64_t big_wgs = ((N + TR - 1) / TR) * ((E + TC - 1) / TC);
+    if (big_wgs >= LQ_LIN_BIG_MIN && (Kin & 3) == 0) {
+        dim3 grid((unsigned)((N + TR - 1) / TR), (unsigned)((E + TC - 1) / TC));
+        if (narrow)
+            hipLaunchKernelGGL((linear_big_kernel<4, 1>), grid, dim3(256), 0, (hipStream_t)stream, x, W, b, y, pre, act, N, Kin, E);
+        else
+            hipLaunchKernelGGL((linear_big_kernel<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, x, W, b, y, pre, act, N, Kin, E);
+        return check_launch("linear_big_kernel");
+    }
     dim3 grid((unsigned)gx, (unsigned)((E + 127) / 128));
     hipLaunchKernelGGL(linear_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, W, b, y, pre, act, N, Kin, E);
     return check_launch("linear_kernel");

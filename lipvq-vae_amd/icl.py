@@ -1,8 +1,8 @@
 """Host glue around the tokenizer, restating the few lines of the reference that drive it.
 
 * ``ICLActionBranch``      -- the action branch of ``ICLObservationGroupEncoder`` when ``vq_vae_enabled``
-                             (robomimic/models/obs_nets.py:1219-1227 construction, :1335-1337 call):
-                             owns ``action_network``, stashes ``_vq_vae_loss``.
+                             (robomimic/models/obs_nets.py:1219-1227 construction, :1335-1337 call) or
+                             ``bin_enabled`` (:1214-1217, :1343-1344): owns ``action_network``, stashes ``_vq_vae_loss``.
 * ``time_distributed``     -- the [B, T, ...] <-> [B*T, ...] reshape of
                              ``TensorUtils.icl_time_distributed`` (robomimic/utils/tensor_utils.py:1045-1090)
                              for the action leaf.
@@ -18,25 +18,31 @@ import torch
 import torch.nn as nn
 
 from . import sharded
+from .binning import AdaptiveBinActionEmbedding
 from .tokenizer import LLFQVAE_V4, VQVAE
 
 
 class ICLActionBranch(nn.Module):
     def __init__(self, action_input_shape: int = 12, action_output_shape: int = 208, vq_vae_enabled: bool = True,
-                 variant: str = "lipvq"):
+                 variant: str = "lipvq", bin_enabled: bool = False):
         super().__init__()
-        if not vq_vae_enabled:
-            raise NotImplementedError("only the vq_vae_enabled branch of the group encoder is on this path")
-        self.vq_vae_enabled = True
-        if variant == "lipvq":       # obs_nets.py:1225: the paper's tokenizer
+        self.bin_enabled = bool(bin_enabled)
+        self.vq_vae_enabled = bool(vq_vae_enabled) and not self.bin_enabled      # the reference's elif order
+        if self.bin_enabled:             # obs_nets.py:1214-1217: the binning tokenizer of the paper's ablation
+            self.action_network = AdaptiveBinActionEmbedding(action_dim=action_input_shape, output_dim=action_output_shape)
+        elif not vq_vae_enabled:
+            raise NotImplementedError("only the vq_vae_enabled and bin_enabled branches of the group encoder are on this path")
+        elif variant == "lipvq":         # obs_nets.py:1225: the paper's tokenizer
             self.action_network = LLFQVAE_V4(feature_dim=action_input_shape, latent_dim=action_output_shape)
-        elif variant == "vqvae":     # obs_nets.py:1220-1222 (commented-out alternative)
+        elif variant == "vqvae":         # obs_nets.py:1220-1222 (commented-out alternative)
             self.action_network = VQVAE(feature_dim=action_input_shape, latent_dim=action_output_shape)
         else:
             raise ValueError(variant)
         self._vq_vae_loss = None
 
     def forward(self, prompt_actions: torch.Tensor) -> torch.Tensor:
+        if self.bin_enabled:
+            return self.action_network(prompt_actions)                    # obs_nets.py:1343-1344 (no tokenizer loss)
         context_actions, loss = self.action_network(prompt_actions)      # obs_nets.py:1336
         self._vq_vae_loss = loss                                          # obs_nets.py:1337
         return context_actions

@@ -85,5 +85,11 @@ def main():
                       "TFLOPs": 2.0 * Nd * a.D * a.E / t_lin / 1e12}))
 
 
+    for (n, k, e) in ((524288, 224, 64), (131072, 384, 208), (65536, 512, 512)):
+        xx, ww, bb2 = torch.randn((n, k), device=dev), torch.randn((e, k), device=dev), torch.randn(e, device=dev)
+        t = timed(lambda: ops.linear(xx, ww, bb2, act=ops.ACT_GELU), max(5, a.iters // 5))
+        print(json.dumps({"kernel": "linear+gelu", "rows": n, "Kin": k, "E": e, "us": t * 1e6, "TFLOPs": 2.0 * n * k * e / t / 1e12}))
+
+
 if __name__ == "__main__":
     main()

@@ -19,7 +19,10 @@ def _cuda(a):
 
 
 @pytest.mark.parametrize("N,Kin,E", [(1024, 64, 512), (77, 33, 96), (1, 7, 32), (300, 208, 384), (4096, 512, 512),
-                                     (65, 64, 40), (33, 5, 8)])
+                                     (65, 64, 40), (33, 5, 8),
+                                     # the 128 x 128-tile kernel (>= 512 workgroups, Kin % 4 == 0): ragged N / E / K chunk
+                                     (70000, 64, 512), (33000, 224, 208), (66000, 36, 130), (65536, 33, 512), (140000, 224, 64),
+                                     (131100, 8, 33)])
 def test_linear_bit_exact(oracle, N, Kin, E):
     from lipvq_vae_amd import ops
     rng = np.random.default_rng(N + Kin)

@@ -61,3 +61,36 @@ def test_engine_free_forward_backward_equals_autograd(oracle):
         for prm, g in zip(params, grads):
             scale = float(prm.grad.abs().max()) + 1e-12
             assert float((prm.grad - g).abs().max()) <= 1e-5 * scale      # codebook scatter-add uses float atomics
+
+
+def test_bin_branch_feeds_the_embedding_stage(oracle, golden_dir):
+    """bin_enabled branch (obs_nets.py:1214-1217) -> [B, T, D] context actions -> dense route of the input embedding:
+    trains end to end (policy-side gradients reach the bin tokenizer's parameters) and matches the oracle chain."""
+    from lipvq_vae_amd.embedding import ICLInputEmbedding
+    from lipvq_vae_amd.icl import ICLActionBranch, time_distributed
+    from test_oracle_bin import load_bin
+    g, meta, bp = load_bin(golden_dir, "bin_icrt")
+    A, D, B, T, E = meta["A"], meta["D"], 8, 10, 512
+    branch = ICLActionBranch(A, D, bin_enabled=True).cuda()
+    assert branch.bin_enabled and not branch.vq_vae_enabled
+    sd = {k: torch.from_numpy(v.copy()) for k, v in bp.items()}
+    sd["running_min"], sd["running_max"] = branch.action_network.running_min.cpu(), branch.action_network.running_max.cpu()
+    branch.action_network.load_state_dict(sd)
+    ep = O.make_embed_params(5, D, E, T, "parameter")
+    emb = ICLInputEmbedding(D, E, T, emb_dropout=0.0).cuda()
+    emb.load_state_dict({("params." if k == "embed_timestep" else "nets.") + k: torch.from_numpy(v.copy()) for k, v in ep.items()})
+    x = g["x0"].reshape(B, T, A)
+    rng = np.random.default_rng(0)
+    obs, cobs = rng.standard_normal((B, T, D)).astype(np.float32), rng.standard_normal((B, T, D)).astype(np.float32)
+    ctx = time_distributed(torch.from_numpy(x).cuda(), branch)
+    assert ctx.shape == (B, T, D) and ctx.requires_grad and branch._vq_vae_loss is None
+    out = emb(torch.from_numpy(obs).cuda(), torch.from_numpy(cobs).cuda(), ctx)
+    out.square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in branch.action_network.parameters())
+    # oracle chain: bin tokenizer -> dense Linear -> LayerNorm into the 2t+1 slots
+    r = oracle.bin_forward(bp, g["x0"], np.full(A, np.inf, np.float32), np.full(A, -np.inf, np.float32))
+    want = np.zeros((B, 3 * T, E), np.float32)
+    W, b = ep["embed_encoder.weight"], ep["embed_encoder.bias"]
+    oracle.embed_rows(oracle.linear(r["out"], W, b), None, ep["embed_timestep"][0], ep["embed_ln.weight"], ep["embed_ln.bias"],
+                      1e-5, want, T, 3 * T * E, 2 * E, E)
+    assert np.array_equal(out.detach().cpu().numpy()[:, 1:2 * T:2], want[:, 1:2 * T:2])
