@@ -229,6 +229,16 @@ int lipvq_bin_hidden_f32(const int64_t* bins, const float* P, const float* b1, f
 /* out = g * act'(pre), elementwise over n floats (backward of the GELUs of bin:28,30). */
 int lipvq_act_bwd_f32(const float* g, const float* pre, float* out, int64_t n, int act, void* stream);
 
+/* ---- opt-in extension: EMA codebook update (not in the reference; named by BASELINE.json's north star) ----
+ * cluster_size [K] and embed_sum [K][D] are the running statistics (updated in place), counts [K] int64 = this batch's
+ * code usage (lipvq_nearest_f32 / lipvq_tokenize_f32 `usage`, summed over ranks), dw [K][D] = sum of the z_e rows mapped
+ * to each code (lipvq_scatter_add_f32, summed over ranks).  Writes the new codebook:
+ *     cluster_size = decay cluster_size + (1-decay) counts;  embed_sum = decay embed_sum + (1-decay) dw;
+ *     n = sum cluster_size;  codebook[k] = embed_sum[k] / ((cluster_size[k] + eps) / (n + K eps) * n).
+ * workspace: 8 bytes. */
+int lipvq_ema_update_f32(float* cluster_size, float* embed_sum, const int64_t* counts, const float* dw, float* codebook,
+                         float decay, float eps, int K, int D, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,7 @@ SIGNATURES = {
     "lipvq_bin_boundaries_f32": (_i, [_vp] * 3 + [_i, _i, _vp]),
     "lipvq_bin_hidden_f32": (_i, [_vp] * 5 + [_i64, _i, _i, _i, _vp]),
     "lipvq_act_bwd_f32": (_i, [_vp] * 3 + [_i64, _i, _vp]),
+    "lipvq_ema_update_f32": (_i, [_vp] * 5 + [C.c_float, C.c_float, _i, _i, _vp, _vp]),
 }
 
 

@@ -167,3 +167,65 @@ extern "C" int lipvq_scaled_diff_f32(const float* a, const float* b, const float
     hipLaunchKernelGGL(scaled_diff_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, c, alpha, gscale, out, n);
     return check_launch("scaled_diff");
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Opt-in EMA codebook update (NOT in the reference, which trains the codebook by gradient, v5:32-35,81; named by the
+// north star and SURVEY 8e as an extension).  The standard VQ-VAE rule (van den Oord et al. 2017, appendix A.1 /
+// sonnet's VectorQuantizerEMA):
+//     cluster_size = decay * cluster_size + (1 - decay) * counts
+//     embed_sum    = decay * embed_sum    + (1 - decay) * dw,       dw[k] = sum of z_e rows mapped to k
+//     n = sum(cluster_size);  smoothed = (cluster_size + eps) / (n + K eps) * n;   codebook = embed_sum / smoothed
+// ema_cluster_kernel: one workgroup; tree-sums n in double (deterministic) into workspace[0].
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void ema_cluster_kernel(float* __restrict__ cs, const int64_t* __restrict__ counts,
+                                                           float decay, int K, double* __restrict__ n_out) {
+    __shared__ double part[1024];
+    const float omd = 1.0f - decay;
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < K; k += 1024) {
+        const float v = lq_fma(decay, cs[k], omd * (float)counts[k]);
+        cs[k] = v;
+        acc += (double)v;
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_out = part[0];
+}
+
+__global__ __launch_bounds__(256) void ema_codebook_kernel(const float* __restrict__ cs, float* __restrict__ es,
+                                                           const float* __restrict__ dw, float* __restrict__ codebook,
+                                                           float decay, float eps, int K, int D,
+                                                           const double* __restrict__ n_in) {
+    const float omd = 1.0f - decay;
+    const float n = (float)*n_in;
+    const float denom = n + (float)K * eps;
+    const int64_t total = (int64_t)K * D;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int k = (int)(e / D);
+        const float sm = (cs[k] + eps) / denom * n;
+        const float v = lq_fma(decay, es[e], omd * dw[e]);
+        es[e] = v;
+        codebook[e] = v / sm;
+    }
+}
+
+extern "C" int lipvq_ema_update_f32(float* cluster_size, float* embed_sum, const int64_t* counts, const float* dw,
+                                    float* codebook, float decay, float eps, int K, int D, void* workspace, void* stream) {
+    if (!cluster_size || !embed_sum || !counts || !dw || !codebook || !workspace)
+        return fail(LIPVQ_EINVAL, "lipvq_ema_update_f32: null pointer");
+    if (K <= 0 || D <= 0 || !(decay >= 0.0f && decay <= 1.0f) || !(eps > 0.0f))
+        return fail(LIPVQ_EINVAL, "lipvq_ema_update_f32: bad arguments (K=%d D=%d decay=%g eps=%g)", K, D, decay, eps);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ema_cluster_kernel, dim3(1), dim3(1024), 0, st, cluster_size, counts, decay, K, (double*)workspace);
+    int rc = check_launch("ema_cluster_kernel");
+    if (rc) return rc;
+    int64_t g = ((int64_t)K * D + 1023) / 1024;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(ema_codebook_kernel, dim3((unsigned)g), dim3(256), 0, st, cluster_size, embed_sum, dw, codebook, decay,
+                       eps, K, D, (const double*)workspace);
+    return check_launch("ema_codebook_kernel");
+}

@@ -456,3 +456,17 @@ def act_bwd(g, pre, act):
     with torch.cuda.device(g.device):
         check(lib.lipvq_act_bwd_f32(_ptr(g), _ptr(pre), _ptr(out), g.numel(), int(act), _stream()), "lipvq_act_bwd_f32")
     return out
+
+
+def ema_update(cluster_size, embed_sum, counts, dw, codebook, decay, eps):
+    """In-place EMA codebook update (opt-in extension; include/lipvq.h lipvq_ema_update_f32)."""
+    K, D = codebook.shape
+    for name, t, shape, dt in (("cluster_size", cluster_size, (K,), torch.float32), ("embed_sum", embed_sum, (K, D), torch.float32),
+                               ("counts", counts, (K,), torch.int64), ("dw", dw, (K, D), torch.float32),
+                               ("codebook", codebook, (K, D), torch.float32)):
+        if not (t.is_cuda and t.dtype == dt and t.is_contiguous() and tuple(t.shape) == shape):
+            raise ValueError(f"ema_update: {name} must be a contiguous CUDA {dt} tensor of shape {shape}")
+    ws = torch.empty(1, device=codebook.device, dtype=torch.float64)
+    with torch.cuda.device(codebook.device):
+        check(lib.lipvq_ema_update_f32(_ptr(cluster_size), _ptr(embed_sum), _ptr(counts), _ptr(dw), _ptr(codebook),
+                                       float(decay), float(eps), K, D, _ptr(ws), _stream()), "lipvq_ema_update_f32")

@@ -11,6 +11,8 @@ cross ranks (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests):
                               n_local / n_global and summed in ONE flat fp32 buffer (14 tensors,
                               ~375 KiB at config 2) before AdamW.step(); replicas stay identical.
 
+  * ``all_reduce_ema_stats``  opt-in EMA extension: int64 counts [K] + fp32 per-code sums [K, D].
+
 Nothing here computes on the data: it only shards, flattens and calls torch.distributed.
 """
 from __future__ import annotations
@@ -46,6 +48,16 @@ def all_reduce_usage(usage: torch.Tensor, group=None) -> torch.Tensor:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(usage, op=dist.ReduceOp.SUM, group=group)
     return usage
+
+
+def all_reduce_ema_stats(counts: torch.Tensor, dw: torch.Tensor, group=None) -> None:
+    """Sum the per-batch EMA statistics over the ranks, in place: counts [K] int64 and dw [K, D] fp32 (opt-in EMA
+    extension, lipvq_vae_amd.ema; 8 KiB + 256 KiB at K = 1024, D = 64)."""
+    if counts.dtype != torch.int64 or dw.dtype != torch.float32:
+        raise TypeError("EMA statistics must be int64 counts and fp32 sums")
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(dw, op=dist.ReduceOp.SUM, group=group)
 
 
 def all_reduce_gradients(params: Iterable[torch.nn.Parameter], n_local: int, n_global: int, group=None) -> None:

@@ -406,6 +406,26 @@ LQ_EXPORT void lq_ref_bin_hidden(const int64_t* bins, const float* P, const floa
         }
 }
 
+/* Opt-in EMA codebook update (extension, not in the reference): see include/lipvq.h lipvq_ema_update_f32. */
+LQ_EXPORT void lq_ref_ema_update(float* cs, float* es, const int64_t* counts, const float* dw, float* codebook,
+                                 float decay, float eps, int K, int D) {
+    const float omd = 1.0f - decay;
+    double nd = 0.0;
+    for (int k = 0; k < K; ++k) {
+        cs[k] = lq_fma(decay, cs[k], omd * (float)counts[k]);
+        nd += (double)cs[k];
+    }
+    const float n = (float)nd, denom = n + (float)K * eps;
+    for (int k = 0; k < K; ++k) {
+        const float sm = (cs[k] + eps) / denom * n;
+        for (int d = 0; d < D; ++d) {
+            const size_t e = (size_t)k * D + d;
+            es[e] = lq_fma(decay, es[e], omd * dw[e]);
+            codebook[e] = es[e] / sm;
+        }
+    }
+}
+
 /* Probes for tests/test_oracle_math.py */
 LQ_EXPORT void lq_ref_math_probe(const float* x, float* out, int64_t n, int fn) {
     for (int64_t i = 0; i < n; ++i) {

@@ -332,6 +332,16 @@ class CanonicalOracle:
         out = self.linear_act(h, bp["output_layer.2.weight"], bp["output_layer.2.bias"], ACT_GELU)
         return {"out": out, "bins": bins, "running_min": rmin, "running_max": rmax, "hidden": h}
 
+    def ema_update(self, cluster_size, embed_sum, counts, dw, decay=0.99, eps=1e-5):
+        """Opt-in EMA codebook update (extension): returns (cluster_size, embed_sum, codebook)."""
+        cs, es = _f32(cluster_size).copy(), _f32(embed_sum).copy()
+        counts, dw = np.ascontiguousarray(counts, np.int64), _f32(dw)
+        K, D = es.shape
+        cb = np.empty_like(es)
+        self.lib.lq_ref_ema_update(_p(cs), _p(es), _p(counts, C.c_int64), _p(dw), _p(cb), C.c_float(decay), C.c_float(eps),
+                                   C.c_int(K), C.c_int(D))
+        return cs, es, cb
+
     def vq_grads(self, p, x, commitment_cost=0.25, fwd=None):
         f = fwd or self.vq_forward(p, x, commitment_cost)
         x = _f32(x)

@@ -58,8 +58,17 @@ def _worker(rank, port, out_dir):
         for prm, k in zip(params, O.LLFQ_KEYS):
             prm.grad = torch.from_numpy(g_local[k].copy())
         sharded.all_reduce_gradients(params, n_local=xl.shape[0], n_global=B * T)
-        np.savez(Path(out_dir) / f"rank{rank}.npz", idx=idx.numpy(), usage=tok.code_usage.numpy(),
-                 **{"g/" + k: prm.grad.numpy() for prm, k in zip(params, O.LLFQ_KEYS)})
+        # opt-in EMA extension: per-shard statistics summed over the ranks, then the (oracle's) update rule
+        ze_l = orc.llfq_encode(p, xl)
+        idx_l = idx.reshape(-1).numpy()
+        counts = torch.from_numpy(np.bincount(idx_l, minlength=K).astype(np.int64))
+        dw = np.zeros((K, D), np.float32)
+        np.add.at(dw, idx_l, ze_l)
+        dw = torch.from_numpy(dw)
+        sharded.all_reduce_ema_stats(counts, dw)
+        ema_cs, ema_es, ema_cb = orc.ema_update(np.zeros(K, np.float32), p["quantizer.codebook"], counts.numpy(), dw.numpy())
+        np.savez(Path(out_dir) / f"rank{rank}.npz", idx=idx.numpy(), usage=tok.code_usage.numpy(), ema_cb=ema_cb,
+                 ema_counts=counts.numpy(), **{"g/" + k: prm.grad.numpy() for prm, k in zip(params, O.LLFQ_KEYS)})
     finally:
         dist.destroy_process_group()
 
@@ -79,6 +88,12 @@ def test_two_rank_sharding_usage_and_gradients(tmp_path, oracle):
     assert int(r0["usage"].sum()) == B * T
     # weighted flat all-reduce == gradient of the loss over the whole batch, identical on both ranks
     # (holds for every term that is a mean over rows; the codebook term too, since scatter-add is linear)
+    # EMA statistics: global counts on both ranks; the updated codebook equals the single-process update
+    assert np.array_equal(r0["ema_counts"], full["usage"]) and np.array_equal(r0["ema_cb"], r1["ema_cb"])
+    dw_full = np.zeros((K, D), np.float32)
+    np.add.at(dw_full, full["indices"], full["z_e"])
+    _, _, cb_full = oracle.ema_update(np.zeros(K, np.float32), p["quantizer.codebook"], full["usage"], dw_full)
+    assert np.abs(r0["ema_cb"] - cb_full).max() <= 1e-6 * (1 + np.abs(cb_full).max())
     g_full = oracle.llfq_grads(p, x, fwd=full)
     for k in O.LLFQ_KEYS:
         assert np.array_equal(r0["g/" + k], r1["g/" + k]), k
