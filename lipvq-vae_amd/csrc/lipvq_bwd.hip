@@ -1,7 +1,7 @@
 // lipvq_bwd.hip -- the parameter-gradient side of the tokenizer's backward pass (what autograd
 // derives from reference backbone_lfqvae_v5.py:70-84 / backbone.py:38-76):
 //   wgrad_kernel          gW = G^T . H and gb = sum_rows G  (contraction over the batch rows, fp32 MFMA,
-//                         split over row chunks into partial slabs)
+//                         split over row chunks of 64...2048 rows into partial slabs)
 //   wgrad_reduce_kernel   deterministic sum of the slabs (double)
 //   scatter_add_kernel    codebook gradient: index_add_ of the gather's backward
 //   lipschitz_bwd_kernel  backward of normalization() (v5:6-12)
@@ -9,39 +9,61 @@
 // ABI: include/lipvq.h.
 #include "lipvq_common.h"
 
-#define WGRAD_ROWS_PER_CHUNK 2048
+// rows per chunk: enough chunks that the (chunk x tile) grid fills the chip even for training-step batches -- with one
+// 2048-row chunk a 1024-row batch was ONE dependent chain of 512 load+MFMA steps per wave (248 us per call).
+static inline int wgrad_chunk_rows(int64_t N) { return N >= 262144 ? 2048 : (N >= 16384 ? 512 : 64); }
 
 // One wave = one 32x32 tile of gW over one chunk of rows.
 //   A operand: lane (i = lane & 31, kh = lane >> 5) = G[row0 + 2s + kh][32 ti + i]
 //   B operand: lane (j = lane & 31, kh)             = act(H[row0 + 2s + kh][32 tj + j])
 //   D[i][j]  : col j = lane & 31, row i = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+// Operands are fetched 8 steps (16 rows) ahead of the MFMAs that consume them.
 __global__ __launch_bounds__(64) void wgrad_kernel(const float* __restrict__ G, const float* __restrict__ H,
                                                    const int64_t* __restrict__ hidx, int h_act,
                                                    float* __restrict__ partW, float* __restrict__ partB,
-                                                   int64_t N, int J, int Kd, int TJ) {
+                                                   int64_t N, int J, int Kd, int TJ, int chunk_rows) {
     const int lane = threadIdx.x;
     const int li = lane & 31, kh = lane >> 5;
     const int ti = blockIdx.y / TJ, tj = blockIdx.y % TJ;
     const int fi = 32 * ti + li, fj = 32 * tj + li;
-    const int64_t r0 = (int64_t)blockIdx.x * WGRAD_ROWS_PER_CHUNK;
-    int64_t r1 = r0 + WGRAD_ROWS_PER_CHUNK;
+    const int64_t r0 = (int64_t)blockIdx.x * chunk_rows;
+    int64_t r1 = r0 + chunk_rows;
     if (r1 > N) r1 = N;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     float bsum = 0.0f;
     const bool ai = fi < J, bj = fj < Kd;
-#pragma unroll 4
-    for (int64_t row = r0 + kh; row < r1 + kh; row += 2) {
-        const bool in = row < r1;
-        float av = 0.0f, bv = 0.0f;
-        if (in && ai) av = G[(size_t)row * J + fi];
-        if (in && bj) {
-            const int64_t hr = hidx ? hidx[row] : row;
-            bv = lq_act_apply(H[(size_t)hr * Kd + fj], h_act);
+    auto fetch = [&](int64_t row, float& av, float& bv) {
+        av = 0.0f;
+        bv = 0.0f;
+        if (row < r1) {
+            if (ai) av = G[(size_t)row * J + fi];
+            if (bj) {
+                const int64_t hr = hidx ? hidx[row] : row;
+                bv = H[(size_t)hr * Kd + fj];
+            }
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-        bsum += av;
+    };
+    float ca[8], cb[8], na[8], nb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fetch(r0 + 2 * j + kh, ca[j], cb[j]);
+    for (int64_t base = r0; base < r1; base += 16) {
+        if (base + 16 < r1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fetch(base + 16 + 2 * j + kh, na[j], nb[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (base + 2 * j < r1) {                     // wave-uniform: skip whole steps past the chunk
+                const bool in = base + 2 * j + kh < r1;
+                const float bv = (in && bj) ? lq_act_apply(cb[j], h_act) : 0.0f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[j], bv, acc, 0, 0, 0);
+                bsum += ca[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ca[j] = na[j]; cb[j] = nb[j]; }
     }
     float* pw = partW + (size_t)blockIdx.x * J * Kd;
 #pragma unroll
@@ -64,7 +86,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
     out[e] = (float)s;
 }
 
-static inline int wgrad_chunks(int64_t N) { return (int)((N + WGRAD_ROWS_PER_CHUNK - 1) / WGRAD_ROWS_PER_CHUNK); }
+static inline int wgrad_chunks(int64_t N) { const int c = wgrad_chunk_rows(N); return (int)((N + c - 1) / c); }
 
 extern "C" size_t lipvq_wgrad_workspace_bytes(int64_t N, int J, int Kd) {
     if (N <= 0 || J <= 0 || Kd <= 0) return 0;
@@ -82,7 +104,8 @@ extern "C" int lipvq_wgrad_f32(const float* G, const float* H, const int64_t* hi
     const int TI = (J + 31) / 32, TJ = (Kd + 31) / 32;
     float* partW = (float*)workspace;
     float* partB = partW + (size_t)nch * J * Kd;
-    hipLaunchKernelGGL(wgrad_kernel, dim3(nch, TI * TJ), dim3(64), 0, st, G, H, hidx, h_act, partW, partB, N, J, Kd, TJ);
+    hipLaunchKernelGGL(wgrad_kernel, dim3(nch, TI * TJ), dim3(64), 0, st, G, H, hidx, h_act, partW, partB, N, J, Kd, TJ,
+                       wgrad_chunk_rows(N));
     size_t ne = (size_t)J * Kd;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, partW, gW, nch, ne);
     if (gb)

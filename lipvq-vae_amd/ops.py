@@ -32,8 +32,34 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """Current HIP stream of the current device as an integer handle (the fast private accessor when torch has it)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+class _on:
+    """`with _on(device):` -- torch.cuda.device(device), skipped when that device is already current (the usual case:
+    one process per GPU), which saves a few microseconds on every small launch of a training step."""
+
+    __slots__ = ("ctx",)
+
+    def __init__(self, device):
+        idx = device.index
+        self.ctx = None if (idx is None or idx == torch.cuda.current_device()) else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*exc)
+        return False
 
 
 def lipschitz_scale(W: torch.Tensor, ci: torch.Tensor):
@@ -42,7 +68,7 @@ def lipschitz_scale(W: torch.Tensor, ci: torch.Tensor):
     D, H = W.shape
     scale = torch.empty(D, device=W.device, dtype=torch.float32)
     Wn = torch.empty_like(W)
-    with torch.cuda.device(W.device):
+    with _on(W.device):
         check(lib.lipvq_lipschitz_scale_f32(_ptr(W), _ptr(ci), _ptr(scale), _ptr(Wn), D, H, _stream()),
               "lipvq_lipschitz_scale_f32")
     return scale, Wn
@@ -66,7 +92,7 @@ def mlp3_pack(W0, b0, W1, b1, W2, b2) -> PackedMlp3:
         raise ValueError("mlp3_pack: inconsistent layer shapes")
     n = lib.lipvq_mlp3_packed_floats(K0, J0, J1, J2)
     buf = torch.empty(n, device=W0.device, dtype=torch.float32)
-    with torch.cuda.device(W0.device):
+    with _on(W0.device):
         check(lib.lipvq_mlp3_pack_f32(_ptr(W0), _ptr(b0), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(buf),
                                       K0, J0, J1, J2, _stream()), "lipvq_mlp3_pack_f32")
     return PackedMlp3(buf, K0, J0, J1, J2)
@@ -88,7 +114,7 @@ def mlp3(x: torch.Tensor, packed: PackedMlp3, acts, gather_idx: torch.Tensor | N
     y = torch.empty((N, packed.J2), device=dev, dtype=torch.float32)
     pre = [torch.empty((N, J), device=dev, dtype=torch.float32) if save_pre else None
            for J in (packed.J0, packed.J1, packed.J2)]
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib.lipvq_mlp3_f32(_ptr(x), _ptr(gather_idx), _ptr(packed.buf), _ptr(y), _ptr(pre[0]),
                                  _ptr(pre[1]), _ptr(pre[2]), N, packed.K0, packed.J0, packed.J1, packed.J2,
                                  int(acts[0]), int(acts[1]), int(acts[2]), _stream()), "lipvq_mlp3_f32")
@@ -110,7 +136,7 @@ def nearest(z: torch.Tensor, codebook: torch.Tensor, dist: int = DIST_NORM, usag
     idx = torch.empty(N, device=z.device, dtype=torch.int64)
     zq = torch.empty_like(z) if want_zq else None
     best = torch.empty(N, device=z.device, dtype=torch.float32) if want_best else None
-    with torch.cuda.device(z.device):
+    with _on(z.device):
         check(lib.lipvq_nearest_f32(_ptr(z), _ptr(codebook), _ptr(idx), _ptr(zq), _ptr(usage), _ptr(best),
                                     N, K, D, int(dist), _stream()), "lipvq_nearest_f32")
     return idx, zq, best
@@ -119,7 +145,7 @@ def nearest(z: torch.Tensor, codebook: torch.Tensor, dist: int = DIST_NORM, usag
 def ste(ze: torch.Tensor, zq: torch.Tensor) -> torch.Tensor:
     ze, zq = _chk(ze, "ze"), _chk(zq, "zq")
     out = torch.empty_like(ze)
-    with torch.cuda.device(ze.device):
+    with _on(ze.device):
         check(lib.lipvq_ste_f32(_ptr(ze), _ptr(zq), _ptr(out), ze.numel(), _stream()), "lipvq_ste_f32")
     return out
 
@@ -131,7 +157,7 @@ def mse_pair(xr, x, zq, ze) -> torch.Tensor:
         return torch.full((2,), float("nan"), device=x.device, dtype=torch.float32)
     out = torch.empty(2, device=x.device, dtype=torch.float32)
     ws = torch.empty(lib.lipvq_mse_workspace_bytes(), device=x.device, dtype=torch.uint8)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         check(lib.lipvq_mse_pair_f32(_ptr(xr), _ptr(x), x.numel(), _ptr(zq), _ptr(ze), ze.numel(), _ptr(out),
                                      _ptr(ws), _stream()), "lipvq_mse_pair_f32")
     return out
@@ -146,7 +172,7 @@ def mlp3_pack_bwd(W0, W1, W2) -> PackedMlp3:
     J1, J2 = W1.shape[0], W2.shape[0]
     n = lib.lipvq_mlp3_packed_bwd_floats(K0, J0, J1, J2)
     buf = torch.empty(n, device=W0.device, dtype=torch.float32)
-    with torch.cuda.device(W0.device):
+    with _on(W0.device):
         check(lib.lipvq_mlp3_pack_bwd_f32(_ptr(W0), _ptr(W1), _ptr(W2), _ptr(buf), K0, J0, J1, J2, _stream()),
               "lipvq_mlp3_pack_bwd_f32")
     return PackedMlp3(buf, K0, J0, J1, J2)
@@ -165,7 +191,7 @@ def mlp3_bwd(gy, pre, packed_bwd: PackedMlp3, acts, want_gx=True):
     g1 = torch.empty((N, p.J1), device=dev, dtype=torch.float32)
     g0 = torch.empty((N, p.J0), device=dev, dtype=torch.float32)
     gx = torch.empty((N, p.K0), device=dev, dtype=torch.float32) if want_gx else None
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib.lipvq_mlp3_bwd_f32(_ptr(gy), _ptr(pre0), _ptr(pre1), _ptr(pre2), _ptr(p.buf),
                                      None if ident else _ptr(g2), _ptr(g1), _ptr(g0), _ptr(gx), N, p.K0, p.J0,
                                      p.J1, p.J2, int(acts[0]), int(acts[1]), int(acts[2]), _stream()),
@@ -187,7 +213,7 @@ def wgrad(G, H, h_act=ACT_NONE, hidx=None, want_bias=True):
     gW = torch.empty((J, Kd), device=dev, dtype=torch.float32)
     gb = torch.empty(J, device=dev, dtype=torch.float32) if want_bias else None
     ws = torch.empty(lib.lipvq_wgrad_workspace_bytes(N, J, Kd), device=dev, dtype=torch.uint8)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib.lipvq_wgrad_f32(_ptr(G), _ptr(H), _ptr(hidx), int(h_act), _ptr(gW), _ptr(gb), _ptr(ws), N, J, Kd,
                                   _stream()), "lipvq_wgrad_f32")
     return gW, gb
@@ -197,7 +223,7 @@ def scatter_add(g, idx, K):
     g, idx = _chk(g, "g"), _chk(idx, "idx", torch.int64)
     N, D = g.shape
     gC = torch.zeros((K, D), device=g.device, dtype=torch.float32)
-    with torch.cuda.device(g.device):
+    with _on(g.device):
         check(lib.lipvq_scatter_add_f32(_ptr(g), _ptr(idx), _ptr(gC), N, K, D, _stream()), "lipvq_scatter_add_f32")
     return gC
 
@@ -205,7 +231,7 @@ def scatter_add(g, idx, K):
 def lipschitz_bwd(W, ci, gWn):
     W, ci, gWn = _chk(W, "W"), _chk(ci, "ci"), _chk(gWn, "gWn")
     gW, gci = torch.empty_like(W), torch.empty_like(ci)
-    with torch.cuda.device(W.device):
+    with _on(W.device):
         check(lib.lipvq_lipschitz_bwd_f32(_ptr(W), _ptr(ci), _ptr(gWn), _ptr(gW), _ptr(gci), W.shape[0], W.shape[1],
                                           _stream()), "lipvq_lipschitz_bwd_f32")
     return gW, gci
@@ -219,7 +245,7 @@ def scaled_diff(a, b, alpha, gscale=None, c=None):
     if gscale is not None:
         gscale = _chk(gscale.reshape(1), "gscale")
     out = torch.empty_like(a)
-    with torch.cuda.device(a.device):
+    with _on(a.device):
         check(lib.lipvq_scaled_diff_f32(_ptr(a), _ptr(b), _ptr(c), float(alpha), _ptr(gscale), _ptr(out), a.numel(),
                                         _stream()), "lipvq_scaled_diff_f32")
     return out
@@ -244,7 +270,7 @@ def nearest_prepare(codebook: torch.Tensor) -> PreparedCodebook:
     codebook = _chk(codebook, "codebook")
     K, D = codebook.shape
     buf = torch.empty(lib.lipvq_nearest_prep_bytes(K, D), device=codebook.device, dtype=torch.uint8)
-    with torch.cuda.device(codebook.device):
+    with _on(codebook.device):
         check(lib.lipvq_nearest_prepare_f32(_ptr(codebook), _ptr(buf), K, D, _stream()), "lipvq_nearest_prepare_f32")
     return PreparedCodebook(buf, K, D)
 
@@ -267,7 +293,7 @@ def nearest_screened(z, codebook, prep: PreparedCodebook, usage=None, want_zq=Tr
     zq = torch.empty_like(z) if want_zq else None
     ws = torch.empty(max(16, lib.lipvq_nearest_workspace_bytes(N) // 4), device=dev, dtype=torch.int32)
     dt = None
-    with torch.cuda.device(dev):
+    with _on(dev):
         if debug_gamma is None:
             check(lib.lipvq_nearest_screened_f32(_ptr(z), _ptr(codebook), _ptr(prep.buf), _ptr(idx), _ptr(zq),
                                                  _ptr(usage), _ptr(ws), N, K, D, _stream()),
@@ -315,7 +341,7 @@ def tokenize(x, packed: PackedMlp3, raw, codebook, prep: PreparedCodebook, usage
     zq = torch.empty((N, D), device=dev, dtype=torch.float32) if want_zq else None
     ze = torch.empty((N, D), device=dev, dtype=torch.float32) if want_ze else None
     ws = workspace if workspace is not None else tokenize_workspace(N, D, dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib.lipvq_tokenize_f32(_ptr(x), _ptr(packed.buf), raw_arr, _ptr(codebook), _ptr(prep.buf), _ptr(idx), _ptr(zq),
                                      _ptr(usage), _ptr(ze), _ptr(ws), N, A, packed.J0, packed.J1, D, K, _stream()),
               "lipvq_tokenize_f32")
@@ -340,7 +366,7 @@ def linear(x, W, b=None, act=ACT_NONE, save_pre=False):
     E = W.shape[0]
     y = torch.empty((N, E), device=x.device, dtype=torch.float32)
     pre = torch.empty_like(y) if save_pre else None
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         check(lib.lipvq_linear_act_f32(_ptr(x), _ptr(W), _ptr(b), _ptr(y), _ptr(pre), N, Kin, E, int(act), _stream()),
               "lipvq_linear_act_f32")
     return (y, pre) if save_pre else y
@@ -372,7 +398,7 @@ def embed_rows(src, idx, pos, ln_w, ln_b, eps, out, N, T, bstride, tstride, offs
         if last > out.numel():
             raise ValueError("embed_rows: the output slots do not fit in `out`")
     stats = torch.empty((N, 2), device=src.device, dtype=torch.float32) if want_stats else None
-    with torch.cuda.device(src.device):
+    with _on(src.device):
         check(lib.lipvq_embed_rows_f32(_ptr(src), _ptr(idx), _ptr(pos), _ptr(ln_w), _ptr(ln_b), float(eps), _ptr(out),
                                        _ptr(stats), N, T, E, src.shape[0], bstride, tstride, offset, _stream()),
               "lipvq_embed_rows_f32")
@@ -388,7 +414,7 @@ def embed_rows_bwd(gout, src, idx, pos, stats, ln_w, g_src, g_pos, g_lnw, g_lnb,
                            ("g_lnb", g_lnb, (E,))):
         if t is not None and (tuple(t.shape) != shape or not t.is_contiguous() or t.dtype != torch.float32):
             raise ValueError(f"embed_rows_bwd: {name} must be a contiguous fp32 tensor of shape {shape}")
-    with torch.cuda.device(src.device):
+    with _on(src.device):
         check(lib.lipvq_embed_rows_bwd_f32(_ptr(gout), _ptr(src), _ptr(idx), _ptr(pos), _ptr(stats), _ptr(ln_w),
                                            _ptr(g_src), _ptr(g_pos), _ptr(g_lnw), _ptr(g_lnb), N, T, E, src.shape[0],
                                            bstride, tstride, offset, _stream()), "lipvq_embed_rows_bwd_f32")
@@ -405,7 +431,7 @@ def bin_minmax(actions, running_min, running_max):
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.shape == (actions.shape[1],)):
             raise ValueError(f"bin_minmax: {name} must be a contiguous fp32 CUDA tensor of shape [{actions.shape[1]}]")
     N, A = actions.shape
-    with torch.cuda.device(actions.device):
+    with _on(actions.device):
         check(lib.lipvq_bin_minmax_f32(_ptr(actions), _ptr(running_min), _ptr(running_max), N, A, _stream()),
               "lipvq_bin_minmax_f32")
 
@@ -415,7 +441,7 @@ def bin_discretize(actions, running_min, running_max, num_bins):
     actions, running_min, running_max = _chk(actions, "actions"), _chk(running_min, "running_min"), _chk(running_max, "running_max")
     N, A = actions.shape
     bins = torch.empty((A, N), device=actions.device, dtype=torch.int64)
-    with torch.cuda.device(actions.device):
+    with _on(actions.device):
         check(lib.lipvq_bin_discretize_f32(_ptr(actions), _ptr(running_min), _ptr(running_max), _ptr(bins), N, A,
                                            int(num_bins), _stream()), "lipvq_bin_discretize_f32")
     return bins
@@ -426,7 +452,7 @@ def bin_boundaries(running_min, running_max, num_bins):
     running_min, running_max = _chk(running_min, "running_min"), _chk(running_max, "running_max")
     A = running_min.numel()
     out = torch.empty((A, num_bins + 1), device=running_min.device, dtype=torch.float32)
-    with torch.cuda.device(out.device):
+    with _on(out.device):
         check(lib.lipvq_bin_boundaries_f32(_ptr(running_min), _ptr(running_max), _ptr(out), A, int(num_bins), _stream()),
               "lipvq_bin_boundaries_f32")
     return out
@@ -441,7 +467,7 @@ def bin_hidden(bins, P, b1, save_pre=False):
     nb, H = P.shape[1], P.shape[2]
     h = torch.empty((N, H), device=P.device, dtype=torch.float32)
     pre = torch.empty_like(h) if save_pre else None
-    with torch.cuda.device(P.device):
+    with _on(P.device):
         check(lib.lipvq_bin_hidden_f32(_ptr(bins), _ptr(P), _ptr(b1), _ptr(h), _ptr(pre), N, A, nb, H, _stream()),
               "lipvq_bin_hidden_f32")
     return (h, pre) if save_pre else h
@@ -453,7 +479,7 @@ def act_bwd(g, pre, act):
     if g.shape != pre.shape:
         raise ValueError("act_bwd: shapes differ")
     out = torch.empty_like(g)
-    with torch.cuda.device(g.device):
+    with _on(g.device):
         check(lib.lipvq_act_bwd_f32(_ptr(g), _ptr(pre), _ptr(out), g.numel(), int(act), _stream()), "lipvq_act_bwd_f32")
     return out
 
@@ -467,6 +493,6 @@ def ema_update(cluster_size, embed_sum, counts, dw, codebook, decay, eps):
         if not (t.is_cuda and t.dtype == dt and t.is_contiguous() and tuple(t.shape) == shape):
             raise ValueError(f"ema_update: {name} must be a contiguous CUDA {dt} tensor of shape {shape}")
     ws = torch.empty(1, device=codebook.device, dtype=torch.float64)
-    with torch.cuda.device(codebook.device):
+    with _on(codebook.device):
         check(lib.lipvq_ema_update_f32(_ptr(cluster_size), _ptr(embed_sum), _ptr(counts), _ptr(dw), _ptr(codebook),
                                        float(decay), float(eps), K, D, _ptr(ws), _stream()), "lipvq_ema_update_f32")
