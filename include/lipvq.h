@@ -101,6 +101,11 @@ size_t lipvq_nearest_workspace_bytes(int64_t N);
  * holds how many rows were decided by the exact kernel (the rest were certified by the screen). */
 int lipvq_nearest_screened_f32(const float* z, const float* codebook, const void* prep, int64_t* idx, float* zq,
                                int64_t* usage, void* workspace, int64_t N, int K, int D, void* stream);
+/* Same contract again (idx / zq / usage as lipvq_nearest_f32 with LIPVQ_DIST_NORM) with every row decided by the exact
+ * re-scoring kernel: needs no prepared codebook.  For batches of a few thousand rows (training steps, where the codebook
+ * changes every step).  D in {32, 64, 128, 208}. */
+int lipvq_nearest_rows_f32(const float* z, const float* codebook, int64_t* idx, float* zq, int64_t* usage, int64_t N,
+                           int K, int D, void* stream);
 /* Test hook: also dumps the approximate distances d~ [N][Kpad] (Kpad = K rounded up to 32) and takes
  * the error-bound factor gamma from the caller. */
 int lipvq_screen_debug_f32(const float* z, const float* codebook, const void* prep, int64_t* idx, float* zq,

@@ -226,18 +226,18 @@ template <int DCH>
 __global__ __launch_bounds__(256) void nearest_rows_kernel(
     const float* __restrict__ z, const float* __restrict__ cb, int64_t* __restrict__ idx, float* __restrict__ zq,
     unsigned long long* __restrict__ usage, const int* __restrict__ row_list, const int* __restrict__ row_count,
-    int K, int z_by_slot) {
+    int K, int z_by_slot, int count_direct) {
     constexpr int D = DCH * 8;
     constexpr int RB = 4, SL = 64;               // rows per workgroup, code slices per row
     __shared__ float s_v[RB][SL];
     __shared__ int s_k[RB][SL];
-    const int count = *row_count;
+    const int count = row_count ? *row_count : count_direct;     // row_list == NULL: every row 0..count_direct-1
     const int r = threadIdx.x & (RB - 1), sl = threadIdx.x / RB;
   for (int base = blockIdx.x * RB; base < count; base += gridDim.x * RB) {
     const int slot = base + r;
     const bool valid = slot < count;
     const int cslot = valid ? slot : count - 1;
-    const int64_t row = row_list[cslot];
+    const int64_t row = row_list ? row_list[cslot] : cslot;
     float zr[D];
     {
         const float4* z4 = reinterpret_cast<const float4*>(z + (size_t)(z_by_slot ? (int64_t)cslot : row) * D);
@@ -465,7 +465,7 @@ static int launch_rows_t(const float* z, int z_by_slot, const float* cb, int64_t
     int64_t blocks = (N + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL((nearest_rows_kernel<DCH>), dim3((unsigned)blocks), dim3(256), 0, st, z, cb, idx, zq,
-                       (unsigned long long*)usage, amb_list, amb_count, K, z_by_slot);
+                       (unsigned long long*)usage, amb_list, amb_count, K, z_by_slot, amb_list ? 0 : (int)N);
     return check_launch("nearest_rows");
 }
 
@@ -502,6 +502,18 @@ static int screened_impl(const float* z, const float* cb, const void* prep, int6
 
 extern "C" int lipvq_nearest_screened_supported(int K, int D) {
     return (K > 0 && (D == 32 || D == 64 || D == 128 || D == 208)) ? 1 : 0;
+}
+
+// Exact decision of EVERY row by the re-scoring kernel (4 rows x 64 code slices per workgroup): no codebook
+// preparation, no screening.  The cheapest route for training-step batches, where the codebook changes every step
+// (the preparation alone costs ~110 us) and a screen launch has a ~75 us floor: 13 us at N = 80, D = 208, K = 1024.
+extern "C" int lipvq_nearest_rows_f32(const float* z, const float* codebook, int64_t* idx, float* zq, int64_t* usage,
+                                      int64_t N, int K, int D, void* stream) {
+    if (N < 0 || K <= 0) return fail(LIPVQ_EINVAL, "nearest_rows: bad sizes");
+    if (N == 0) return LIPVQ_OK;
+    if (!z || !codebook || !idx) return fail(LIPVQ_EINVAL, "nearest_rows: null pointer");
+    if (N > 0x7fffffffLL) return fail(LIPVQ_EUNSUPPORTED, "nearest_rows: N too large");
+    return lipvq_launch_rows(z, 0, codebook, idx, zq, usage, nullptr, nullptr, N, K, D, (hipStream_t)stream);
 }
 
 // Same contract as lipvq_nearest_f32(.., LIPVQ_DIST_NORM) -- identical idx / zq / usage -- through the

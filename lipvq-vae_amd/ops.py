@@ -275,6 +275,24 @@ def nearest_prepare(codebook: torch.Tensor) -> PreparedCodebook:
     return PreparedCodebook(buf, K, D)
 
 
+def nearest_rows(z, codebook, usage=None, want_zq=True):
+    """(idx, zq) exactly as nearest(z, codebook, DIST_NORM), every row decided by the exact re-scoring kernel (no
+    prepared codebook): the route for small batches."""
+    z, codebook = _chk(z, "z"), _chk(codebook, "codebook")
+    N, D = z.shape
+    K = codebook.shape[0]
+    if codebook.shape[1] != D:
+        raise ValueError("nearest_rows: codebook width does not match")
+    if usage is not None:
+        usage = _chk(usage, "usage", torch.int64)
+    idx = torch.empty(N, device=z.device, dtype=torch.int64)
+    zq = torch.empty_like(z) if want_zq else None
+    with _on(z.device):
+        check(lib.lipvq_nearest_rows_f32(_ptr(z), _ptr(codebook), _ptr(idx), _ptr(zq), _ptr(usage), N, K, D, _stream()),
+              "lipvq_nearest_rows_f32")
+    return idx, zq
+
+
 def nearest_screened(z, codebook, prep: PreparedCodebook, usage=None, want_zq=True, return_workspace=False,
                      debug_gamma=None):
     """Same results as nearest(z, codebook, DIST_NORM), via MFMA screening + exact re-scoring of the

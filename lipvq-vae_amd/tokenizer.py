@@ -140,10 +140,18 @@ class LLFQVAE_V4(_TokenizerBase):
             return ops.mlp3_pack(*(t.detach() for t in self._dec_params()))
         return self._dec_cache.get(self._dec_params(), build)
 
+    # rows up to which _quantize skips the screen: measured (scripts/measure_quantize_small.py, K = 1024) exact rows vs
+    # screen [+ codebook preparation]: D = 208: 36 vs 75 [+69] us at N = 80, 74 vs 122 [+69] at 2048, 143 vs 89 [+69] at 4096
+    EXACT_ROWS_MAX = 2048
+
     def _quantize(self, z_e, usage):
         """(idx, z_q) of v5:37-48: MFMA screen + exact re-scoring where the latent width has a
         screening instance, the all-pairs exact kernel otherwise.  Identical results either way."""
         cb = self.quantizer.codebook.detach()
+        if ops.nearest_screen_supported(cb.shape[0], cb.shape[1]) and 0 < z_e.shape[0] <= self.EXACT_ROWS_MAX:
+            # training-step batches: the exact kernel on every row beats preparing the codebook + one screen launch
+            self.last_exact_rows = None
+            return ops.nearest_rows(z_e, cb, usage=usage)
         if ops.nearest_screen_supported(cb.shape[0], cb.shape[1]) and z_e.shape[0] > 0:
             prep = self._cb_cache.get((self.quantizer.codebook,), lambda: ops.nearest_prepare(cb))
             idx, zq, ws = ops.nearest_screened(z_e, cb, prep, usage=usage, return_workspace=True)

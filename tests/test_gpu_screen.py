@@ -145,3 +145,22 @@ def test_zero_rows_and_constant_codebook(ops, oracle):
     idx, _, ws = ops.nearest_screened(dev(z), cbd, ops.nearest_prepare(cbd), return_workspace=True)
     assert np.array_equal(idx.cpu().numpy(), idx_ref) and (idx_ref == 0).all()
     assert int(ws[0]) == N
+
+
+@pytest.mark.parametrize("N,K,D", [(80, 1024, 208), (1, 37, 32), (4097, 1000, 64), (333, 8192, 128)])
+def test_nearest_rows_all_rows_equals_oracle(oracle, N, K, D):
+    """lipvq_nearest_rows_f32 (the small-batch route: exact kernel on every row, no prepared codebook)."""
+    from lipvq_vae_amd import ops
+    rng = np.random.default_rng(N + K)
+    cb = rng.uniform(0, 1, (K, D)).astype(np.float32)
+    z = rng.uniform(0, 1, (N, D)).astype(np.float32)
+    z[: N // 2] = cb[rng.integers(0, K, N // 2)] + rng.normal(0, 1e-3, (N // 2, D)).astype(np.float32)
+    if N > 2:
+        z[1] = cb[5]                                       # exact hit
+        cb[7] = cb[5]                                      # duplicate code: the lower index must win
+    idx_ref, zq_ref, usage_ref = oracle.nearest(z, cb)
+    usage = torch.zeros(K, dtype=torch.int64, device="cuda")
+    idx, zq = ops.nearest_rows(torch.from_numpy(z).cuda(), torch.from_numpy(cb).cuda(), usage=usage)
+    assert np.array_equal(idx.cpu().numpy(), idx_ref)
+    assert np.array_equal(zq.cpu().numpy(), zq_ref)
+    assert np.array_equal(usage.cpu().numpy(), usage_ref)
