@@ -104,3 +104,25 @@ def test_skewed_and_degenerate_code_distributions(oracle):
         model.reset_usage()
         idx2, _ = model._quantize(model.encode(xt), model.code_usage)      # stand-alone screen + exact rows (wave aggregation)
         assert torch.equal(idx2, idx) and np.array_equal(model.code_usage.cpu().numpy(), ref["usage"])
+
+
+def test_two_streams_concurrently(oracle):
+    """The library is stateless: two tokenizers driven from two HIP streams at the same time (each with its own
+    workspace) give the serial answers."""
+    p, m1 = _setup(41, 7, 64, 1024, oracle)
+    _, m2 = _setup(41, 7, 64, 1024, oracle)
+    xs = [torch.from_numpy(O.make_inputs(50 + i, 40000 + 77 * i, 7)).cuda() for i in range(4)]
+    serial = [m1.tokenize(x, count_usage=False)[0].clone() for x in xs]
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    out = [None] * 4
+    for rep in range(3):
+        with torch.cuda.stream(s1):
+            out[0] = m1.tokenize(xs[0], count_usage=False)[0].clone()
+            out[2] = m1.tokenize(xs[2], count_usage=False)[0].clone()
+        with torch.cuda.stream(s2):
+            out[1] = m2.tokenize(xs[1], count_usage=False)[0].clone()
+            out[3] = m2.tokenize(xs[3], count_usage=False)[0].clone()
+        torch.cuda.synchronize()
+        for a, b in zip(out, serial):
+            assert torch.equal(a, b)
