@@ -128,6 +128,20 @@ int lipvq_tokenize_f32(const float* x, const float* packed, const float* const* 
                        const void* prep, int64_t* idx, float* zq, int64_t* usage, float* ze_out, void* workspace,
                        int64_t N, int A, int J0, int J1, int D, int K, void* stream);
 
+/* ---- fast mode (opt-in): the encoder's three GEMMs on fp16 MFMAs with fp32 accumulation -- the half-precision
+ * encoder of BASELINE.json's config 2 / SURVEY section 7.  NOT bit-identical to lipvq_tokenize_f32: a fraction of a
+ * percent of the indices differ, always between near-equidistant codes (the flip rate is reported by bench.py and
+ * bounded in tests/test_gpu_fast.py); z_q rows are exact codebook rows; the quantizer (screen + exact re-scoring) is the
+ * parity one, applied to the fp16-encoder z_e; rows the screen cannot certify are decided by the exact kernel from the
+ * fp32 encoder.  packed16: lipvq_mlp3_pack_f16_f32 of {W0, W1, W2 (normalised)} (lipvq_mlp3_packed_f16_bytes() bytes,
+ * 16-byte aligned); `packed` still supplies the fp32 biases.  Same shapes as lipvq_tokenize_supported(). */
+size_t lipvq_mlp3_packed_f16_bytes(int A, int J0, int J1, int D);
+int lipvq_mlp3_pack_f16_f32(const float* W0, const float* W1, const float* W2, void* packed16, int A, int J0, int J1,
+                            int D, void* stream);
+int lipvq_tokenize_fast_f32(const float* x, const float* packed, const void* packed16, const float* const* raw6,
+                            const float* codebook, const void* prep, int64_t* idx, float* zq, int64_t* usage,
+                            void* workspace, int64_t N, int A, int J0, int J1, int D, int K, void* stream);
+
 /* ---- backward (what autograd derives from v5:70-84 / vq:38-76) --------------------------- */
 
 /* Backward-data of lipvq_mlp3_f32.  gy [N][J2] = dL/dy.  pre0/pre1/pre2 are the saved

@@ -73,6 +73,7 @@ struct Gelu2 {
 struct TokArgs {
     const float* x;              // [N][A]
     const float* packed;         // lipvq_mlp3_pack_f32 of (A -> 64 -> 128 -> D)
+    const unsigned char* packed16;  // fast mode: lipvq_mlp3_pack_f16_f32 of the same stack (NULL in parity mode)
     const unsigned char* prep;   // lipvq_nearest_prepare_f32 of the codebook
     const float* cb;             // [K][D]
     int64_t* idx;                // [N]
@@ -87,7 +88,10 @@ struct TokArgs {
 };
 
 // T0 = 2 (64 features), T1 = 4 (128 features): the reference's encoder widths (v5:54-59).
-template <int S>
+// FAST: the encoder's three GEMMs as fp16 MFMAs (v_mfma_f32_32x32x16_f16, fp32 accumulation) -- the "fast" mode
+// of SURVEY section 7 / BASELINE config 2's half-precision encoder: NOT bit-identical to the oracle (a fraction of a
+// percent of the indices differ, all between near-equidistant codes); everything after z_e is the parity path.
+template <int S, bool FAST>
 __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
     constexpr int T0 = 2, T1 = 4, T2 = S / 2;
     constexpr int S1 = 16 * T0, S2 = 16 * T1;               // k-steps (pairs) of layers 1 and 2
@@ -97,13 +101,15 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
     const PrepLayout L = prep_layout(a.K, a.D);
     const int S0 = PL.S0;
     const int S0q = (S0 + 3) / 4;
-    // LDS carve (floats unless noted)
+    // LDS carve (floats unless noted).  FAST: the three weight blocks are fp16 MFMA fragments instead:
+    // [T][k-steps of 16][64 lanes][8 halfs]
+    const int S0h = (a.A + 15) / 16;                                   // fp16 k-steps of layer 0
     float* w_P0 = reinterpret_cast<float*>(lds);                       // [T0][S0q][64][4]
-    float* w_B0 = w_P0 + T0 * S0q * 256;                               // [32*T0]
+    float* w_B0 = w_P0 + (FAST ? T0 * S0h * 256 : T0 * S0q * 256);     // [32*T0]
     float* w_P1 = w_B0 + 32 * T0;                                      // [T1][S1/4][64][4]
-    float* w_B1 = w_P1 + T1 * (S1 / 4) * 256;
+    float* w_B1 = w_P1 + (FAST ? T1 * (2 * T0) * 256 : T1 * (S1 / 4) * 256);
     float* w_P2 = w_B1 + 32 * T1;                                      // [T2][S2/4][64][4]
-    float* w_B2 = w_P2 + T2 * (S2 / 4) * 256;
+    float* w_B2 = w_P2 + (FAST ? T2 * (2 * T1) * 256 : T2 * (S2 / 4) * 256);
     float* w_mu = w_B2 + 32 * T2;                                      // [16*S]
     unsigned char* stage0 = reinterpret_cast<unsigned char*>(w_mu + 16 * S);   // 2 stage buffers (also the
                                                                                 // per-wave transpose slices of the decision)
@@ -118,21 +124,30 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
 
     // ---- once per workgroup: weights (re-laid out 4 k-steps per 16-byte LDS read), biases, mu --------
     {
-        const float* P0 = a.packed + PL.oP0;
-        for (int i = tid; i < T0 * S0q * 256; i += FUSED_THREADS) {
-            const int q = i & 3, l = (i >> 2) & 63, sq = (i >> 8) % S0q, t = (i >> 8) / S0q;
-            const int s = 4 * sq + q;
-            w_P0[i] = (s < S0) ? P0[((size_t)t * S0 + s) * 64 + l] : 0.0f;
-        }
-        const float* P1 = a.packed + PL.oP1;
-        for (int i = tid; i < T1 * (S1 / 4) * 256; i += FUSED_THREADS) {
-            const int q = i & 3, l = (i >> 2) & 63, sq = (i >> 8) % (S1 / 4), t = (i >> 8) / (S1 / 4);
-            w_P1[i] = P1[((size_t)t * S1 + 4 * sq + q) * 64 + l];
-        }
-        const float* P2 = a.packed + PL.oP2;
-        for (int i = tid; i < T2 * (S2 / 4) * 256; i += FUSED_THREADS) {
-            const int q = i & 3, l = (i >> 2) & 63, sq = (i >> 8) % (S2 / 4), t = (i >> 8) / (S2 / 4);
-            w_P2[i] = P2[((size_t)t * S2 + 4 * sq + q) * 64 + l];
+        if (FAST) {
+            // packed16 = [P0h | P1h | P2h], each already [t][s][lane][8 halfs] = 4 floats per (t, s, lane)
+            const float* src = reinterpret_cast<const float*>(a.packed16);
+            const int n0 = T0 * S0h * 256, n1 = T1 * (2 * T0) * 256, n2 = T2 * (2 * T1) * 256;
+            for (int i = tid; i < n0; i += FUSED_THREADS) w_P0[i] = src[i];
+            for (int i = tid; i < n1; i += FUSED_THREADS) w_P1[i] = src[n0 + i];
+            for (int i = tid; i < n2; i += FUSED_THREADS) w_P2[i] = src[n0 + n1 + i];
+        } else {
+            const float* P0 = a.packed + PL.oP0;
+            for (int i = tid; i < T0 * S0q * 256; i += FUSED_THREADS) {
+                const int q = i & 3, l = (i >> 2) & 63, sq = (i >> 8) % S0q, t = (i >> 8) / S0q;
+                const int s = 4 * sq + q;
+                w_P0[i] = (s < S0) ? P0[((size_t)t * S0 + s) * 64 + l] : 0.0f;
+            }
+            const float* P1 = a.packed + PL.oP1;
+            for (int i = tid; i < T1 * (S1 / 4) * 256; i += FUSED_THREADS) {
+                const int q = i & 3, l = (i >> 2) & 63, sq = (i >> 8) % (S1 / 4), t = (i >> 8) / (S1 / 4);
+                w_P1[i] = P1[((size_t)t * S1 + 4 * sq + q) * 64 + l];
+            }
+            const float* P2 = a.packed + PL.oP2;
+            for (int i = tid; i < T2 * (S2 / 4) * 256; i += FUSED_THREADS) {
+                const int q = i & 3, l = (i >> 2) & 63, sq = (i >> 8) % (S2 / 4), t = (i >> 8) / (S2 / 4);
+                w_P2[i] = P2[((size_t)t * S2 + 4 * sq + q) * 64 + l];
+            }
         }
         for (int i = tid; i < 32 * T0; i += FUSED_THREADS) w_B0[i] = a.packed[PL.oB0 + i];
         for (int i = tid; i < 32 * T1; i += FUSED_THREADS) w_B1[i] = a.packed[PL.oB1 + i];
@@ -153,120 +168,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
         const int64_t row = row0 + ln;
         const int64_t rowc = row < a.N ? row : a.N - 1;
 
-        // ================= phase A: encoder + Lipschitz layer, fp32 MFMA ====================
-        f32x16 h0[T0];
-        {
-            const float* xr = a.x + (size_t)rowc * a.A;
-#pragma unroll
-            for (int t = 0; t < T0; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) h0[t][r] = w_B0[32 * t + 2 * r + h];
-            for (int sq = 0; sq < S0q; ++sq) {
-                float4 av[T0];
-#pragma unroll
-                for (int t = 0; t < T0; ++t) av[t] = *reinterpret_cast<const float4*>(w_P0 + ((t * S0q + sq) * 64 + lane) * 4);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int k = 2 * (4 * sq + q) + h;
-                    const float bv = (k < a.A) ? xr[k] : 0.0f;
-#pragma unroll
-                    for (int t = 0; t < T0; ++t) {
-                        const float aq = q == 0 ? av[t].x : q == 1 ? av[t].y : q == 2 ? av[t].z : av[t].w;
-                        // padded k-steps (s >= S0) multiply zeros: acc + 0*0 = acc (oracle pads odd fan-in the same way)
-                        h0[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq, bv, h0[t], 0, 0, 0);
-                    }
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < T0; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) h0[t][r] = FUSED_GELU(h0[t][r]);
-        }
-        // ---- layer 1, software pipelined at source level: the GELU of tile t-1 is written between the MFMAs of tile t
-        // (two elements per 4-MFMA group).  A 64-cycle fp32 MFMA leaves ~12 vector issue slots before its dependent
-        // successor can start, so the polynomial (17 instructions per element) runs in the chain's shadow (ablation:
-        // GELU cost 87 us of a 407 us encoder-only launch when it ran after each chain).  The rare |x| >= sqrt(18)
-        // elements are fixed up behind a wave-uniform branch so that the pipelined region stays straight-line code.
-        f32x16 h1[T1];
-        f32x16 pend;                      // pre-activations of the previous tile, GELU pending
-        auto gelu_fixup = [&](f32x16& out, const f32x16& pre) {
-            bool slow = false;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) slow |= !(pre[r] * pre[r] < 18.0f);
-            if (__builtin_amdgcn_ballot_w64(slow) != 0ull) {          // wave-uniform, practically never taken
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (!(pre[r] * pre[r] < 18.0f)) out[r] = lq_gelu_tail(pre[r]);
-            }
-        };
-#pragma unroll
-        for (int t = 0; t < T1; ++t) {
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = w_B1[32 * t + 2 * r + h];
-#pragma unroll
-            for (int sq = 0; sq < S1 / 4; ++sq) {
-                const float4 av = *reinterpret_cast<const float4*>(w_P1 + ((t * (S1 / 4) + sq) * 64 + lane) * 4);
-                Gelu2 g;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, h0[(4 * sq + 0) / 16][(4 * sq + 0) % 16], acc, 0, 0, 0);
-                if (t > 0) g.stage0(pend[2 * sq], pend[2 * sq + 1]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, h0[(4 * sq + 1) / 16][(4 * sq + 1) % 16], acc, 0, 0, 0);
-                if (t > 0) g.stage1();
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, h0[(4 * sq + 2) / 16][(4 * sq + 2) % 16], acc, 0, 0, 0);
-                if (t > 0) g.stage2();
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, h0[(4 * sq + 3) / 16][(4 * sq + 3) % 16], acc, 0, 0, 0);
-                if (t > 0) {
-#ifndef LQ_ABL_NOGELU
-                    float o0, o1;
-                    g.stage3(o0, o1);
-                    h1[t - 1][2 * sq] = o0; h1[t - 1][2 * sq + 1] = o1;
-#else
-                    h1[t - 1][2 * sq] = pend[2 * sq]; h1[t - 1][2 * sq + 1] = pend[2 * sq + 1];
-#endif
-                }
-            }
-#ifndef LQ_ABL_NOGELU
-            if (t > 0) gelu_fixup(h1[t - 1], pend);
-#endif
-            pend = acc;
-        }
-        // the last tile's GELU runs inside the first layer-2 chain: steps 0 .. 47 of that chain only read h1[0..2]
         f16x8 ah[S], al[S];
         float n2 = 0.0f, amax = 0.0f;
         f32x16 zc[T2];                   // centred z_e (fp32) until the row's scale is known
-#pragma unroll
-        for (int t = 0; t < T2; ++t) {
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = w_B2[32 * t + 2 * r + h];
-#pragma unroll
-            for (int sq = 0; sq < S2 / 4; ++sq) {
-                if (t == 0 && sq == 3 * (S2 / 16)) {
-                    // h1[T1-1] is needed from here on (k-steps 48..63 of a 128-wide layer): finish its GELU
-#ifndef LQ_ABL_NOGELU
-                    gelu_fixup(h1[T1 - 1], pend);
-#endif
-                }
-                const float4 av = *reinterpret_cast<const float4*>(w_P2 + ((t * (S2 / 4) + sq) * 64 + lane) * 4);
-                const bool pg = (t == 0 && sq < 8);          // the 16 pending GELUs ride on groups 0..7 (< 12: they only read h1[0..2])
-                Gelu2 g;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, h1[(4 * sq + 0) / 16][(4 * sq + 0) % 16], acc, 0, 0, 0);
-                if (pg) g.stage0(pend[(2 * sq) & 15], pend[(2 * sq + 1) & 15]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, h1[(4 * sq + 1) / 16][(4 * sq + 1) % 16], acc, 0, 0, 0);
-                if (pg) g.stage1();
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, h1[(4 * sq + 2) / 16][(4 * sq + 2) % 16], acc, 0, 0, 0);
-                if (pg) g.stage2();
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, h1[(4 * sq + 3) / 16][(4 * sq + 3) % 16], acc, 0, 0, 0);
-                if (pg) {
-#ifndef LQ_ABL_NOGELU
-                    float o0, o1;
-                    g.stage3(o0, o1);
-                    h1[T1 - 1][(2 * sq) & 15] = o0; h1[T1 - 1][(2 * sq + 1) & 15] = o1;
-#else
-                    h1[T1 - 1][(2 * sq) & 15] = pend[(2 * sq) & 15]; h1[T1 - 1][(2 * sq + 1) & 15] = pend[(2 * sq + 1) & 15];
-#endif
-                }
-            }
+        // sigmoid, centring, row statistics and the optional z_e store of one finished 32-feature tile
+        auto finish_tile = [&](const int t, f32x16& acc) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float zv = FUSED_SIGMOID(acc[r]);
@@ -302,6 +208,178 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
                 }
             }
 #endif
+        };
+
+        if constexpr (!FAST) {
+            // ================= phase A: encoder + Lipschitz layer, fp32 MFMA ====================
+            f32x16 h0[T0];
+            {
+                const float* xr = a.x + (size_t)rowc * a.A;
+#pragma unroll
+                for (int t = 0; t < T0; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) h0[t][r] = w_B0[32 * t + 2 * r + h];
+                for (int sq = 0; sq < S0q; ++sq) {
+                    float4 av[T0];
+#pragma unroll
+                    for (int t = 0; t < T0; ++t) av[t] = *reinterpret_cast<const float4*>(w_P0 + ((t * S0q + sq) * 64 + lane) * 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int k = 2 * (4 * sq + q) + h;
+                        const float bv = (k < a.A) ? xr[k] : 0.0f;
+#pragma unroll
+                        for (int t = 0; t < T0; ++t) {
+                            const float aq = q == 0 ? av[t].x : q == 1 ? av[t].y : q == 2 ? av[t].z : av[t].w;
+                            // padded k-steps (s >= S0) multiply zeros: acc + 0*0 = acc (oracle pads odd fan-in the same way)
+                            h0[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq, bv, h0[t], 0, 0, 0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < T0; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) h0[t][r] = FUSED_GELU(h0[t][r]);
+            }
+            // ---- layer 1, software pipelined at source level: the GELU of tile t-1 is written between the MFMAs of tile t
+            // (two elements per 4-MFMA group).  A 64-cycle fp32 MFMA leaves ~12 vector issue slots before its dependent
+            // successor can start, so the polynomial (17 instructions per element) runs in the chain's shadow (ablation:
+            // GELU cost 87 us of a 407 us encoder-only launch when it ran after each chain).  The rare |x| >= sqrt(18)
+            // elements are fixed up behind a wave-uniform branch so that the pipelined region stays straight-line code.
+            f32x16 h1[T1];
+            f32x16 pend;                      // pre-activations of the previous tile, GELU pending
+            auto gelu_fixup = [&](f32x16& out, const f32x16& pre) {
+                bool slow = false;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) slow |= !(pre[r] * pre[r] < 18.0f);
+                if (__builtin_amdgcn_ballot_w64(slow) != 0ull) {          // wave-uniform, practically never taken
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (!(pre[r] * pre[r] < 18.0f)) out[r] = lq_gelu_tail(pre[r]);
+                }
+            };
+#pragma unroll
+            for (int t = 0; t < T1; ++t) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = w_B1[32 * t + 2 * r + h];
+#pragma unroll
+                for (int sq = 0; sq < S1 / 4; ++sq) {
+                    const float4 av = *reinterpret_cast<const float4*>(w_P1 + ((t * (S1 / 4) + sq) * 64 + lane) * 4);
+                    Gelu2 g;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, h0[(4 * sq + 0) / 16][(4 * sq + 0) % 16], acc, 0, 0, 0);
+                    if (t > 0) g.stage0(pend[2 * sq], pend[2 * sq + 1]);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, h0[(4 * sq + 1) / 16][(4 * sq + 1) % 16], acc, 0, 0, 0);
+                    if (t > 0) g.stage1();
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, h0[(4 * sq + 2) / 16][(4 * sq + 2) % 16], acc, 0, 0, 0);
+                    if (t > 0) g.stage2();
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, h0[(4 * sq + 3) / 16][(4 * sq + 3) % 16], acc, 0, 0, 0);
+                    if (t > 0) {
+#ifndef LQ_ABL_NOGELU
+                        float o0, o1;
+                        g.stage3(o0, o1);
+                        h1[t - 1][2 * sq] = o0; h1[t - 1][2 * sq + 1] = o1;
+#else
+                        h1[t - 1][2 * sq] = pend[2 * sq]; h1[t - 1][2 * sq + 1] = pend[2 * sq + 1];
+#endif
+                    }
+                }
+#ifndef LQ_ABL_NOGELU
+                if (t > 0) gelu_fixup(h1[t - 1], pend);
+#endif
+                pend = acc;
+            }
+            // the last tile's GELU runs inside the first layer-2 chain: steps 0 .. 47 of that chain only read h1[0..2]
+#pragma unroll
+            for (int t = 0; t < T2; ++t) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = w_B2[32 * t + 2 * r + h];
+#pragma unroll
+                for (int sq = 0; sq < S2 / 4; ++sq) {
+                    if (t == 0 && sq == 3 * (S2 / 16)) {
+                        // h1[T1-1] is needed from here on (k-steps 48..63 of a 128-wide layer): finish its GELU
+#ifndef LQ_ABL_NOGELU
+                        gelu_fixup(h1[T1 - 1], pend);
+#endif
+                    }
+                    const float4 av = *reinterpret_cast<const float4*>(w_P2 + ((t * (S2 / 4) + sq) * 64 + lane) * 4);
+                    const bool pg = (t == 0 && sq < 8);          // the 16 pending GELUs ride on groups 0..7 (< 12: they only read h1[0..2])
+                    Gelu2 g;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, h1[(4 * sq + 0) / 16][(4 * sq + 0) % 16], acc, 0, 0, 0);
+                    if (pg) g.stage0(pend[(2 * sq) & 15], pend[(2 * sq + 1) & 15]);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, h1[(4 * sq + 1) / 16][(4 * sq + 1) % 16], acc, 0, 0, 0);
+                    if (pg) g.stage1();
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, h1[(4 * sq + 2) / 16][(4 * sq + 2) % 16], acc, 0, 0, 0);
+                    if (pg) g.stage2();
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, h1[(4 * sq + 3) / 16][(4 * sq + 3) % 16], acc, 0, 0, 0);
+                    if (pg) {
+#ifndef LQ_ABL_NOGELU
+                        float o0, o1;
+                        g.stage3(o0, o1);
+                        h1[T1 - 1][(2 * sq) & 15] = o0; h1[T1 - 1][(2 * sq + 1) & 15] = o1;
+#else
+                        h1[T1 - 1][(2 * sq) & 15] = pend[(2 * sq) & 15]; h1[T1 - 1][(2 * sq + 1) & 15] = pend[(2 * sq + 1) & 15];
+#endif
+                    }
+                }
+                finish_tile(t, acc);
+            }
+        } else {
+            // ---- fast mode: fp16 operands, fp32 accumulation.  k index of (step s, lane half h, element j) = 16 s + 2 j + h,
+            // i.e. the B operand of step s is registers 8 (s & 1) .. +7 of tile s >> 1 of the previous layer as they stand.
+            const _Float16* wh0 = reinterpret_cast<const _Float16*>(w_P0);
+            const _Float16* wh1 = reinterpret_cast<const _Float16*>(w_P1);
+            const _Float16* wh2 = reinterpret_cast<const _Float16*>(w_P2);
+            const float* xr = a.x + (size_t)rowc * a.A;
+            f32x16 h0[T0];
+#pragma unroll
+            for (int t = 0; t < T0; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h0[t][r] = w_B0[32 * t + 2 * r + h];
+            for (int s2 = 0; s2 < S0h; ++s2) {
+                f16x8 bx;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 16 * s2 + 2 * j + h;
+                    bx[j] = (_Float16)((k < a.A) ? xr[k] : 0.0f);
+                }
+#pragma unroll
+                for (int t = 0; t < T0; ++t) {
+                    const f16x8 av = *reinterpret_cast<const f16x8*>(wh0 + ((size_t)(t * S0h + s2) * 64 + lane) * 8);
+                    h0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bx, h0[t], 0, 0, 0);
+                }
+            }
+            f16x8 b0[2 * T0];
+#pragma unroll
+            for (int t = 0; t < T0; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) b0[2 * t + (r >> 3)][r & 7] = (_Float16)FUSED_GELU(h0[t][r]);
+            f16x8 b1[2 * T1];
+#pragma unroll
+            for (int t = 0; t < T1; ++t) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = w_B1[32 * t + 2 * r + h];
+#pragma unroll
+                for (int s2 = 0; s2 < 2 * T0; ++s2) {
+                    const f16x8 av = *reinterpret_cast<const f16x8*>(wh1 + ((size_t)(t * (2 * T0) + s2) * 64 + lane) * 8);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b0[s2], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) b1[2 * t + (r >> 3)][r & 7] = (_Float16)FUSED_GELU(acc[r]);
+            }
+#pragma unroll
+            for (int t = 0; t < T2; ++t) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = w_B2[32 * t + 2 * r + h];
+#pragma unroll
+                for (int s2 = 0; s2 < 2 * T1; ++s2) {
+                    const f16x8 av = *reinterpret_cast<const f16x8*>(wh2 + ((size_t)(t * (2 * T1) + s2) * 64 + lane) * 8);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b1[s2], acc, 0, 0, 0);
+                }
+                finish_tile(t, acc);
+            }
         }
         n2 += __shfl_xor(n2, 32, 64);
         amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
@@ -348,19 +426,22 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
     }
 }
 
-template <int S>
+template <int S, bool FAST>
 static size_t fused_lds_bytes(int A, int K) {
     constexpr int T0 = 2, T1 = 4, T2 = S / 2;
     const int S0q = ((A + 1) / 2 + 3) / 4;
-    size_t fl = (size_t)T0 * S0q * 256 + 32 * T0 + (size_t)T1 * 8 * 256 + 32 * T1 + (size_t)T2 * 16 * 256 + 32 * T2 + 16 * S;
+    const int S0h = (A + 15) / 16;
+    size_t fl = FAST ? (size_t)T0 * S0h * 256 + (size_t)T1 * (2 * T0) * 256 + (size_t)T2 * (2 * T1) * 256
+                     : (size_t)T0 * S0q * 256 + (size_t)T1 * 8 * 256 + (size_t)T2 * 16 * 256;
+    fl += 32 * T0 + 32 * T1 + 32 * T2 + 16 * S;
     return fl * sizeof(float) + 2 * (size_t)ScreenCfg<S, fused_tc(S)>::STAGE_BYTES + (K <= FUSED_HIST_MAX ? (size_t)K * 4 : 0);
 }
 
-template <int S>
+template <int S, bool FAST>
 static int launch_tokenize(const TokArgs& a, hipStream_t st) {
-    const size_t lds = fused_lds_bytes<S>(a.A, a.K);
+    const size_t lds = fused_lds_bytes<S, FAST>(a.A, a.K);
     if (lds > 160 * 1024) return fail(LIPVQ_EUNSUPPORTED, "tokenize: %zu B of LDS needed", lds);
-    auto kfn = tokenize_kernel<S>;
+    auto kfn = tokenize_kernel<S, FAST>;
     static size_t reserved = 0;                 // per instantiation; the attribute call costs ~10 us of host time
     if (lds > reserved) {
         hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -371,6 +452,46 @@ static int launch_tokenize(const TokArgs& a, hipStream_t st) {
     int64_t blocks = nblk < 256 ? nblk : 256;            // one persistent workgroup per CU
     hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(FUSED_THREADS), lds, st, a);
     return check_launch("tokenize");
+}
+
+// fp16 MFMA fragments of the encoder stack for the fast mode: [layer][tile t][step s][lane][8 halfs] with
+// element (t, s, lane, j) = W[32 t + feat(lane & 31)][16 s + 2 j + (lane >> 5)]  (0 outside the matrix)
+__global__ void mlp3_pack_f16_kernel(const float* __restrict__ W0, const float* __restrict__ W1, const float* __restrict__ W2,
+                                     _Float16* __restrict__ out, int A, int J0, int J1, int D) {
+    const int S0h = (A + 15) / 16, S1h = J0 / 16, S2h = J1 / 16;
+    const int T0 = J0 / 32, T1 = J1 / 32, T2 = (D + 31) / 32;
+    const size_t n0 = (size_t)T0 * S0h * 512, n1 = (size_t)T1 * S1h * 512, n2 = (size_t)T2 * S2h * 512;
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n0 + n1 + n2) return;
+    const float* W;
+    int K, J, Sh;
+    size_t e = g;
+    if (e < n0) { W = W0; K = A; J = J0; Sh = S0h; }
+    else if (e < n0 + n1) { e -= n0; W = W1; K = J0; J = J1; Sh = S1h; }
+    else { e -= n0 + n1; W = W2; K = J1; J = D; Sh = S2h; }
+    const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
+    const size_t ts = e >> 9;
+    const int s = (int)(ts % Sh), t = (int)(ts / Sh);
+    const int f = 32 * t + feat_of_tile_row(lane & 31);
+    const int k = 16 * s + 2 * j + (lane >> 5);
+    out[g] = (_Float16)((f < J && k < K) ? W[(size_t)f * K + k] : 0.0f);
+}
+
+extern "C" size_t lipvq_mlp3_packed_f16_bytes(int A, int J0, int J1, int D) {
+    if (A <= 0 || J0 <= 0 || J1 <= 0 || D <= 0 || (J0 & 31) || (J1 & 31)) return 0;
+    const size_t S0h = (A + 15) / 16, T2 = (D + 31) / 32;
+    return ((size_t)(J0 / 32) * S0h + (size_t)(J1 / 32) * (J0 / 16) + T2 * (J1 / 16)) * 512 * sizeof(_Float16);
+}
+
+extern "C" int lipvq_mlp3_pack_f16_f32(const float* W0, const float* W1, const float* W2, void* packed16, int A, int J0,
+                                       int J1, int D, void* stream) {
+    if (!W0 || !W1 || !W2 || !packed16) return fail(LIPVQ_EINVAL, "mlp3_pack_f16: null pointer");
+    const size_t bytes = lipvq_mlp3_packed_f16_bytes(A, J0, J1, D);
+    if (!bytes) return fail(LIPVQ_EUNSUPPORTED, "mlp3_pack_f16: unsupported shape A=%d J0=%d J1=%d D=%d", A, J0, J1, D);
+    const size_t n = bytes / sizeof(_Float16);
+    hipLaunchKernelGGL(mlp3_pack_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W0, W1, W2,
+                       (_Float16*)packed16, A, J0, J1, D);
+    return check_launch("mlp3_pack_f16");
 }
 
 extern "C" int lipvq_tokenize_supported(int A, int J0, int J1, int D, int K) {
@@ -388,9 +509,9 @@ extern "C" size_t lipvq_tokenize_workspace_bytes(int64_t N, int D) {
 // lipvq_nearest_prepare_f32 of the codebook; workspace: lipvq_tokenize_workspace_bytes(N, D).
 // Outputs exactly as lipvq_mlp3_f32 + lipvq_nearest_f32(LIPVQ_DIST_NORM): idx, zq (may be NULL),
 // usage (may be NULL, accumulated), ze_out (may be NULL).  workspace[0] (int) = rows decided by the exact kernel.
-extern "C" int lipvq_tokenize_f32(const float* x, const float* packed, const float* const* raw6, const float* codebook,
-                                  const void* prep, int64_t* idx, float* zq, int64_t* usage, float* ze_out,
-                                  void* workspace, int64_t N, int A, int J0, int J1, int D, int K, void* stream) {
+static int tokenize_impl(const float* x, const float* packed, const void* packed16, const float* const* raw6,
+                         const float* codebook, const void* prep, int64_t* idx, float* zq, int64_t* usage, float* ze_out,
+                         void* workspace, int64_t N, int A, int J0, int J1, int D, int K, void* stream) {
     if (N < 0) return fail(LIPVQ_EINVAL, "tokenize: N < 0");
     if (N == 0) return LIPVQ_OK;
     if (!x || !packed || !raw6 || !codebook || !prep || !idx || !workspace) return fail(LIPVQ_EINVAL, "tokenize: null pointer");
@@ -399,8 +520,8 @@ extern "C" int lipvq_tokenize_f32(const float* x, const float* packed, const flo
     if (!lipvq_tokenize_supported(A, J0, J1, D, K))
         return fail(LIPVQ_EUNSUPPORTED, "tokenize: unsupported shape A=%d J0=%d J1=%d D=%d K=%d", A, J0, J1, D, K);
     if (N > 2147483647LL) return fail(LIPVQ_EUNSUPPORTED, "tokenize: N too large");
-    if ((((uintptr_t)codebook | (uintptr_t)zq | (uintptr_t)ze_out | (uintptr_t)workspace) & 15) != 0)
-        return fail(LIPVQ_EINVAL, "tokenize: codebook, zq, ze_out and workspace must be 16-byte aligned");
+    if ((((uintptr_t)codebook | (uintptr_t)zq | (uintptr_t)ze_out | (uintptr_t)workspace | (uintptr_t)packed16) & 15) != 0)
+        return fail(LIPVQ_EINVAL, "tokenize: codebook, zq, ze_out, workspace and packed16 must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     unsigned char* ws = (unsigned char*)workspace;
     int* amb_count = (int*)ws;
@@ -410,16 +531,40 @@ extern "C" int lipvq_tokenize_f32(const float* x, const float* packed, const flo
     float* ze_buf = ze_out;
     hipError_t e = hipMemsetAsync(amb_count, 0, 64, st);
     if (e != hipSuccess) return fail(LIPVQ_EHIP, "tokenize: %s", hipGetErrorString(e));
-    TokArgs a{x, packed, (const unsigned char*)prep, codebook, idx, zq, (unsigned long long*)usage, ze_buf,
-              amb_count, amb_list, N, A, D, K, LIPVQ_SCREEN_GAMMA};
+    TokArgs a{x, packed, (const unsigned char*)packed16, (const unsigned char*)prep, codebook, idx, zq,
+              (unsigned long long*)usage, ze_buf, amb_count, amb_list, N, A, D, K, LIPVQ_SCREEN_GAMMA};
     int rc;
-    switch (D) {
-        case 32: rc = launch_tokenize<2>(a, st); break;
-        case 64: rc = launch_tokenize<4>(a, st); break;
-        default: rc = launch_tokenize<8>(a, st); break;
+    if (packed16) {
+        switch (D) {
+            case 32: rc = launch_tokenize<2, true>(a, st); break;
+            case 64: rc = launch_tokenize<4, true>(a, st); break;
+            default: rc = launch_tokenize<8, true>(a, st); break;
+        }
+    } else {
+        switch (D) {
+            case 32: rc = launch_tokenize<2, false>(a, st); break;
+            case 64: rc = launch_tokenize<4, false>(a, st); break;
+            default: rc = launch_tokenize<8, false>(a, st); break;
+        }
     }
     if (rc) return rc;
     // uncertified rows (count on the device): exact decision, from the stored z_e rows or from x
     if (ze_out) return lipvq_launch_rows(ze_out, 0, codebook, idx, zq, usage, amb_list, amb_count, N, K, D, st);
     return lipvq_launch_rows_encode(x, raw6, A, codebook, idx, zq, usage, amb_list, amb_count, N, K, D, st);
+}
+
+extern "C" int lipvq_tokenize_f32(const float* x, const float* packed, const float* const* raw6, const float* codebook,
+                                  const void* prep, int64_t* idx, float* zq, int64_t* usage, float* ze_out,
+                                  void* workspace, int64_t N, int A, int J0, int J1, int D, int K, void* stream) {
+    return tokenize_impl(x, packed, nullptr, raw6, codebook, prep, idx, zq, usage, ze_out, workspace, N, A, J0, J1, D, K, stream);
+}
+
+// Fast mode: the encoder's GEMMs on fp16 MFMAs (packed16 = lipvq_mlp3_pack_f16_f32 of the same weights; `packed` still
+// supplies the fp32 biases).  Not bit-identical to lipvq_tokenize_f32: see tokenize_kernel.  Rows the screen cannot
+// certify are decided by the exact kernel from the fp32 encoder (they get the parity-mode answer).
+extern "C" int lipvq_tokenize_fast_f32(const float* x, const float* packed, const void* packed16, const float* const* raw6,
+                                       const float* codebook, const void* prep, int64_t* idx, float* zq, int64_t* usage,
+                                       void* workspace, int64_t N, int A, int J0, int J1, int D, int K, void* stream) {
+    if (!packed16) return fail(LIPVQ_EINVAL, "tokenize_fast: packed16 is null");
+    return tokenize_impl(x, packed, packed16, raw6, codebook, prep, idx, zq, usage, nullptr, workspace, N, A, J0, J1, D, K, stream);
 }

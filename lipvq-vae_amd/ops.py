@@ -341,8 +341,22 @@ def tokenize_workspace(N: int, D: int, device) -> torch.Tensor:
     return torch.empty(max(16, (lib.lipvq_tokenize_workspace_bytes(N, D) + 3) // 4), device=device, dtype=torch.int32)
 
 
+def mlp3_pack_f16(W0, W1, W2):
+    """fp16 MFMA fragments of an encoder stack for the fast tokenize mode (uint8 buffer)."""
+    W0, W1, W2 = _chk(W0, "W0"), _chk(W1, "W1"), _chk(W2, "W2")
+    A, J0, J1, D = W0.shape[1], W0.shape[0], W1.shape[0], W2.shape[0]
+    nbytes = lib.lipvq_mlp3_packed_f16_bytes(A, J0, J1, D)
+    if not nbytes or W1.shape[1] != J0 or W2.shape[1] != J1:
+        raise ValueError("mlp3_pack_f16: unsupported stack shape")
+    buf = torch.empty(nbytes, device=W0.device, dtype=torch.uint8)
+    with _on(W0.device):
+        check(lib.lipvq_mlp3_pack_f16_f32(_ptr(W0), _ptr(W1), _ptr(W2), _ptr(buf), A, J0, J1, D, _stream()),
+              "lipvq_mlp3_pack_f16_f32")
+    return buf
+
+
 def tokenize(x, packed: PackedMlp3, raw, codebook, prep: PreparedCodebook, usage=None, want_zq=True, want_ze=False,
-             workspace=None):
+             workspace=None, packed16=None):
     """(idx, zq, ze, workspace) of the fused encode + quantize launch (lipvq_tokenize_f32).  raw = the encoder's six
     unpacked tensors (W0, b0, W1, b1, W2 normalised, b2): the exact kernel re-encodes uncertified rows with them."""
     raw = tuple(_chk(t, f"raw[{i}]") for i, t in enumerate(raw))
@@ -360,9 +374,16 @@ def tokenize(x, packed: PackedMlp3, raw, codebook, prep: PreparedCodebook, usage
     ze = torch.empty((N, D), device=dev, dtype=torch.float32) if want_ze else None
     ws = workspace if workspace is not None else tokenize_workspace(N, D, dev)
     with _on(dev):
-        check(lib.lipvq_tokenize_f32(_ptr(x), _ptr(packed.buf), raw_arr, _ptr(codebook), _ptr(prep.buf), _ptr(idx), _ptr(zq),
-                                     _ptr(usage), _ptr(ze), _ptr(ws), N, A, packed.J0, packed.J1, D, K, _stream()),
-              "lipvq_tokenize_f32")
+        if packed16 is not None:            # fast mode (fp16 encoder GEMMs): not bit-identical, see include/lipvq.h
+            if want_ze:
+                raise ValueError("tokenize: the fast mode does not return z_e")
+            check(lib.lipvq_tokenize_fast_f32(_ptr(x), _ptr(packed.buf), _ptr(packed16), raw_arr, _ptr(codebook), _ptr(prep.buf),
+                                              _ptr(idx), _ptr(zq), _ptr(usage), _ptr(ws), N, A, packed.J0, packed.J1, D, K,
+                                              _stream()), "lipvq_tokenize_fast_f32")
+        else:
+            check(lib.lipvq_tokenize_f32(_ptr(x), _ptr(packed.buf), raw_arr, _ptr(codebook), _ptr(prep.buf), _ptr(idx), _ptr(zq),
+                                         _ptr(usage), _ptr(ze), _ptr(ws), N, A, packed.J0, packed.J1, D, K, _stream()),
+                  "lipvq_tokenize_f32")
     return idx, zq, ze, ws
 
 

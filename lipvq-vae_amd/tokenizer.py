@@ -83,6 +83,7 @@ class _TokenizerBase(nn.Module):
         self._enc_cache = _PackCache()
         self._dec_cache = _PackCache()
         self._cb_cache = _PackCache()
+        self._enc16_cache = _PackCache()
         self.last_exact_rows = None      # int32 device tensor: element 0 = rows the screen could not certify
 
     def reset_usage(self):
@@ -168,8 +169,14 @@ class LLFQVAE_V4(_TokenizerBase):
         return ops.mlp3(self._as_rows(x), packed, (ACT_GELU, ACT_GELU, ACT_SIGMOID))
 
     @torch.no_grad()
-    def tokenize(self, x, count_usage=True):
-        """encode + quantize: (indices[N] int64, z_latent[N,D])   (v5:71-74)."""
+    def tokenize(self, x, count_usage=True, mode="parity"):
+        """encode + quantize: (indices[N] int64, z_latent[N,D])   (v5:71-74).
+
+        mode="parity" (default): fp32 everywhere, indices bit-identical to the CPU oracle / the reference.
+        mode="fast": the encoder's GEMMs on fp16 MFMAs (fp32 accumulation) -- SURVEY section 7's throughput mode; a
+        fraction of a percent of the indices differ from parity mode, always between near-equidistant codes."""
+        if mode not in ("parity", "fast"):
+            raise ValueError(f"unknown tokenize mode {mode!r}")
         x = self._as_rows(x)
         usage = self.code_usage if count_usage else None
         cb = self.quantizer.codebook.detach()
@@ -181,9 +188,15 @@ class LLFQVAE_V4(_TokenizerBase):
             key = (x.shape[0], x.device)
             if getattr(self, "_tok_ws_key", None) != key:        # the scratch (row list + z_e) is reused across calls
                 self._tok_ws, self._tok_ws_key = ops.tokenize_workspace(x.shape[0], self.latent_dim, x.device), key
+            packed16 = None
+            if mode == "fast":
+                packed16 = self._enc16_cache.get((w0, w1, self.to_latent.W, self.to_latent.ci),
+                                                 lambda: ops.mlp3_pack_f16(w0, w1, Wn))
             idx, zq, _, ws = ops.tokenize(x, packed, (w0, b0, w1, b1, Wn, b2), cb, prep, usage=usage,
-                                          workspace=self._tok_ws)
+                                          workspace=self._tok_ws, packed16=packed16)
             self.last_exact_rows = ws
+        elif mode == "fast":
+            raise RuntimeError("tokenize(mode='fast') needs the fused kernel's shapes (hidden 64/128, D in {32, 64, 128})")
         else:
             idx, zq = self._quantize(self.encode(x), usage)
         self.last_indices = idx
