@@ -175,7 +175,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
         auto finish_tile = [&](const int t, f32x16& acc) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float zv = FUSED_SIGMOID(acc[r]);
+                // fast mode: hardware exp2 / rcp (1 ulp each) instead of the canonical exp polynomial + IEEE division
+                const float zv = FAST ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[r] * -1.44269504088896341f))
+                                      : FUSED_SIGMOID(acc[r]);
                 acc[r] = zv;
                 const float v = zv - w_mu[32 * t + 2 * r + h];
                 zc[t][r] = v;
