@@ -97,8 +97,15 @@ def cpu_baseline(model, x_dev, idx_dev, budget_s=12.0):
             da = torch.norm(ze - cb[idx_cpu[bad]], dim=-1)
             db = torch.norm(ze - cb[idx_gpu[bad]], dim=-1)
             worst_gap = float(((db - da).abs() / torch.maximum(da, db)).max())
+    # what the reference's train() actually sets (scripts/train.py:57): one thread, on a ~3 s slice
+    torch.set_num_threads(1)
+    n1 = int(max(chunk, min(n, (rate0 / max(1, threads) * 3.0) // chunk * chunk)))
+    t = time.perf_counter()
+    O.torch_llfq_tokenize(p, x[:n1], chunk=chunk)
+    rate_1t = n1 / (time.perf_counter() - t)
+    torch.set_num_threads(threads)
     return {
-        "value": n / dt, "unit": "actions/s", "cores": threads, "kind": "port",
+        "value": n / dt, "unit": "actions/s", "cores": threads, "kind": "port", "value_1_thread": rate_1t,
         "sample": f"first {n} rows of the same batch, torch-CPU restatement, {chunk}-row chunks, {dt:.1f} s",
         "host_cpus": os.cpu_count(), "index_mismatches_vs_gpu": mism, "rows_compared": n,
         "max_rel_distance_gap_of_mismatches": worst_gap,
@@ -256,6 +263,41 @@ def main():
                             "dtype": "f16 encoder operands, f32 accumulation, f32 quantizer",
                             "index_flip_rate_vs_parity": float((idx_fast != idx_parity).float().mean().item()),
                             "note": "opt-in (tokenize(mode='fast')); not bit-identical, hence not the reported value"}
+    if world == 1:
+        # "report also full fwd (+decode+loss) and fwd+bwd+AdamW step" -- same batch, a few steps each,
+        # beside the metric (never `value`)
+        def timed_ms(fn, n):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record()
+            for _ in range(n):
+                fn()
+            a1.record()
+            torch.cuda.synchronize()
+            return a0.elapsed_time(a1) / n
+
+        def full_forward():
+            with torch.no_grad():
+                model(x)
+
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)       # icl.py:885-889
+
+        def train_step():
+            opt.zero_grad()
+            _, loss = model(x)
+            loss.backward()
+            opt.step()
+
+        saved = {k: v.clone() for k, v in model.state_dict().items()}
+        ff_ms = timed_ms(full_forward, 5)
+        ts_ms = timed_ms(train_step, 5)
+        model.load_state_dict(saved)                 # the cpu_baseline below compares against the untrained parameters
+        out["also"] = {"full_forward": {"value": N / (ff_ms * 1e-3), "unit": "actions/s", "ms_per_step": ff_ms,
+                                        "what": "forward(x) without autograd: encode + quantize + decode + three losses"},
+                       "train_step": {"value": N / (ts_ms * 1e-3), "unit": "actions/s", "ms_per_step": ts_ms,
+                                      "what": "zero_grad + forward + loss.backward() + AdamW.step() (icl.py:913-914, 968-970)"}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, x, idx)
         out["gpu_vs_cpu"] = value / out["cpu_baseline"]["value"]
