@@ -7,11 +7,21 @@
 //   lipschitz_bwd_kernel  backward of normalization() (v5:6-12)
 //   scaled_diff_kernel    out = alpha * g * (a - b) + c   (the d mse / d input terms)
 // ABI: include/lipvq.h.
+#include <stdlib.h>
+
 #include "lipvq_common.h"
 
 // rows per chunk: enough chunks that the (chunk x tile) grid fills the chip even for training-step batches -- with one
 // 2048-row chunk a 1024-row batch was ONE dependent chain of 512 load+MFMA steps per wave (248 us per call).
-static inline int wgrad_chunk_rows(int64_t N) { return N >= 262144 ? 2048 : (N >= 16384 ? 512 : 64); }
+static inline int wgrad_chunk_rows(int64_t N) {
+    static int forced = -1;                      // LIPVQ_WGRAD_CHUNK: measurement knob
+    if (forced < 0) {
+        const char* e = getenv("LIPVQ_WGRAD_CHUNK");
+        forced = e ? atoi(e) : 0;
+    }
+    if (forced > 0) return forced;
+    return N >= 262144 ? 1024 : (N >= 16384 ? 256 : 64);
+}
 
 // One wave = one 32x32 tile of gW over one chunk of rows.
 //   A operand: lane (i = lane & 31, kh = lane >> 5) = G[row0 + 2s + kh][32 ti + i]
@@ -77,13 +87,123 @@ __global__ __launch_bounds__(64) void wgrad_kernel(const float* __restrict__ G, 
     }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nchunks,
-                                    size_t n_elem) {
-    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_elem) return;
+// Workgroup-per-chunk variant (what lipvq_wgrad_f32 launches when the row tile fits LDS): the per-tile kernel above lets
+// every wave stream 128-byte pieces of 512-byte rows (each G element is fetched by TJ waves, each H element by TI), which
+// at N = 524 288 ran 620-740 us per call (12 TFLOP/s, ~1.7 TB/s of partial-row HBM reads).  Here the 8 waves of a
+// workgroup own ALL 32x32 tiles of gW for one chunk of rows: 32 rows of G and act(H) at a time are staged into LDS with
+// whole-row coalesced loads (activation and the hidx gather applied once per element), every wave then feeds its
+// tiles' MFMAs from LDS.  Same chunk-ordered accumulation per tile as above.
+#define WGW_WAVES 8
+#define WGW_MAXT 4            // tiles per wave: TI * TJ <= 32
+
+template <int CG, int TPW>        // column groups of 64 lanes covering max(Jp, Kp); 32x32 tiles per wave
+__global__ __launch_bounds__(64 * WGW_WAVES) void wgrad_wg_kernel(const float* __restrict__ G, const float* __restrict__ H,
+                                                                  const int64_t* __restrict__ hidx, int h_act,
+                                                                  float* __restrict__ partW, float* __restrict__ partB,
+                                                                  int64_t N, int J, int Kd, int TI, int TJ, int chunk_rows) {
+    extern __shared__ float wg_lds[];
+    const int Jp = 32 * TI, Kp = 32 * TJ;
+    float* Gs = wg_lds;                   // [32][Jp]
+    float* Hs = Gs + 32 * Jp;             // [32][Kp]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int T = TI * TJ;
+    const int64_t r0 = (int64_t)blockIdx.x * chunk_rows;
+    int64_t r1 = r0 + chunk_rows;
+    if (r1 > N) r1 = N;
+    f32x16 acc[TPW];
+    float bsum[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        bsum[q] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+    }
+    // staging map: wave w fetches rows 4w .. 4w+3 of the 32-row block, lanes along the columns (whole-row coalesced);
+    // the next block's loads are in flight (registers) while the current block is multiplied
+    float gq[4][CG], hq[4][CG];
+    auto fetch = [&](int64_t rb) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int64_t row = rb + 4 * wave + rr;
+            const bool in = row < r1;
+            int64_t hr = row;
+            if (in && hidx) hr = hidx[row];
+#pragma unroll
+            for (int cg = 0; cg < CG; ++cg) {
+                const int c = lane + 64 * cg;
+                gq[rr][cg] = (in && c < J) ? G[(size_t)row * J + c] : 0.0f;
+                hq[rr][cg] = (in && c < Kd) ? H[(size_t)hr * Kd + c] : 0.0f;
+            }
+        }
+    };
+    fetch(r0);
+    for (int64_t rb = r0; rb < r1; rb += 32) {
+        __syncthreads();                                   // the previous block's operands have been consumed
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int cg = 0; cg < CG; ++cg) {
+                const int c = lane + 64 * cg;
+                if (c < Jp) Gs[(4 * wave + rr) * Jp + c] = gq[rr][cg];
+                if (c < Kp) Hs[(4 * wave + rr) * Kp + c] = (c < Kd) ? lq_act_apply(hq[rr][cg], h_act) : 0.0f;
+            }
+        __syncthreads();
+        if (rb + 32 < r1) fetch(rb + 32);
+        const int steps = (r1 - rb >= 32) ? 16 : (int)((r1 - rb + 1) >> 1);
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) {
+            const int t = wave + q * WGW_WAVES;
+            if (t < T) {                                   // wave-uniform
+                const int ti = t / TJ, tj = t - ti * TJ;
+                const float* ga = Gs + kh * Jp + 32 * ti + li;
+                const float* hb = Hs + kh * Kp + 32 * tj + li;
+                for (int s2 = 0; s2 < steps; ++s2) {
+                    const float av = ga[2 * s2 * Jp];
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, hb[2 * s2 * Kp], acc[q], 0, 0, 0);
+                    bsum[q] += av;
+                }
+            }
+        }
+    }
+    float* pw = partW + (size_t)blockIdx.x * J * Kd;
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int t = wave + q * WGW_WAVES;
+        if (t >= T) continue;
+        const int ti = t / TJ, tj = t - ti * TJ;
+        const int fj = 32 * tj + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int oi = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (oi < J && fj < Kd) pw[(size_t)oi * Kd + fj] = acc[q][r];
+        }
+        if (tj == 0) {
+            const float tot = bsum[q] + __shfl_xor(bsum[q], 32, 64);
+            const int fi = 32 * ti + li;
+            if (kh == 0 && fi < J) partB[(size_t)blockIdx.x * J + fi] = tot;
+        }
+    }
+}
+
+// out[e] = sum over chunks of part[c][e]: 32 elements x 8 chunk groups per block (group g sums chunks g, g+8, ... in
+// double), the 8 group sums are combined in a fixed order: deterministic.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nchunks,
+                                                           size_t n_elem) {
+    __shared__ double sh[8][32];
+    const int le = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const size_t e = (size_t)blockIdx.x * 32 + le;
     double s = 0.0;
-    for (int c = 0; c < nchunks; ++c) s += (double)part[(size_t)c * n_elem + e];
-    out[e] = (float)s;
+    if (e < n_elem)
+        for (int c = g; c < nchunks; c += 8) s += (double)part[(size_t)c * n_elem + e];
+    sh[g][le] = s;
+    __syncthreads();
+    if (g == 0 && e < n_elem) {
+        double t = sh[0][le];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) t += sh[q][le];
+        out[e] = (float)t;
+    }
 }
 
 static inline int wgrad_chunks(int64_t N) { const int c = wgrad_chunk_rows(N); return (int)((N + c - 1) / c); }
@@ -104,12 +224,27 @@ extern "C" int lipvq_wgrad_f32(const float* G, const float* H, const int64_t* hi
     const int TI = (J + 31) / 32, TJ = (Kd + 31) / 32;
     float* partW = (float*)workspace;
     float* partB = partW + (size_t)nch * J * Kd;
-    hipLaunchKernelGGL(wgrad_kernel, dim3(nch, TI * TJ), dim3(64), 0, st, G, H, hidx, h_act, partW, partB, N, J, Kd, TJ,
-                       wgrad_chunk_rows(N));
+    const size_t lds = (size_t)32 * 32 * (TI + TJ) * sizeof(float);
+    static int use_wg = -1;                     // LIPVQ_WGRAD_PER_TILE=1 forces the one-wave-per-tile kernel (measurement knob)
+    if (use_wg < 0) use_wg = getenv("LIPVQ_WGRAD_PER_TILE") ? 0 : 1;
+    if (use_wg && TI * TJ <= WGW_WAVES * WGW_MAXT && TI <= 8 && TJ <= 8 && lds <= 64 * 1024) {
+        const int wide = 32 * (TI > TJ ? TI : TJ);
+        const int tpw = (TI * TJ + WGW_WAVES - 1) / WGW_WAVES;
+        typedef void (*wg_fn)(const float*, const float*, const int64_t*, int, float*, float*, int64_t, int, int, int, int, int);
+        wg_fn kfn;
+#define LQ_WG(cg_) (tpw <= 1 ? (wg_fn)wgrad_wg_kernel<cg_, 1> : tpw <= 2 ? (wg_fn)wgrad_wg_kernel<cg_, 2> : (wg_fn)wgrad_wg_kernel<cg_, 4>)
+        kfn = wide <= 64 ? LQ_WG(1) : (wide <= 128 ? LQ_WG(2) : LQ_WG(4));
+#undef LQ_WG
+        hipLaunchKernelGGL(kfn, dim3(nch), dim3(64 * WGW_WAVES), lds, st, G, H, hidx, h_act, partW, partB, N, J, Kd, TI, TJ,
+                           wgrad_chunk_rows(N));
+    } else {
+        hipLaunchKernelGGL(wgrad_kernel, dim3(nch, TI * TJ), dim3(64), 0, st, G, H, hidx, h_act, partW, partB, N, J, Kd, TJ,
+                           wgrad_chunk_rows(N));
+    }
     size_t ne = (size_t)J * Kd;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, partW, gW, nch, ne);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((ne + 31) / 32)), dim3(256), 0, st, partW, gW, nch, ne);
     if (gb)
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((J + 255) / 256)), dim3(256), 0, st, partB, gb, nch, (size_t)J);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((J + 31) / 32)), dim3(256), 0, st, partB, gb, nch, (size_t)J);
     return check_launch("wgrad");
 }
 

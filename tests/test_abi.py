@@ -40,9 +40,9 @@ def test_ctypes_table_matches_header():
     # pure host-side entry points are callable without a GPU
     assert _capi.lib.lipvq_mlp3_packed_floats(7, 64, 128, 64) == (2 * 4 * 64 + 64) + (4 * 32 * 64 + 128) + (2 * 64 * 64 + 64)
     assert _capi.lib.lipvq_mse_workspace_bytes() > 0
-    # one partial slab per chunk of rows: 64-row chunks below 16 384 rows, 2048-row chunks from 262 144 rows on
+    # one partial slab per chunk of rows: 64-row chunks below 16 384 rows, 1024-row chunks from 262 144 rows on
     assert _capi.lib.lipvq_wgrad_workspace_bytes(5000, 128, 64) == 79 * (128 * 64 + 128) * 4
-    assert _capi.lib.lipvq_wgrad_workspace_bytes(300000, 128, 64) == 147 * (128 * 64 + 128) * 4
+    assert _capi.lib.lipvq_wgrad_workspace_bytes(300000, 128, 64) == 293 * (128 * 64 + 128) * 4
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
