@@ -431,13 +431,13 @@ extern "C" int lipvq_mlp3_f32(const float* x, const int64_t* gather_idx, const f
     if (!x || !packed || !y) return fail(LIPVQ_EINVAL, "mlp3: null pointer");
     if (K0 <= 0 || J2 <= 0) return fail(LIPVQ_EINVAL, "mlp3: bad sizes");
     if (int e = check_hidden("mlp3", J0, J1)) return e;
-    mlp3_fn fn = mlp3_select<false>(J0 / 32, J1 / 32);
-    if (!fn) return fail(LIPVQ_EUNSUPPORTED, "mlp3: no kernel instance for hidden widths %d,%d", J0, J1);
     Mlp3Args a{x, gather_idx, packed, y, pre0, pre1, pre2, nullptr, nullptr, nullptr,
                N, K0, J0, J1, J2, act0, act1, act2, LIPVQ_ACT_NONE};
     bool done;
     if (int e = launch_mlp3_wg<false>(a, (hipStream_t)stream, "mlp3_wg", &done)) return e;
     if (done) return LIPVQ_OK;
+    mlp3_fn fn = mlp3_select<false>(J0 / 32, J1 / 32);       // fallback (input tile wider than LDS): instantiated widths only
+    if (!fn) return fail(LIPVQ_EUNSUPPORTED, "mlp3: no kernel instance for hidden widths %d,%d with K0=%d", J0, J1, K0);
     return launch_mlp3(fn, a, (hipStream_t)stream, "mlp3");
 }
 
@@ -451,12 +451,12 @@ extern "C" int lipvq_mlp3_bwd_f32(const float* gy, const float* pre0, const floa
     if (act2 != LIPVQ_ACT_NONE && !pre2) return fail(LIPVQ_EINVAL, "mlp3_bwd: pre2 required when act2 is not the identity");
     if (K0 <= 0 || J2 <= 0) return fail(LIPVQ_EINVAL, "mlp3_bwd: bad sizes");
     if (int e = check_hidden("mlp3_bwd", J0, J1)) return e;
-    mlp3_fn fn = mlp3_select<true>(J1 / 32, J0 / 32);
-    if (!fn) return fail(LIPVQ_EUNSUPPORTED, "mlp3_bwd: no kernel instance for hidden widths %d,%d", J0, J1);
     Mlp3Args a{gy, nullptr, packed_bwd, gx, g1, g0, g2, (act2 != LIPVQ_ACT_NONE) ? pre2 : nullptr, pre1, pre0,
                N, J2, J1, J0, K0, act1, act0, LIPVQ_ACT_NONE, act2};
     bool done;
     if (int e = launch_mlp3_wg<true>(a, (hipStream_t)stream, "mlp3_wg_bwd", &done)) return e;
     if (done) return LIPVQ_OK;
+    mlp3_fn fn = mlp3_select<true>(J1 / 32, J0 / 32);
+    if (!fn) return fail(LIPVQ_EUNSUPPORTED, "mlp3_bwd: no kernel instance for hidden widths %d,%d with J2=%d", J0, J1, J2);
     return launch_mlp3(fn, a, (hipStream_t)stream, "mlp3_bwd");
 }

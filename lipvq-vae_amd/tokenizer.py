@@ -109,8 +109,8 @@ class _TokenizerBase(nn.Module):
 class LLFQVAE_V4(_TokenizerBase):
     def __init__(self, feature_dim, latent_dim, num_codes=1024, hidden_dim=128):
         super().__init__()
-        if hidden_dim % 32 or not (32 <= hidden_dim <= 96 or hidden_dim == 128):
-            raise ValueError("hidden_dim must be 32, 64, 96 or 128 on the MI355X path")
+        if hidden_dim % 32 or not (32 <= hidden_dim <= 256):
+            raise ValueError("hidden_dim must be a multiple of 32 in [32, 256] on the MI355X path (MFMA tiles of 32)")
         # construction order = the reference's (v5:54-68), so RNG draws line up
         self.encoder = nn.Sequential(nn.Linear(feature_dim, 64), nn.GELU(), nn.Linear(64, hidden_dim), nn.GELU())
         self.to_latent = LipschitzMLP(hidden_dim, latent_dim)

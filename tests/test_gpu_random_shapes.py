@@ -1,0 +1,83 @@
+"""GPU: seeded random shape sweep of the newer kernels against the canonical oracle (bit-exact) -- ragged rows, odd fan-ins,
+non-multiple-of-32 widths, tiny and mid-size batches; complements the hand-picked cases of the per-kernel test files."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lipvq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _cuda(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_linear_and_mlp3_random_shapes(oracle, seed):
+    from lipvq_vae_amd import ops
+    rng = np.random.default_rng(1000 + seed)
+    N = int(rng.choice([1, 2, 31, 33, 100, 777, 4099, 20011]))
+    K0 = int(rng.integers(1, 70))
+    J0, J1 = int(rng.choice([32, 64, 96, 128])), int(rng.choice([32, 64, 96, 128]))
+    J2 = int(rng.integers(1, 230))
+    x = rng.standard_normal((N, K0)).astype(np.float32)
+    Ws = [(rng.standard_normal((J0, K0)) / np.sqrt(K0)).astype(np.float32), rng.standard_normal(J0).astype(np.float32),
+          (rng.standard_normal((J1, J0)) / np.sqrt(J0)).astype(np.float32), rng.standard_normal(J1).astype(np.float32),
+          (rng.standard_normal((J2, J1)) / np.sqrt(J1)).astype(np.float32), rng.standard_normal(J2).astype(np.float32)]
+    acts = tuple(int(a) for a in rng.choice([O.ACT_NONE, O.ACT_GELU, O.ACT_SIGMOID, O.ACT_RELU], 3))
+    y_ref, pre_ref = oracle.mlp3(x, *Ws, acts, save_pre=True)
+    y, pre = ops.mlp3(_cuda(x), ops.mlp3_pack(*[_cuda(w) for w in Ws]), acts, save_pre=True)
+    assert np.array_equal(y.cpu().numpy(), y_ref)
+    for a, b in zip(pre, pre_ref):
+        assert np.array_equal(a.cpu().numpy(), b)
+    # the single Linear with an activation epilogue, same data
+    act = int(rng.choice([O.ACT_NONE, O.ACT_GELU]))
+    l_ref = oracle.linear_act(x, Ws[0], Ws[1], act)
+    assert np.array_equal(ops.linear(_cuda(x), _cuda(Ws[0]), _cuda(Ws[1]), act=act).cpu().numpy(), l_ref)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_embed_rows_random_shapes(oracle, seed):
+    from lipvq_vae_amd import ops
+    rng = np.random.default_rng(2000 + seed)
+    B, T = int(rng.integers(1, 40)), int(rng.integers(1, 23))
+    E = 4 * int(rng.integers(1, 257))
+    K = int(rng.integers(1, 300))
+    S = int(rng.integers(1, 4))                      # streams sharing the output rows
+    slot = int(rng.integers(0, S))
+    table = rng.standard_normal((K, E)).astype(np.float32)
+    pos = rng.standard_normal((T, E)).astype(np.float32) if rng.random() < 0.8 else None
+    w, b = rng.standard_normal(E).astype(np.float32), rng.standard_normal(E).astype(np.float32)
+    idx = rng.integers(0, K, B * T).astype(np.int64)
+    N = B * T - (int(rng.integers(0, T)) if B > 1 and rng.random() < 0.3 else 0)      # sometimes a ragged last batch entry
+    ref = np.full((B, S * T, E), 3.0, np.float32)
+    st_ref = oracle.embed_rows(table, idx[:N], pos, w, b, 1e-5, ref, T, S * T * E, S * E, slot * E, N=N, want_stats=True)
+    out = torch.full((B, S * T, E), 3.0, device="cuda")
+    st = ops.embed_rows(_cuda(table), _cuda(idx[:N]), None if pos is None else _cuda(pos), _cuda(w), _cuda(b), 1e-5, out, N, T,
+                        S * T * E, S * E, slot * E, want_stats=True)
+    assert np.array_equal(out.cpu().numpy(), ref)
+    assert np.array_equal(st.cpu().numpy(), st_ref)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_bin_kernels_random_shapes(oracle, seed):
+    from lipvq_vae_amd import ops
+    rng = np.random.default_rng(3000 + seed)
+    N, A = int(rng.choice([1, 5, 64, 1000, 9001])), int(rng.integers(1, 16))
+    nb, D = int(rng.integers(1, 40)), int(rng.integers(1, 220))
+    bp = O.make_bin_params(seed, A, D, nb)
+    x = (rng.standard_normal((N, A)) * rng.uniform(0.1, 5)).astype(np.float32)
+    if N > 4:
+        x[:, 0] = x[0, 0]                            # a constant column: degenerate boundaries
+    rmin, rmax = oracle.bin_minmax(x[: max(1, N // 2)], np.full(A, np.inf, np.float32), np.full(A, -np.inf, np.float32))
+    tmin, tmax = _cuda(np.full(A, np.inf, np.float32)), _cuda(np.full(A, -np.inf, np.float32))
+    ops.bin_minmax(_cuda(x[: max(1, N // 2)]), tmin, tmax)
+    assert np.array_equal(tmin.cpu().numpy(), rmin) and np.array_equal(tmax.cpu().numpy(), rmax)
+    bins = ops.bin_discretize(_cuda(x), tmin, tmax, nb)
+    bins_ref = oracle.bin_discretize(x, rmin, rmax, nb)
+    assert np.array_equal(bins.cpu().numpy(), bins_ref)
+    P_ref = oracle.bin_table(bp)
+    h_ref = oracle.bin_hidden(bins_ref, P_ref, bp["output_layer.0.bias"])
+    h = ops.bin_hidden(bins, _cuda(P_ref), _cuda(bp["output_layer.0.bias"]))
+    assert np.array_equal(h.cpu().numpy(), h_ref)
