@@ -81,3 +81,45 @@ def test_bin_kernels_random_shapes(oracle, seed):
     h_ref = oracle.bin_hidden(bins_ref, P_ref, bp["output_layer.0.bias"])
     h = ops.bin_hidden(bins, _cuda(P_ref), _cuda(bp["output_layer.0.bias"]))
     assert np.array_equal(h.cpu().numpy(), h_ref)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_tokenize_random_shapes(oracle, seed):
+    """Fused tokenize (parity mode) and the screened quantizer against the oracle on random N / A / D / K / input scales."""
+    from lipvq_vae_amd.tokenizer import LLFQVAE_V4
+    rng = np.random.default_rng(4000 + seed)
+    N = int(rng.choice([1, 31, 257, 2049, 5000, 30011]))
+    A, D = int(rng.integers(1, 17)), int(rng.choice([32, 64, 128]))
+    K = int(rng.integers(2, 3000))
+    p = O.make_params(seed, A, D, K, oracle=oracle)
+    model = LLFQVAE_V4(A, D, num_codes=K).cuda()
+    model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in p.items()})
+    x = (O.make_inputs(seed, N, A) * rng.choice([0.01, 1.0, 30.0])).astype(np.float32)
+    ze_ref = oracle.llfq_encode(p, x)
+    idx_ref, zq_ref, usage_ref = oracle.nearest(ze_ref, p["quantizer.codebook"])
+    model.code_usage.zero_()
+    idx, zq = model.tokenize(_cuda(x))
+    assert np.array_equal(idx.cpu().numpy(), idx_ref) and np.array_equal(zq.cpu().numpy(), zq_ref)
+    assert np.array_equal(model.code_usage.cpu().numpy(), usage_ref)
+    idx2, _ = model._quantize(model.encode(_cuda(x)), None)            # unfused: mlp3_wg + exact rows / screen
+    assert np.array_equal(idx2.cpu().numpy(), idx_ref)
+
+
+@pytest.mark.parametrize("hidden,N", [(256, 300), (32, 77), (192, 1000)])
+def test_module_other_hidden_widths(oracle, hidden, N):
+    """hidden_dim beyond the reference default: forward values and parameter gradients against the oracle."""
+    from lipvq_vae_amd.tokenizer import LLFQVAE_V4
+    A, D, K = 9, 48, 200
+    p = O.make_params(hidden, A, D, K, hidden=hidden, oracle=oracle)
+    model = LLFQVAE_V4(A, D, num_codes=K, hidden_dim=hidden).cuda()
+    model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in p.items()})
+    x = O.make_inputs(N, N, A)
+    f = oracle.llfq_forward(p, x)
+    z, loss = model(_cuda(x))
+    assert np.array_equal(z.detach().cpu().numpy(), f["z_q"]) and np.array_equal(model.last_indices.cpu().numpy(), f["indices"])
+    assert abs(loss.item() - f["loss"]) <= 1e-5 * abs(f["loss"])
+    loss.backward()
+    g = oracle.llfq_grads(p, x, fwd=f)
+    for k, prm in model.named_parameters():
+        scale = np.abs(g[k]).max() + 1e-12
+        assert np.abs(prm.grad.cpu().numpy() - g[k]).max() <= 2e-5 * scale, k
