@@ -11,11 +11,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define LIPVQ_SCREEN_GAMMA 3.814697265625e-06f   /* 2^-18 */
 #ifndef SCREEN_WAVES
 #define SCREEN_WAVES 8
-// the same for rows whose z_e was never stored: recomputed from x with the raw (unpacked) encoder weights
-// raw6 = {W0, b0, W1, b1, W2 (Lipschitz-normalised), b2}
-int lipvq_launch_rows_encode(const float* x, const float* const* raw6, int A, const float* cb, int64_t* idx, float* zq,
-                             int64_t* usage, const int* amb_list, const int* amb_count, int64_t N, int K, int D,
-                             hipStream_t st);
 #endif
 
 struct PrepLayout {
@@ -75,11 +70,6 @@ __device__ __forceinline__ float lq_pow2f(int k) { return __uint_as_float((unsig
 constexpr int screen_default_tc(int S) { return (S <= 4) ? LQ_OPT_TC : (S <= 8) ? 2 : 1; }
 #else
 constexpr int screen_default_tc(int S) { return (S <= 2) ? 8 : (S <= 4) ? 4 : (S <= 8) ? 2 : 1; }
-// the same for rows whose z_e was never stored: recomputed from x with the raw (unpacked) encoder weights
-// raw6 = {W0, b0, W1, b1, W2 (Lipschitz-normalised), b2}
-int lipvq_launch_rows_encode(const float* x, const float* const* raw6, int A, const float* cb, int64_t* idx, float* zq,
-                             int64_t* usage, const int* amb_list, const int* amb_count, int64_t N, int K, int D,
-                             hipStream_t st);
 #endif
 
 template <int S, int TC_ = screen_default_tc(S)>
@@ -93,11 +83,6 @@ struct ScreenCfg {
 __device__ __forceinline__ void lq_track(const f32x16& acc, int code, float (&m1)[16], float (&m2)[16], int (&k1)[16]) {
 #ifdef LQ_ABL_NOTRACK
     m1[0] = fminf(m1[0], acc[0] + acc[5] + acc[10] + acc[15]); return;   // keeps the MFMAs alive
-// the same for rows whose z_e was never stored: recomputed from x with the raw (unpacked) encoder weights
-// raw6 = {W0, b0, W1, b1, W2 (Lipschitz-normalised), b2}
-int lipvq_launch_rows_encode(const float* x, const float* const* raw6, int A, const float* cb, int64_t* idx, float* zq,
-                             int64_t* usage, const int* amb_list, const int* amb_count, int64_t N, int K, int D,
-                             hipStream_t st);
 #endif
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -121,11 +106,6 @@ __device__ __forceinline__ void lq_screen_core(const f16x8 (&ah)[S], const f16x8
     const int nstage = 0;            // ablation build only (scripts/ablate.sh)
 #else
     const int nstage = ntiles / C::TC;
-// the same for rows whose z_e was never stored: recomputed from x with the raw (unpacked) encoder weights
-// raw6 = {W0, b0, W1, b1, W2 (Lipschitz-normalised), b2}
-int lipvq_launch_rows_encode(const float* x, const float* const* raw6, int A, const float* cb, int64_t* idx, float* zq,
-                             int64_t* usage, const int* amb_list, const int* amb_count, int64_t N, int K, int D,
-                             hipStream_t st);
 #endif
     // Stage copies go global -> LDS directly (global_load_lds_dwordx4: no VGPR round trip, no ds_write
     // issue; ablation: the register-staged copy cost 84 us of a 440 us launch).  One wave-instruction
@@ -150,21 +130,11 @@ int lipvq_launch_rows_encode(const float* x, const float* const* raw6, int A, co
     for (int st = 0; st < nstage; ++st) {
 #ifndef LQ_ABL_NOSTAGE
         if (st + 1 < nstage) stage_dma(st + 1, (st + 1) & 1);     // its last readers passed the previous barrier
-// the same for rows whose z_e was never stored: recomputed from x with the raw (unpacked) encoder weights
-// raw6 = {W0, b0, W1, b1, W2 (Lipschitz-normalised), b2}
-int lipvq_launch_rows_encode(const float* x, const float* const* raw6, int A, const float* cb, int64_t* idx, float* zq,
-                             int64_t* usage, const int* amb_list, const int* amb_count, int64_t N, int K, int D,
-                             hipStream_t st);
 #endif
 #ifdef LQ_ABL_NOSTAGE
         const unsigned char* sb = stage0;
 #else
         const unsigned char* sb = stage0 + (size_t)(st & 1) * C::STAGE_BYTES;
-// the same for rows whose z_e was never stored: recomputed from x with the raw (unpacked) encoder weights
-// raw6 = {W0, b0, W1, b1, W2 (Lipschitz-normalised), b2}
-int lipvq_launch_rows_encode(const float* x, const float* const* raw6, int A, const float* cb, int64_t* idx, float* zq,
-                             int64_t* usage, const int* amb_list, const int* amb_count, int64_t N, int K, int D,
-                             hipStream_t st);
 #endif
 #pragma unroll
         for (int c = 0; c < C::TC; ++c) {
@@ -186,11 +156,6 @@ int lipvq_launch_rows_encode(const float* x, const float* const* raw6, int A, co
         }
 #ifndef LQ_ABL_NOBARRIER
         __syncthreads();
-// the same for rows whose z_e was never stored: recomputed from x with the raw (unpacked) encoder weights
-// raw6 = {W0, b0, W1, b1, W2 (Lipschitz-normalised), b2}
-int lipvq_launch_rows_encode(const float* x, const float* const* raw6, int A, const float* cb, int64_t* idx, float* zq,
-                             int64_t* usage, const int* amb_list, const int* amb_count, int64_t N, int K, int D,
-                             hipStream_t st);
 #endif
     }
 }
@@ -286,11 +251,6 @@ __device__ __forceinline__ bool lq_screen_decide(const float (&m1)[16], const fl
     bool certified = (twoemax < INFINITY) && (second - best > 2.0f * eps * fown) && (bk >= 0) && (bk < K);
 #ifdef LQ_ABL_CERT_ALL
     certified = true; my_k = (my_k >= 0 && my_k < K) ? my_k : (lane * 7) % K;
-// the same for rows whose z_e was never stored: recomputed from x with the raw (unpacked) encoder weights
-// raw6 = {W0, b0, W1, b1, W2 (Lipschitz-normalised), b2}
-int lipvq_launch_rows_encode(const float* x, const float* const* raw6, int A, const float* cb, int64_t* idx, float* zq,
-                             int64_t* usage, const int* amb_list, const int* amb_count, int64_t N, int K, int D,
-                             hipStream_t st);
 #endif
     return certified;
 }
@@ -319,11 +279,6 @@ __device__ __forceinline__ void lq_screen_gather(const float* __restrict__ cb, f
                                                  bool certified, int64_t row0, int64_t N, int D, int lane) {
 #ifdef LQ_ABL_NOGATHER
     return;
-// the same for rows whose z_e was never stored: recomputed from x with the raw (unpacked) encoder weights
-// raw6 = {W0, b0, W1, b1, W2 (Lipschitz-normalised), b2}
-int lipvq_launch_rows_encode(const float* x, const float* const* raw6, int A, const float* cb, int64_t* idx, float* zq,
-                             int64_t* usage, const int* amb_list, const int* amb_count, int64_t N, int K, int D,
-                             hipStream_t st);
 #endif
     const int nvec = D / 4;
     for (int rr = 0; rr < 32; rr += 4) {
