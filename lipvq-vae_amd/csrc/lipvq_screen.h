@@ -146,8 +146,12 @@ __device__ __forceinline__ void lq_screen_core(const f16x8 (&ah)[S], const f16x8
             for (int r = 0; r < 16; ++r) acc[r] = e2 * frow[r];      // |e'|^2 in the units of row (r, h)
 #pragma unroll
             for (int s = 0; s < S; ++s) {
+#ifdef LQ_ABL_NOLDSB
+                const f16x8 bh = ah[(s + 1) % S], bl = al[(s + 1) % S];      // ablation only: no LDS fragment reads (wrong results)
+#else
                 const f16x8 bh = *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 0) * 64 + lane) * 16);
                 const f16x8 bl = *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 1) * 64 + lane) * 16);
+#endif
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl, acc, 0, 0, 0);
