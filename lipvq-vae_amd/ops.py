@@ -75,7 +75,7 @@ def lipschitz_scale(W: torch.Tensor, ci: torch.Tensor):
 
 
 class PackedMlp3:
-    """Weights of one three-layer stack in MFMA A-operand order (see csrc/lipvq_hip.hip)."""
+    """Weights of one three-layer stack in MFMA A-operand order (see csrc/lipvq_mlp.hip)."""
 
     __slots__ = ("buf", "K0", "J0", "J1", "J2")
 
