@@ -123,3 +123,19 @@ def test_module_other_hidden_widths(oracle, hidden, N):
     for k, prm in model.named_parameters():
         scale = np.abs(g[k]).max() + 1e-12
         assert np.abs(prm.grad.cpu().numpy() - g[k]).max() <= 2e-5 * scale, k
+
+
+@pytest.mark.parametrize("A,D,K,N", [(64, 64, 512, 3000), (33, 32, 100, 700), (17, 128, 300, 1500)])
+def test_tokenize_wide_actions(oracle, A, D, K, N):
+    """Action widths up to the fused kernel's limit (A <= 64): parity mode against the oracle, fast mode well-formed."""
+    from lipvq_vae_amd.tokenizer import LLFQVAE_V4
+    p = O.make_params(A + D, A, D, K, oracle=oracle)
+    model = LLFQVAE_V4(A, D, num_codes=K).cuda()
+    model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in p.items()})
+    x = O.make_inputs(A, N, A)
+    idx_ref, zq_ref, _ = oracle.nearest(oracle.llfq_encode(p, x), p["quantizer.codebook"])
+    idx, zq = model.tokenize(_cuda(x), count_usage=False)
+    assert np.array_equal(idx.cpu().numpy(), idx_ref) and np.array_equal(zq.cpu().numpy(), zq_ref)
+    idx_f, zq_f = model.tokenize(_cuda(x), count_usage=False, mode="fast")
+    assert (idx_f.cpu().numpy() != idx_ref).mean() <= 0.01
+    assert torch.equal(zq_f, model.quantizer.codebook.detach()[idx_f])
