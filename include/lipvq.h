@@ -170,6 +170,10 @@ int lipvq_wgrad_f32(const float* G, const float* H, const int64_t* hidx, int h_a
 int lipvq_scatter_add_f32(const float* g, const int64_t* idx, float* gC, int64_t N, int K, int D,
                           void* stream);
 
+/* The same sum, deterministically: rows are added in ascending row order per code (no atomics), so repeated runs give
+ * bit-identical gradients (what torch.use_deterministic_algorithms(True) asks of index_add_).  gC is accumulated into. */
+int lipvq_scatter_add_det_f32(const float* g, const int64_t* idx, float* gC, int64_t N, int K, int D, void* stream);
+
 /* Backward of lipvq_lipschitz_scale_f32: gWn [D][H] -> gW [D][H], gci [D]. */
 int lipvq_lipschitz_bwd_f32(const float* W, const float* ci, const float* gWn, float* gW, float* gci, int D,
                             int H, void* stream);

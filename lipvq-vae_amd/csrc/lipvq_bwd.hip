@@ -260,6 +260,40 @@ __global__ void scatter_add_kernel(const float* __restrict__ g, const int64_t* _
     }
 }
 
+// Deterministic variant: one workgroup per code k, one wave per 64 columns; every wave walks idx in row order (ballot over
+// 64 rows at a time) and adds the matching rows of g in ascending row order -- the result does not depend on scheduling
+// and equals a sequential fp32 index_add_ over n = 0..N-1.  Cost O(K N / 64) ballots (idx stays in L2): ~0.5 ms at
+// N = 524 288, K = 1024 against 0.24 ms for the atomic kernel; microseconds at training-step sizes.
+__global__ __launch_bounds__(256) void scatter_add_det_kernel(const float* __restrict__ g, const int64_t* __restrict__ idx,
+                                                              float* __restrict__ gC, int64_t N, int D) {
+    const int k = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = blockDim.x >> 6;
+    for (int d0 = wave * 64; d0 < D; d0 += nw * 64) {
+        const int d = d0 + lane;
+        float acc = (d < D) ? gC[(size_t)k * D + d] : 0.0f;
+        for (int64_t base = 0; base < N; base += 64) {
+            const int64_t n = base + lane;
+            unsigned long long m = __builtin_amdgcn_ballot_w64(n < N && idx[n] == (int64_t)k);
+            while (m) {                                        // wave-uniform
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                if (d < D) acc = acc + g[(size_t)(base + b) * D + d];
+            }
+        }
+        if (d < D) gC[(size_t)k * D + d] = acc;
+    }
+}
+
+extern "C" int lipvq_scatter_add_det_f32(const float* g, const int64_t* idx, float* gC, int64_t N, int K, int D,
+                                         void* stream) {
+    if (!g || !idx || !gC || N < 0 || K <= 0 || D <= 0) return fail(LIPVQ_EINVAL, "scatter_add_det: bad argument");
+    if (N == 0) return LIPVQ_OK;
+    const int waves = D <= 64 ? 1 : (D <= 128 ? 2 : 4);
+    hipLaunchKernelGGL(scatter_add_det_kernel, dim3((unsigned)K), dim3(64 * waves), 0, (hipStream_t)stream, g, idx, gC, N, D);
+    return check_launch("scatter_add_det");
+}
+
 extern "C" int lipvq_scatter_add_f32(const float* g, const int64_t* idx, float* gC, int64_t N, int K, int D,
                                      void* stream) {
     if (!g || !idx || !gC || N < 0 || K <= 0 || D <= 0) return fail(LIPVQ_EINVAL, "scatter_add: bad argument");

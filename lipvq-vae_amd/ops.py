@@ -219,12 +219,19 @@ def wgrad(G, H, h_act=ACT_NONE, hidx=None, want_bias=True):
     return gW, gb
 
 
-def scatter_add(g, idx, K):
+def scatter_add(g, idx, K, deterministic=None):
+    """gC[k] = sum of the rows of g whose idx is k (the gather's backward / index_add_).  deterministic=None follows
+    torch.are_deterministic_algorithms_enabled(): the ordered kernel instead of fp32 atomics."""
     g, idx = _chk(g, "g"), _chk(idx, "idx", torch.int64)
     N, D = g.shape
+    if deterministic is None:
+        deterministic = torch.are_deterministic_algorithms_enabled()
     gC = torch.zeros((K, D), device=g.device, dtype=torch.float32)
     with _on(g.device):
-        check(lib.lipvq_scatter_add_f32(_ptr(g), _ptr(idx), _ptr(gC), N, K, D, _stream()), "lipvq_scatter_add_f32")
+        if deterministic:
+            check(lib.lipvq_scatter_add_det_f32(_ptr(g), _ptr(idx), _ptr(gC), N, K, D, _stream()), "lipvq_scatter_add_det_f32")
+        else:
+            check(lib.lipvq_scatter_add_f32(_ptr(g), _ptr(idx), _ptr(gC), N, K, D, _stream()), "lipvq_scatter_add_f32")
     return gC
 
 

@@ -120,3 +120,42 @@ def test_ste_and_mse(ops, oracle):
     out = ops.mse_pair(dev(xr), dev(x), dev(zq), dev(ze)).cpu().numpy()
     # means are order-dependent sums: tolerance 1e-6 relative (double accumulation on both sides)
     assert abs(out[0] - a) <= 1e-6 * abs(a) and abs(out[1] - b) <= 1e-6 * abs(b)
+
+
+@pytest.mark.parametrize("N,K,D", [(5000, 37, 64), (80, 1024, 208), (70001, 256, 32)])
+def test_scatter_add_deterministic_is_sequential_fp32(N, K, D):
+    """lipvq_scatter_add_det_f32 equals a sequential fp32 index_add_ over rows 0..N-1, bit for bit, on every run."""
+    from lipvq_vae_amd import ops
+    rng = np.random.default_rng(N)
+    g = rng.standard_normal((N, D)).astype(np.float32)
+    idx = rng.integers(0, K, N).astype(np.int64)
+    idx[: N // 3] = 5                                   # one heavily used code: long ordered chains
+    want = np.zeros((K, D), np.float32)
+    for n in range(N):                                  # fp32 adds in row order
+        want[idx[n]] += g[n]
+    gt, it = torch.from_numpy(g).cuda(), torch.from_numpy(idx).cuda()
+    a = ops.scatter_add(gt, it, K, deterministic=True)
+    b = ops.scatter_add(gt, it, K, deterministic=True)
+    assert torch.equal(a, b) and np.array_equal(a.cpu().numpy(), want)
+    c = ops.scatter_add(gt, it, K, deterministic=False).cpu().numpy()          # atomics: same sum up to fp32 ordering
+    assert np.abs(c - want).max() <= 1e-4 * (1 + np.abs(want).max())
+
+
+def test_training_gradients_are_reproducible_in_deterministic_mode(oracle):
+    from lipvq_vae_amd.tokenizer import LLFQVAE_V4
+    A, D, K, N = 7, 64, 256, 4000
+    p = O.make_params(3, A, D, K, oracle=oracle)
+    x = torch.from_numpy(O.make_inputs(3, N, A)).cuda()
+    grads = []
+    prev = torch.are_deterministic_algorithms_enabled()
+    torch.use_deterministic_algorithms(True)
+    try:
+        for _ in range(2):
+            m = LLFQVAE_V4(A, D, num_codes=K).cuda()
+            m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in p.items()})
+            _, loss = m(x)
+            loss.backward()
+            grads.append([q.grad.clone() for q in m.parameters()])
+    finally:
+        torch.use_deterministic_algorithms(prev)
+    assert all(torch.equal(a, b) for a, b in zip(*grads))
