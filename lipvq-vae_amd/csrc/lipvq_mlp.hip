@@ -250,22 +250,26 @@ __global__ __launch_bounds__(256) void mlp3_kernel(Mlp3Args a) {
 #define MLPS_WAVES 8
 #define MLPS_LD 33
 
+#ifndef MLPS_PF
+#define MLPS_PF 8           // k-steps of packed weights in flight ahead of the MFMAs
+#endif
+
 __device__ __forceinline__ void mlps_chain(const float* __restrict__ Pt, int S, const float* __restrict__ bp, f32x16& acc) {
-    float cur[8], nxt[8];
+    float cur[MLPS_PF], nxt[MLPS_PF];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) cur[j] = (j < S) ? Pt[(size_t)j * 64] : 0.0f;
-    for (int s0 = 0; s0 < S; s0 += 8) {
-        if (s0 + 8 < S) {
+    for (int j = 0; j < MLPS_PF; ++j) cur[j] = (j < S) ? Pt[(size_t)j * 64] : 0.0f;
+    for (int s0 = 0; s0 < S; s0 += MLPS_PF) {
+        if (s0 + MLPS_PF < S) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) nxt[j] = (s0 + 8 + j < S) ? Pt[(size_t)(s0 + 8 + j) * 64] : 0.0f;
+            for (int j = 0; j < MLPS_PF; ++j) nxt[j] = (s0 + MLPS_PF + j < S) ? Pt[(size_t)(s0 + MLPS_PF + j) * 64] : 0.0f;
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < MLPS_PF; ++j) {
             if (s0 + j < S)          // wave-uniform
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[j], bp[(s0 + j) * 2 * MLPS_LD], acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) cur[j] = nxt[j];
+        for (int j = 0; j < MLPS_PF; ++j) cur[j] = nxt[j];
     }
 }
 
