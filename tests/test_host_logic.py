@@ -72,3 +72,56 @@ def test_perplexity_host_math():
     assert abs(m.perplexity() - 4.0) < 1e-9
     m.reset_usage()
     assert int(m.code_usage.sum()) == 0
+
+
+def test_input_embedding_module_keys_and_errors():
+    """Host side of the embedding stage (no GPU): the reference's state_dict keys, the three time-embedding modes, and
+    the errors the reference would raise."""
+    from lipvq_vae_amd.embedding import ICLInputEmbedding, sinusoidal_table
+    m = ICLInputEmbedding(64, 512, 10)
+    assert set(m.state_dict()) == {"nets.embed_encoder.weight", "nets.embed_encoder.bias", "params.embed_timestep",
+                                   "nets.embed_ln.weight", "nets.embed_ln.bias"}
+    assert m.time_table(10).shape == (10, 512)
+    with pytest.raises(ValueError):
+        m.time_table(7)                               # nn.Parameter time embedding: T must equal context_length
+    e = ICLInputEmbedding(64, 256, 10, nn_parameter_for_timesteps=False)
+    assert "nets.embed_timestep.weight" in e.state_dict() and e.time_table(4).shape == (4, 256)
+    with pytest.raises(IndexError):
+        e.time_table(11)
+    s = ICLInputEmbedding(64, 128, 10, sinusoidal_embedding=True)
+    assert not any("embed_timestep" in k for k in s.state_dict())
+    tab = sinusoidal_table(5, 128, "cpu")
+    assert tab.shape == (5, 128) and torch.allclose(tab[0, 0::2], torch.zeros(64)) and torch.allclose(tab[0, 1::2], torch.ones(64))
+    with pytest.raises(ValueError):
+        ICLInputEmbedding(64, 514, 10)                # embed_dim must be a multiple of 4
+    with pytest.raises(RuntimeError):
+        m.input_embedding(torch.zeros(2, 10, 64))     # CPU tensors are refused: no fallback
+
+
+def test_bin_tokenizer_constructor_matches_reference_layout():
+    from lipvq_vae_amd.binning import AdaptiveBinActionEmbedding
+    torch.manual_seed(5)
+    m = AdaptiveBinActionEmbedding(4, 24, num_bins=6, embedding_dim=8, num_step_stop=3)
+    torch.manual_seed(5)
+    embs = [torch.nn.Embedding(6, 8) for _ in range(4)]
+    l0, l2 = torch.nn.Linear(32, 16), torch.nn.Linear(16, 24)
+    assert all(torch.equal(a.weight, b.weight) for a, b in zip(m.embedding_layers, embs))
+    assert torch.equal(m.output_layer[0].weight, l0.weight) and torch.equal(m.output_layer[2].weight, l2.weight)
+    assert torch.isinf(m.running_min).all() and torch.isinf(m.running_max).all() and m._update_enabled
+    assert list(m.state_dict())[:2] == ["running_min", "running_max"]
+    with pytest.raises(ValueError):
+        m(torch.zeros(3, 5))                          # wrong action width
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(3, 4))                          # CPU tensor
+
+
+def test_action_branch_switches():
+    from lipvq_vae_amd.binning import AdaptiveBinActionEmbedding
+    from lipvq_vae_amd.icl import ICLActionBranch
+    from lipvq_vae_amd.tokenizer import LLFQVAE_V4, VQVAE
+    assert isinstance(ICLActionBranch(7, 32).action_network, LLFQVAE_V4)
+    assert isinstance(ICLActionBranch(7, 32, variant="vqvae").action_network, VQVAE)
+    b = ICLActionBranch(7, 32, bin_enabled=True)
+    assert isinstance(b.action_network, AdaptiveBinActionEmbedding) and not b.vq_vae_enabled     # the reference's elif order
+    with pytest.raises(NotImplementedError):
+        ICLActionBranch(7, 32, vq_vae_enabled=False)
