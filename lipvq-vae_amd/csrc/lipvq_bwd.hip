@@ -186,23 +186,27 @@ __global__ __launch_bounds__(64 * WGW_WAVES) void wgrad_wg_kernel(const float* _
     }
 }
 
-// out[e] = sum over chunks of part[c][e]: 32 elements x 8 chunk groups per block (group g sums chunks g, g+8, ... in
+// gW / gb = sum over chunks of the partial slabs (one launch for both): 32 elements x 8 chunk groups per block (group g sums chunks g, g+8, ... in
 // double), the 8 group sums are combined in a fixed order: deterministic.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nchunks,
-                                                           size_t n_elem) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partW, const float* __restrict__ partB,
+                                                           float* __restrict__ gW, float* __restrict__ gb, int nchunks,
+                                                           size_t n_w, size_t n_b) {
     __shared__ double sh[8][32];
     const int le = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const size_t e = (size_t)blockIdx.x * 32 + le;
+    const size_t e = (size_t)blockIdx.x * 32 + le;             // [0, n_w): weight gradient, [n_w, n_w + n_b): bias gradient
+    const bool isw = e < n_w, isb = !isw && e < n_w + n_b;
+    const float* part = isw ? partW : partB;
+    const size_t stride = isw ? n_w : n_b, off = isw ? e : e - n_w;
     double s = 0.0;
-    if (e < n_elem)
-        for (int c = g; c < nchunks; c += 8) s += (double)part[(size_t)c * n_elem + e];
+    if (isw || isb)
+        for (int c = g; c < nchunks; c += 8) s += (double)part[(size_t)c * stride + off];
     sh[g][le] = s;
     __syncthreads();
-    if (g == 0 && e < n_elem) {
+    if (g == 0 && (isw || isb)) {
         double t = sh[0][le];
 #pragma unroll
         for (int q = 1; q < 8; ++q) t += sh[q][le];
-        out[e] = (float)t;
+        (isw ? gW : gb)[off] = (float)t;
     }
 }
 
@@ -241,10 +245,9 @@ extern "C" int lipvq_wgrad_f32(const float* G, const float* H, const int64_t* hi
         hipLaunchKernelGGL(wgrad_kernel, dim3(nch, TI * TJ), dim3(64), 0, st, G, H, hidx, h_act, partW, partB, N, J, Kd, TJ,
                            wgrad_chunk_rows(N));
     }
-    size_t ne = (size_t)J * Kd;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((ne + 31) / 32)), dim3(256), 0, st, partW, gW, nch, ne);
-    if (gb)
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((J + 31) / 32)), dim3(256), 0, st, partB, gb, nch, (size_t)J);
+    const size_t ne = (size_t)J * Kd, nb = gb ? (size_t)J : 0;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((ne + nb + 31) / 32)), dim3(256), 0, st, partW, partB, gW, gb, nch, ne,
+                       nb);
     return check_launch("wgrad");
 }
 

@@ -24,20 +24,34 @@
 // ------------------------------------------------------------------------------------------
 // P[(t*S + s)*64 + lane] = Wv[32t + feat(lane & 31)][2s + (lane >> 5)]   (0 outside), where the
 // virtual weight Wv[f][k] = W[f*sf + k*sk] (sf,sk select W or its transpose); J x K = its shape.
-__global__ void mlp3_pack_kernel(const float* __restrict__ W, const float* __restrict__ b,
-                                 float* __restrict__ P, float* __restrict__ B, int K, int J, int S,
-                                 int T, int sf, int sk) {
+// One launch packs the three layers of a stack.
+struct PackLayer {
+    const float* W;
+    const float* b;
+    size_t oP, oB, n;          // offsets into the packed buffer; threads this layer needs
+    int K, J, S, T, sf, sk;
+};
+struct PackArgs {
+    PackLayer l[3];
+    float* packed;
+};
+
+__global__ void mlp3_pack_kernel(const PackArgs a) {
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t nP = (size_t)T * S * 64;
+    int li = 0;
+    if (gid >= a.l[0].n) { gid -= a.l[0].n; li = 1; if (gid >= a.l[1].n) { gid -= a.l[1].n; li = 2; } }
+    const PackLayer& L = a.l[li];
+    if (gid >= L.n) return;
+    size_t nP = (size_t)L.T * L.S * 64;
     if (gid < nP) {
         int lane = (int)(gid & 63);
         size_t ts = gid >> 6;
-        int s = (int)(ts % S), t = (int)(ts / S);
+        int s = (int)(ts % L.S), t = (int)(ts / L.S);
         int f = 32 * t + feat_of_tile_row(lane & 31);
         int k = 2 * s + (lane >> 5);
-        P[gid] = (f < J && k < K) ? W[(size_t)f * sf + (size_t)k * sk] : 0.0f;
+        a.packed[L.oP + gid] = (f < L.J && k < L.K) ? L.W[(size_t)f * L.sf + (size_t)k * L.sk] : 0.0f;
     }
-    if (gid < (size_t)T * 32) B[gid] = (b && (int)gid < J) ? b[gid] : 0.0f;
+    if (gid < (size_t)L.T * 32) a.packed[L.oB + gid] = (L.b && (int)gid < L.J) ? L.b[gid] : 0.0f;
 }
 
 extern "C" size_t lipvq_mlp3_packed_floats(int K0, int J0, int J1, int J2) {
@@ -45,12 +59,16 @@ extern "C" size_t lipvq_mlp3_packed_floats(int K0, int J0, int J1, int J2) {
     return packed_layout(K0, J0, J1, J2).total;
 }
 
-static void pack_layer(const float* W, const float* b, float* packed, size_t oP, size_t oB, int K, int J,
-                       int S, int T, int sf, int sk, hipStream_t st) {
+static PackLayer pack_layer(const float* W, const float* b, size_t oP, size_t oB, int K, int J, int S, int T, int sf, int sk) {
     size_t n = (size_t)T * S * 64;
     if (n < (size_t)T * 32) n = (size_t)T * 32;
-    hipLaunchKernelGGL(mlp3_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, b,
-                       packed + oP, packed + oB, K, J, S, T, sf, sk);
+    return PackLayer{W, b, oP, oB, n, K, J, S, T, sf, sk};
+}
+
+static void pack_launch(const PackLayer& l0, const PackLayer& l1, const PackLayer& l2, float* packed, hipStream_t st) {
+    PackArgs a{{l0, l1, l2}, packed};
+    const size_t n = l0.n + l1.n + l2.n;
+    hipLaunchKernelGGL(mlp3_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
 }
 
 static int check_hidden(const char* who, int a, int b) {
@@ -67,9 +85,9 @@ extern "C" int lipvq_mlp3_pack_f32(const float* W0, const float* b0, const float
     if (int e = check_hidden("mlp3_pack", J0, J1)) return e;
     PackedLayout L = packed_layout(K0, J0, J1, J2);
     hipStream_t st = (hipStream_t)stream;
-    pack_layer(W0, b0, packed, L.oP0, L.oB0, K0, J0, L.S0, L.T0, K0, 1, st);
-    pack_layer(W1, b1, packed, L.oP1, L.oB1, J0, J1, L.S1, L.T1, J0, 1, st);
-    pack_layer(W2, b2, packed, L.oP2, L.oB2, J1, J2, L.S2, L.T2, J1, 1, st);
+    pack_launch(pack_layer(W0, b0, L.oP0, L.oB0, K0, J0, L.S0, L.T0, K0, 1),
+                pack_layer(W1, b1, L.oP1, L.oB1, J0, J1, L.S1, L.T1, J0, 1),
+                pack_layer(W2, b2, L.oP2, L.oB2, J1, J2, L.S2, L.T2, J1, 1), packed, st);
     return check_launch("mlp3_pack");
 }
 
@@ -87,9 +105,9 @@ extern "C" int lipvq_mlp3_pack_bwd_f32(const float* W0, const float* W1, const f
     PackedLayout L = packed_layout(J2, J1, J0, K0);
     hipStream_t st = (hipStream_t)stream;
     // layer 0': in J2, out J1, virtual weight [J1][J2] = W2^T : Wv[f][k] = W2[k][f] = W2[k*J1 + f]
-    pack_layer(W2, nullptr, packed, L.oP0, L.oB0, J2, J1, L.S0, L.T0, 1, J1, st);
-    pack_layer(W1, nullptr, packed, L.oP1, L.oB1, J1, J0, L.S1, L.T1, 1, J0, st);
-    pack_layer(W0, nullptr, packed, L.oP2, L.oB2, J0, K0, L.S2, L.T2, 1, K0, st);
+    pack_launch(pack_layer(W2, nullptr, L.oP0, L.oB0, J2, J1, L.S0, L.T0, 1, J1),
+                pack_layer(W1, nullptr, L.oP1, L.oB1, J1, J0, L.S1, L.T1, 1, J0),
+                pack_layer(W0, nullptr, L.oP2, L.oB2, J0, K0, L.S2, L.T2, 1, K0), packed, st);
     return check_launch("mlp3_pack_bwd");
 }
 
