@@ -33,9 +33,15 @@ class _LLFQFn(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad[2:])
         if need_grad:
             z_e, pre_e = ops.mlp3(x, enc_packed, _ENC_ACTS, save_pre=True)
+            idx, z_q = module._quantize(z_e, module.code_usage)
+        elif x.shape[0] > module.EXACT_ROWS_MAX and ops.tokenize_supported(module.feature_dim, 64, module.hidden_dim,
+                                                                          module.latent_dim, module.num_codes):
+            # no autograd (rollouts under no_grad, bulk evaluation): the fused encode + quantize launch, z_e written for the loss
+            idx, z_q, z_e = module._tokenize_fused(x, module.code_usage, want_ze=True)
+            pre_e = None
         else:
             z_e, pre_e = ops.mlp3(x, enc_packed, _ENC_ACTS), None
-        idx, z_q = module._quantize(z_e, module.code_usage)
+            idx, z_q = module._quantize(z_e, module.code_usage)
         if need_grad:
             x_rec, pre_d = ops.mlp3(codebook, dec_packed, _DEC_ACTS, gather_idx=idx, save_pre=True)
         else:

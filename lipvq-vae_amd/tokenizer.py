@@ -168,6 +168,25 @@ class LLFQVAE_V4(_TokenizerBase):
         packed, _, _ = self._packed_encoder()
         return ops.mlp3(self._as_rows(x), packed, (ACT_GELU, ACT_GELU, ACT_SIGMOID))
 
+    def _tokenize_fused(self, x, usage, want_ze=False, fast=False):
+        """(idx, z_q, z_e | None) from ONE persistent launch: z_e never leaves registers unless asked for
+        (csrc/lipvq_fused.hip).  Caller checks ops.tokenize_supported()."""
+        cb = self.quantizer.codebook.detach()
+        packed, _, Wn = self._packed_encoder()
+        w0, b0, w1, b1, _, b2, _ = (t.detach() for t in self._enc_params())
+        prep = self._cb_cache.get((self.quantizer.codebook,), lambda: ops.nearest_prepare(cb))
+        key = (x.shape[0], x.device)
+        if getattr(self, "_tok_ws_key", None) != key:        # the scratch (row list) is reused across calls
+            self._tok_ws, self._tok_ws_key = ops.tokenize_workspace(x.shape[0], self.latent_dim, x.device), key
+        packed16 = None
+        if fast:
+            packed16 = self._enc16_cache.get((w0, w1, self.to_latent.W, self.to_latent.ci),
+                                             lambda: ops.mlp3_pack_f16(w0, w1, Wn))
+        idx, zq, ze, ws = ops.tokenize(x, packed, (w0, b0, w1, b1, Wn, b2), cb, prep, usage=usage, want_ze=want_ze,
+                                       workspace=self._tok_ws, packed16=packed16)
+        self.last_exact_rows = ws
+        return idx, zq, ze
+
     @torch.no_grad()
     def tokenize(self, x, count_usage=True, mode="parity"):
         """encode + quantize: (indices[N] int64, z_latent[N,D])   (v5:71-74).
@@ -179,22 +198,8 @@ class LLFQVAE_V4(_TokenizerBase):
             raise ValueError(f"unknown tokenize mode {mode!r}")
         x = self._as_rows(x)
         usage = self.code_usage if count_usage else None
-        cb = self.quantizer.codebook.detach()
         if x.shape[0] > 0 and ops.tokenize_supported(self.feature_dim, 64, self.hidden_dim, self.latent_dim, self.num_codes):
-            # one persistent launch: z_e never leaves registers (csrc/lipvq_fused.hip)
-            packed, _, Wn = self._packed_encoder()
-            w0, b0, w1, b1, _, b2, _ = (t.detach() for t in self._enc_params())
-            prep = self._cb_cache.get((self.quantizer.codebook,), lambda: ops.nearest_prepare(cb))
-            key = (x.shape[0], x.device)
-            if getattr(self, "_tok_ws_key", None) != key:        # the scratch (row list + z_e) is reused across calls
-                self._tok_ws, self._tok_ws_key = ops.tokenize_workspace(x.shape[0], self.latent_dim, x.device), key
-            packed16 = None
-            if mode == "fast":
-                packed16 = self._enc16_cache.get((w0, w1, self.to_latent.W, self.to_latent.ci),
-                                                 lambda: ops.mlp3_pack_f16(w0, w1, Wn))
-            idx, zq, _, ws = ops.tokenize(x, packed, (w0, b0, w1, b1, Wn, b2), cb, prep, usage=usage,
-                                          workspace=self._tok_ws, packed16=packed16)
-            self.last_exact_rows = ws
+            idx, zq, _ = self._tokenize_fused(x, usage, fast=(mode == "fast"))
         elif mode == "fast":
             raise RuntimeError("tokenize(mode='fast') needs the fused kernel's shapes (hidden 64/128, D in {32, 64, 128})")
         else:

@@ -126,3 +126,19 @@ def test_two_streams_concurrently(oracle):
         torch.cuda.synchronize()
         for a, b in zip(out, serial):
             assert torch.equal(a, b)
+
+
+def test_no_grad_forward_takes_the_fused_launch_and_agrees(oracle):
+    """forward() without autograd (N above the small-batch threshold) runs encode + quantize as the fused launch; z_latent,
+    loss and indices equal the autograd path's bit for bit."""
+    p, model = _setup(61, 7, 64, 1024, oracle)
+    x = torch.from_numpy(O.make_inputs(61, 5000, 7)).cuda()
+    z_a, loss_a = model(x)
+    idx_a = model.last_indices.clone()
+    assert loss_a.requires_grad
+    with torch.no_grad():
+        z_b, loss_b = model(x)
+    assert model.last_exact_rows is not None                      # the fused kernel's workspace: that path ran
+    assert torch.equal(z_a, z_b) and torch.equal(idx_a, model.last_indices) and loss_a.item() == loss_b.item()
+    f = oracle.llfq_forward(p, x.cpu().numpy())
+    assert np.array_equal(z_b.cpu().numpy(), f["z_q"]) and abs(loss_b.item() - f["loss"]) <= 1e-5 * abs(f["loss"])
