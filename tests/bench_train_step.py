@@ -3,7 +3,7 @@ real ICRT shapes: GPU (this library) vs the torch-CPU restatement of the referen
 (what the reference's train() sets, scripts/train.py:57).  Prints ms/step."""
 import sys, time
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))  # repo root
 import torch
 import lipvq_vae_amd
 from lipvq_vae_amd.tokenizer import LLFQVAE_V4
