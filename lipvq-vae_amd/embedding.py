@@ -32,12 +32,12 @@ __all__ = ["ICLInputEmbedding", "sinusoidal_table"]
 
 def sinusoidal_table(T: int, E: int, device) -> torch.Tensor:
     """[T, E] rows of PositionalEncoding (reference robomimic/models/transformers.py:58-77) for timesteps 0..T-1."""
-    t = torch.arange(T, dtype=torch.float32).unsqueeze(-1)
-    div = torch.exp(torch.arange(0, E, 2) * (-math.log(10000.0) / E)).unsqueeze(0)
-    pe = torch.zeros((T, E))
+    t = torch.arange(T, dtype=torch.float32, device=device).unsqueeze(-1)
+    div = torch.exp(torch.arange(0, E, 2, device=device) * (-math.log(10000.0) / E)).unsqueeze(0)
+    pe = torch.zeros((T, E), device=device)          # built on `device`, as the reference builds it on its own
     pe[:, 0::2] = torch.sin(t * div)
     pe[:, 1::2] = torch.cos(t * div)
-    return pe.to(device)
+    return pe
 
 
 class _LinearFn(torch.autograd.Function):
