@@ -219,6 +219,58 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
     if (zq) lq_screen_gather(cb, zq, my_k, certified, row0, N, D, lane);
 }
 
+// Exact scan of codes [kb, ke) for one row held in registers: torch's 8-accumulator order, sqrt comparison, first minimum.
+// Every 32 dimensions the partial sums are combined in the final order; since each accumulator only grows (squares are
+// non-negative and fp32 addition is monotone) and the combination is monotone in every accumulator, a partial value that
+// already reaches the best square so far proves the full square does too, and the rest of that code's row is not
+// fetched.  Same results bit for bit; the scan is bound by re-reading the codebook (1.15 ms for 3 317 rows at K = 8192,
+// D = 128 without the early exit).
+template <int DCH>
+__device__ __forceinline__ void lq_exact_scan(const float (&zr)[DCH * 8], const float* __restrict__ cb, int kb, int ke,
+                                              float& best_v, float& best_s, int& best_k) {
+    constexpr int D = DCH * 8;
+#ifdef LQ_SCAN_G
+    constexpr int G = LQ_SCAN_G;
+#else
+    // chunks of 8 dimensions between two early-exit tests.  Measured (same-run builds): every 32 dimensions pays at D = 128,
+    // K = 8192 (cfg3 launch 4.74 -> 4.10 ms) and is neutral at D = 64; at D = 208 -- the training-step route, where every row
+    // of a small batch is scanned and uniform-random data prunes nothing -- six tests per code cost 18 %, so none there.
+    constexpr int G = (DCH > 16) ? DCH : 4;
+#endif
+    for (int k = kb; k < ke; ++k) {
+        const float4* c4 = reinterpret_cast<const float4*>(cb + (size_t)k * D);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+        bool dead = false;
+#pragma unroll
+        for (int g = 0; g < DCH; g += G) {
+#pragma unroll
+            for (int i = g; i < (g + G < DCH ? g + G : DCH); ++i) {
+                const float4 lo = c4[2 * i], hi = c4[2 * i + 1];
+                const float d0 = zr[8 * i + 0] - lo.x, d1 = zr[8 * i + 1] - lo.y;
+                const float d2 = zr[8 * i + 2] - lo.z, d3 = zr[8 * i + 3] - lo.w;
+                const float d4 = zr[8 * i + 4] - hi.x, d5 = zr[8 * i + 5] - hi.y;
+                const float d6 = zr[8 * i + 6] - hi.z, d7 = zr[8 * i + 7] - hi.w;
+                a0 = lq_fma(d0, d0, a0); a1 = lq_fma(d1, d1, a1);
+                a2 = lq_fma(d2, d2, a2); a3 = lq_fma(d3, d3, a3);
+                a4 = lq_fma(d4, d4, a4); a5 = lq_fma(d5, d5, a5);
+                a6 = lq_fma(d6, d6, a6); a7 = lq_fma(d7, d7, a7);
+            }
+#ifndef LQ_NO_EARLY_EXIT
+            if (g + G < DCH) {
+                const float part = ((((((a0 + a1) + a2) + a3) + a4) + a5) + a6) + a7;
+                if (part >= best_s) { dead = true; break; }
+            }
+#endif
+        }
+        if (dead) continue;
+        const float s = ((((((a0 + a1) + a2) + a3) + a4) + a5) + a6) + a7;
+        if (s < best_s) {
+            const float v = lq_sqrt(s);
+            if (v < best_v) { best_v = v; best_s = s; best_k = k; }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // exact decision for the listed rows: 4 rows x 64 code slices per workgroup
 // ------------------------------------------------------------------------------------------
@@ -252,27 +304,7 @@ __global__ __launch_bounds__(256) void nearest_rows_kernel(
     float best_v = INFINITY, best_s = INFINITY;
     int best_k = kb < K ? kb : 0;            // always a valid code, even if every distance is NaN (torch.argmin
                                              // of an all-NaN row is unspecified; an out-of-range index is not an option)
-    for (int k = kb; k < ke; ++k) {
-        const float4* c4 = reinterpret_cast<const float4*>(cb + (size_t)k * D);
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
-#pragma unroll
-        for (int i = 0; i < DCH; ++i) {
-            const float4 lo = c4[2 * i], hi = c4[2 * i + 1];
-            const float d0 = zr[8 * i + 0] - lo.x, d1 = zr[8 * i + 1] - lo.y;
-            const float d2 = zr[8 * i + 2] - lo.z, d3 = zr[8 * i + 3] - lo.w;
-            const float d4 = zr[8 * i + 4] - hi.x, d5 = zr[8 * i + 5] - hi.y;
-            const float d6 = zr[8 * i + 6] - hi.z, d7 = zr[8 * i + 7] - hi.w;
-            a0 = lq_fma(d0, d0, a0); a1 = lq_fma(d1, d1, a1);
-            a2 = lq_fma(d2, d2, a2); a3 = lq_fma(d3, d3, a3);
-            a4 = lq_fma(d4, d4, a4); a5 = lq_fma(d5, d5, a5);
-            a6 = lq_fma(d6, d6, a6); a7 = lq_fma(d7, d7, a7);
-        }
-        const float s = ((((((a0 + a1) + a2) + a3) + a4) + a5) + a6) + a7;
-        if (s < best_s) {
-            const float v = lq_sqrt(s);
-            if (v < best_v) { best_v = v; best_s = s; best_k = k; }
-        }
-    }
+    lq_exact_scan<DCH>(zr, cb, kb, ke, best_v, best_s, best_k);
     s_v[r][sl] = best_v; s_k[r][sl] = best_k;
     __syncthreads();
     if (sl == 0 && valid) {
@@ -367,27 +399,7 @@ __global__ __launch_bounds__(256) void nearest_rows_encode_kernel(
     const int kb = sl * per, ke = (kb + per < K) ? kb + per : K;
     float best_v = INFINITY, best_s = INFINITY;
     int best_k = kb < K ? kb : 0;
-    for (int k = kb; k < ke; ++k) {
-        const float4* c4 = reinterpret_cast<const float4*>(cb + (size_t)k * D);
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
-#pragma unroll
-        for (int i = 0; i < DCH; ++i) {
-            const float4 lo = c4[2 * i], hi = c4[2 * i + 1];
-            const float d0 = zr[8 * i + 0] - lo.x, d1 = zr[8 * i + 1] - lo.y;
-            const float d2 = zr[8 * i + 2] - lo.z, d3 = zr[8 * i + 3] - lo.w;
-            const float d4 = zr[8 * i + 4] - hi.x, d5 = zr[8 * i + 5] - hi.y;
-            const float d6 = zr[8 * i + 6] - hi.z, d7 = zr[8 * i + 7] - hi.w;
-            a0 = lq_fma(d0, d0, a0); a1 = lq_fma(d1, d1, a1);
-            a2 = lq_fma(d2, d2, a2); a3 = lq_fma(d3, d3, a3);
-            a4 = lq_fma(d4, d4, a4); a5 = lq_fma(d5, d5, a5);
-            a6 = lq_fma(d6, d6, a6); a7 = lq_fma(d7, d7, a7);
-        }
-        const float s = ((((((a0 + a1) + a2) + a3) + a4) + a5) + a6) + a7;
-        if (s < best_s) {
-            const float v = lq_sqrt(s);
-            if (v < best_v) { best_v = v; best_s = s; best_k = k; }
-        }
-    }
+    lq_exact_scan<DCH>(zr, cb, kb, ke, best_v, best_s, best_k);
     s_v[r][sl] = best_v; s_k[r][sl] = best_k;
     __syncthreads();
     if (sl == 0 && valid) {
