@@ -41,6 +41,7 @@ WORKLOADS = {
     "cfg3": (4096, 128, 7, 128, 8192),
     "cfg1": (64, 16, 7, 32, 256),
     "encA": (4096, 128, 7, 64, 32),      # dev only: tiny codebook -> the fused kernel is almost pure encoder phase
+    "icrt": (4096, 128, 12, 208, 1024),  # the reference's own widths (obs_nets.py:2411, v5:89-92) at the metric's batch: unfused path
 }
 PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 vector = fp32-input MFMA peak
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak (the screening kernel's pipe)
