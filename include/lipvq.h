@@ -262,6 +262,24 @@ int lipvq_act_bwd_f32(const float* g, const float* pre, float* out, int64_t n, i
 int lipvq_ema_update_f32(float* cluster_size, float* embed_sum, const int64_t* counts, const float* dw, float* codebook,
                          float decay, float eps, int K, int D, void* workspace, void* stream);
 
+/* ---- multi-GPU: the path's only cross-GPU exchange (the reference is single-GPU,
+ *      robomimic/utils/torch_utils.py:48-50, so there is no reference line to cite) ----
+ * One process per GPU, rows sharded, parameters replicated.  Per batch the code-usage histogram (and, with the EMA
+ * extension, the per-code sums) is summed over the ranks by RCCL over xGMI.  The library binds RCCL at run time
+ * (dlopen of librccl.so.1 -- the copy PyTorch has already mapped when there is one, so both share one RCCL), hence the
+ * tokenizer library itself loads on hosts without RCCL; these four entries then return LIPVQ_EUNSUPPORTED.
+ *
+ * lipvq_allreduce_counts takes ANY ncclComm_t (as void*): the application's own communicator, or one made by
+ * lipvq_comm_init from a 128-byte unique id that rank 0 obtains with lipvq_comm_unique_id and hands to the other ranks
+ * over any out-of-band channel (torch.distributed's store, a file, MPI).  In place, sum, enqueued on `stream`. */
+#define LIPVQ_COMM_ID_BYTES 128
+int lipvq_comm_unique_id(void* id128);
+int lipvq_comm_init(void** comm, const void* id128, int rank, int world);
+int lipvq_comm_destroy(void* comm);
+int lipvq_allreduce_counts(int64_t* counts, int K, void* comm /* ncclComm_t */, void* stream);
+/* the same for fp32 payloads (EMA per-code sums [K][D], flat data-parallel gradients) */
+int lipvq_allreduce_f32(float* buf, int64_t n, void* comm /* ncclComm_t */, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,11 @@ SIGNATURES = {
     "lipvq_bin_hidden_f32": (_i, [_vp] * 5 + [_i64, _i, _i, _i, _vp]),
     "lipvq_act_bwd_f32": (_i, [_vp] * 3 + [_i64, _i, _vp]),
     "lipvq_ema_update_f32": (_i, [_vp] * 5 + [C.c_float, C.c_float, _i, _i, _vp, _vp]),
+    "lipvq_comm_unique_id": (_i, [_vp]),
+    "lipvq_comm_init": (_i, [C.POINTER(_vp), _vp, _i, _i]),
+    "lipvq_comm_destroy": (_i, [_vp]),
+    "lipvq_allreduce_counts": (_i, [_vp, _i, _vp, _vp]),
+    "lipvq_allreduce_f32": (_i, [_vp, _i64, _vp, _vp]),
 }
 
 

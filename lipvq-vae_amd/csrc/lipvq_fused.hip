@@ -407,7 +407,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
         for (int r = 0; r < 16; ++r) { m1[r] = INFINITY; m2[r] = INFINITY; k1[r] = 0; }
         lq_screen_core<S, FUSED_THREADS, fused_tc(S)>(ah, al, tiles, L.ntiles, stage0, tid, frow, m1, m2, k1);
         int my_k;
-        const bool certified = lq_screen_decide(m1, m2, k1, stage0 + (size_t)wave * 4096, hdr, n2, fown, a.gamma, a.K, lane, my_k);
+        const bool certified = lq_screen_decide(m1, m2, k1, stage0 + (size_t)wave * 4096, hdr, n2, fown, a.gamma, a.K, a.D, lane, my_k);
         if (h == 0 && row < a.N) {
             if (certified) {
                 a.idx[row] = (int64_t)my_k;

@@ -184,7 +184,7 @@ __device__ __forceinline__ void lq_row_factors(float fown, int lane, float (&fro
 // Returns certified (valid in every lane, duplicated across the halves); my_k = the row's code.
 __device__ __forceinline__ bool lq_screen_decide(const float (&m1)[16], const float (&m2)[16], const int (&k1)[16],
                                                  unsigned char* wave_lds /* 4 KiB, this wave only */,
-                                                 const unsigned* hdr, float n2, float fown, float gamma, int K,
+                                                 const unsigned* hdr, float n2, float fown, float gamma, int K, int D,
                                                  int lane, int& my_k) {
     const int ln = lane & 31, h = lane >> 5;
     float* tv = reinterpret_cast<float*>(wave_lds);           // [32 rows][32 lanes], reused by the three passes
@@ -248,11 +248,26 @@ __device__ __forceinline__ bool lq_screen_decide(const float (&m1)[16], const fl
     const float Emax = lq_sqrt(__uint_as_float(hdr[1]));
     const float twoemax = __uint_as_float(hdr[2]);
     const float cross = 2.0f * lq_sqrt(n2) * Emax;
-    // screening error + the rounding of the reference's own fp32 distance / square root (2^-20 of the largest
-    // full squared distance the row can see)
-    const float eps = gamma * (E2max + cross) + 9.5367431640625e-07f * (n2 + E2max + cross);
-    // best/second are in this row's units (fown = 2^(sz+se)); non-finite inputs make the comparison false
-    bool certified = (twoemax < INFINITY) && (second - best > 2.0f * eps * fown) && (bk >= 0) && (bk < K);
+    // Certification margin, in this row's units (fown = 2^(sz+se); best/second are d~ * fown).  With S_k = |z - e_k|^2 in
+    // real arithmetic and d~_k = S_k - |z'|^2 +- eps_s:
+    //  (1) screening error: |d~ - d| <= eps_s = gamma (E2max + 2 |z'| Emax)                       (lipvq_screen.hip, "Error bound")
+    //  (2) the reference's own fp32 arithmetic (v5:41-46, torch.norm's 8-accumulator sum, then sqrt, then argmin): every
+    //      term of the sum is non-negative, so |fl(S) - S| <= c u S with u = 2^-24 and c = D/8 + 9 (one rounding per
+    //      difference, squared: 2u; D/8 fma roundings per accumulator; 7 adds); the correctly rounded roots of two sums
+    //      differ strictly once fl(S_k) / fl(S_k1) > ((1+u)/(1-u))^2.  Together: the reference decides k1 against k with a
+    //      STRICT inequality (so no first-index tie rule can interfere) whenever  S_k - S_k1 > 2 (c + 2) u S_k1.
+    //  Hence "second - best > 2 eps_s + 2 (D/8 + 12) u s1" certifies k1, where s1 >= S_k1 is bounded from the screen's own
+    //  numbers: S_k1 <= best + |z'|^2 + eps_s, plus the rounding of n2 itself ((D + 2) u n2).  The bound is relative to the
+    //  WINNER's distance (not to the largest distance the row can see), so it is rigorous for every D and negligible for
+    //  rows close to a code.
+    const int Dpad16 = ((D + 15) / 16) * 16;
+    const float u24 = 5.9604644775390625e-08f;                                  // 2^-24
+    const float eps_s = gamma * (E2max + cross) * fown;
+    const float n2s = n2 * fown;
+    const float s1 = fmaxf(0.0f, best + n2s) + eps_s + (float)(Dpad16 + 2) * u24 * n2s;
+    const float thr = 2.0f * eps_s + 2.125f * (float)(Dpad16 / 8 + 12) * u24 * s1;
+    // non-finite inputs make the comparison false
+    bool certified = (twoemax < INFINITY) && (second - best > thr) && (bk >= 0) && (bk < K);
 #ifdef LQ_ABL_CERT_ALL
     certified = true; my_k = (my_k >= 0 && my_k < K) ? my_k : (lane * 7) % K;
 #endif

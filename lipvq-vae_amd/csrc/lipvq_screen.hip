@@ -206,7 +206,7 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
         lq_screen_core<S, SCREEN_WAVES * 64>(ah, al, tiles, L.ntiles, lds, tid, frow, m1, m2, k1);
     }
     int my_k;
-    const bool certified = lq_screen_decide(m1, m2, k1, lds + (size_t)wave * 4096, hdr, n2, fown, gamma, K, lane, my_k);
+    const bool certified = lq_screen_decide(m1, m2, k1, lds + (size_t)wave * 4096, hdr, n2, fown, gamma, K, D, lane, my_k);
     if (h == 0 && row < N) {
         if (certified) {
             idx[row] = (int64_t)my_k;

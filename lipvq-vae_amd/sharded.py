@@ -77,6 +77,77 @@ def all_reduce_gradients(params: Iterable[torch.nn.Parameter], n_local: int, n_g
         off += n
 
 
+class RcclCounts:
+    """The C-ABI binding of the path's collective (include/lipvq.h: lipvq_comm_* / lipvq_allreduce_counts): an RCCL
+    communicator owned by the tokenizer library, for callers that do not route the histogram through
+    ``torch.distributed``.  Rank 0 draws the 128-byte unique id, ``torch.distributed`` (any backend, used only as the
+    out-of-band channel) hands it to the other ranks, and every rank joins with its CURRENT device.
+
+    ``all_reduce(usage)`` enqueues the in-place sum on a side stream ordered after the current stream and returns an
+    event; ``wait(event)`` makes the current stream wait for it -- the reduction of batch k overlaps the tokenize
+    launch of batch k+1 the same way ``dist.all_reduce(async_op=True)`` does in bench.py."""
+
+    def __init__(self, group=None):
+        import ctypes as C
+
+        from . import _capi
+        self._capi, self._C = _capi, C
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            raw = (C.c_ubyte * 128)()
+            _capi.check(_capi.lib.lipvq_comm_unique_id(C.cast(raw, C.c_void_p)), "lipvq_comm_unique_id")
+            ident = torch.tensor(list(raw), dtype=torch.uint8)
+        if self.world > 1:
+            box = [ident.tolist()]
+            dist.broadcast_object_list(box, src=0, group=group)      # the store carries it: works for nccl and gloo groups
+            ident = torch.tensor(box[0], dtype=torch.uint8)
+        raw = (C.c_ubyte * 128)(*ident.tolist())
+        comm = C.c_void_p()
+        _capi.check(_capi.lib.lipvq_comm_init(C.byref(comm), C.cast(raw, C.c_void_p), self.rank, self.world), "lipvq_comm_init")
+        self._comm = comm
+        self._side = torch.cuda.Stream()
+
+    def all_reduce(self, usage: torch.Tensor) -> "torch.cuda.Event":
+        if not (usage.is_cuda and usage.dtype == torch.int64 and usage.is_contiguous()):
+            raise TypeError("RcclCounts.all_reduce: a contiguous int64 CUDA tensor is required")
+        self._side.wait_stream(torch.cuda.current_stream())
+        self._capi.check(self._capi.lib.lipvq_allreduce_counts(usage.data_ptr(), usage.numel(), self._comm,
+                                                               self._side.cuda_stream), "lipvq_allreduce_counts")
+        usage.record_stream(self._side)
+        ev = torch.cuda.Event()
+        ev.record(self._side)
+        return ev
+
+    def all_reduce_f32(self, buf: torch.Tensor) -> "torch.cuda.Event":
+        if not (buf.is_cuda and buf.dtype == torch.float32 and buf.is_contiguous()):
+            raise TypeError("RcclCounts.all_reduce_f32: a contiguous fp32 CUDA tensor is required")
+        self._side.wait_stream(torch.cuda.current_stream())
+        self._capi.check(self._capi.lib.lipvq_allreduce_f32(buf.data_ptr(), buf.numel(), self._comm, self._side.cuda_stream),
+                         "lipvq_allreduce_f32")
+        buf.record_stream(self._side)
+        ev = torch.cuda.Event()
+        ev.record(self._side)
+        return ev
+
+    @staticmethod
+    def wait(event) -> None:
+        torch.cuda.current_stream().wait_event(event)
+
+    def close(self) -> None:
+        if self._comm is not None and self._comm.value:
+            torch.cuda.synchronize()
+            self._capi.check(self._capi.lib.lipvq_comm_destroy(self._comm), "lipvq_comm_destroy")
+        self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ShardedTokenizer:
     """Tokenise this rank's share of a batch and keep the global code-usage statistics.
 
@@ -91,12 +162,21 @@ class ShardedTokenizer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
     def tokenize(self, actions: torch.Tensor, reduce_usage: bool = True):
-        """actions [B, T, A] (the full batch, or this rank's own [B_local, T, A] with pre_sharded=True
-        semantics left to the caller) -> (indices [B_local, T], z_latent [B_local, T, D]) of this rank's rows."""
+        """actions [B, T, A] (the full batch) -> (indices [B_local, T], z_latent [B_local, T, D]) of this rank's rows.
+
+        ``tokenizer.code_usage`` is a CUMULATIVE histogram (the kernels add into it on every call), so only THIS
+        batch's counts cross the ranks: the delta of the call is summed over the ranks and added to what the buffer
+        held before, which is already global.  After any number of calls every rank holds the histogram of all rows
+        of all batches (reducing the buffer itself would re-multiply earlier batches by the world size each call)."""
         s, e = shard_bounds(actions.shape[0], self.rank, self.world)
         local = actions[s:e]
         b, t = local.shape[0], local.shape[1]
+        usage = self.tokenizer.code_usage
+        before = usage.clone() if reduce_usage else None
         idx, z = self.tokenizer.tokenize(local.reshape(b * t, -1))
         if reduce_usage:
-            all_reduce_usage(self.tokenizer.code_usage, self.group)
+            usage = self.tokenizer.code_usage
+            delta = usage - before
+            all_reduce_usage(delta, self.group)
+            usage.copy_(before + delta)
         return idx.reshape(b, t), z.reshape(b, t, -1)

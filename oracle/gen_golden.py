@@ -124,6 +124,71 @@ def run_llfq(ref, name, seed, N, A, D, K, regime="trained", full=False, clamp=Fa
           f"{np.min((out['d_second'] - out['d_best']) / np.maximum(out['d_second'], 1e-30)):.3e}")
 
 
+def run_llfq_big(ref, name, seed, N, A, D, K, chunk, oracle=None):
+    """Full-size pin of the quantizer decision: the REFERENCE MODULE's own sub-modules (encoder, to_latent, quantizer) run
+    row-chunked over N rows (the [N, K, D] temporary of v5:41-45 does not fit otherwise); the fixture keeps only what a
+    parity test needs -- indices (uint16), the reference's best and second-best distance per row (fp32) -- so 65 536 rows
+    stay well under 1 MB.  Parameters and inputs are re-drawn from the seed by the tests (sha256 stored)."""
+    p = O.make_params(seed, A, D, K, regime="trained", variant="llfq", oracle=oracle)
+    x = torch.from_numpy(O.make_inputs(seed, N, A).copy())
+    model = ref.LLFQVAE_V4(A, D, num_codes=K)
+    model.load_state_dict(O.to_torch(p), strict=True)
+    model = model.float()
+    idxs, d1s, d2s = [], [], []
+    with torch.no_grad():
+        for s in range(0, N, chunk):
+            z_e = model.to_latent(model.encoder(x[s:s + chunk]))
+            _, idx = model.quantizer(z_e)
+            a, b = top2(ref_llfq_distances(model, z_e))
+            idxs.append(idx), d1s.append(a), d2s.append(b)
+    idx = torch.cat(idxs).numpy()
+    assert idx.max() < 65536
+    d1, d2 = np.concatenate(d1s), np.concatenate(d2s)
+    # the torch restatement that bench.py times must be the reference on a slice of this size too
+    n_chk = min(N, 8 * chunk)
+    idx2, _ = O.torch_llfq_tokenize(O.to_torch(p), x[:n_chk], chunk=chunk)
+    assert np.array_equal(idx2.numpy(), idx[:n_chk]), name
+    np.savez_compressed(GOLD / f"{name}.npz",
+                        meta=meta_of(name=name, seed=seed, N=N, A=A, D=D, K=K, regime="trained", variant="llfq-big", chunk=chunk),
+                        seed=seed, N=N, A=A, D=D, K=K, params_sha256=np.array(O.params_digest(p)),
+                        indices=idx.astype(np.uint16), d_best=d1, d_second=d2)
+    rel = (d2 - d1) / np.maximum(d2, 1e-30)
+    print(f"{name}: N={N} A={A} D={D} K={K} codes used={len(np.unique(idx))} min rel top-2 gap={rel.min():.3e} "
+          f"rows with gap < 1e-6: {int((rel < 1e-6).sum())}")
+
+
+def run_nearties(ref, name, seed, N, K, D, chunk):
+    """The reference quantizer (LFQQuantizer.forward, v5:37-48) on adversarial near-tie rows (oracle.make_neartie_case);
+    inputs are re-drawn from the seed by the tests, the fixture keeps the reference's indices and top-2 distances."""
+    z, cb = O.make_neartie_case(seed, N, K, D)
+    q = ref.LFQQuantizer(K, D)
+    idxs, d1s, d2s = [], [], []
+    with torch.no_grad():
+        q.codebook.copy_(torch.from_numpy(cb))
+        for s in range(0, N, chunk):
+            zt = torch.from_numpy(z[s:s + chunk])
+            _, idx = q(zt)
+            m = torch.clamp((2 * torch.sign(zt) + 1).unsqueeze(1), max=1)
+            a, b = top2(torch.norm(m * (zt.unsqueeze(1) - q.codebook.unsqueeze(0)), dim=-1))
+            idxs.append(idx), d1s.append(a), d2s.append(b)
+    idx = torch.cat(idxs).numpy()
+    d1, d2 = np.concatenate(d1s), np.concatenate(d2s)
+    np.savez_compressed(GOLD / f"{name}.npz", meta=meta_of(name=name, seed=seed, N=N, K=K, D=D, variant="llfq-nearties"),
+                        seed=seed, N=N, K=K, D=D, indices=idx.astype(np.uint16), d_best=d1, d_second=d2)
+    print(f"{name}: N={N} K={K} D={D} exact fp32 ties: {int((d1 == d2).sum())}, rel gap < 1e-6: "
+          f"{int(((d2 - d1) / np.maximum(d2, 1e-30) < 1e-6).sum())}")
+
+
+def run_big_all(v5, orc):
+    run_nearties(v5, "llfq_nearties_d128_k8192", 601, 1024, 8192, 128, chunk=32)
+    run_nearties(v5, "llfq_nearties_d208_k1024", 602, 2048, 1024, 208, chunk=128)
+    run_nearties(v5, "llfq_nearties_d64_k1024", 603, 2048, 1024, 64, chunk=256)
+    torch.set_num_threads(1)
+    run_llfq_big(v5, "llfq_cfg2_big", 501, 65536, 7, 64, 1024, chunk=256, oracle=orc)        # BASELINE config 2's widths
+    run_llfq_big(v5, "llfq_cfg3_big", 502, 4096, 7, 128, 8192, chunk=32, oracle=orc)         # BASELINE config 3's widths
+    run_llfq_big(v5, "llfq_icrt_big", 503, 16384, 12, 208, 1024, chunk=128, oracle=orc)      # the reference's own widths (v5:89-92)
+
+
 def run_vq(ref, name, seed, N, A, D, K, regime="trained", oracle=None):
     p = O.make_params(seed, A, D, K, regime=regime, variant="vq", oracle=oracle)
     x_np = O.make_inputs(seed, N, A)
@@ -307,6 +372,7 @@ def main():
     ap.add_argument("--only-edge", action="store_true")
     ap.add_argument("--only-embed", action="store_true")
     ap.add_argument("--only-bin", action="store_true")
+    ap.add_argument("--only-big", action="store_true")
     args = ap.parse_args()
     if args.only_embed:
         GOLD.mkdir(parents=True, exist_ok=True)
@@ -322,6 +388,8 @@ def main():
         return run_init(v5, vq)
     if args.only_edge:
         return run_nearest_edge(v5, "llfq_nearest_edge")
+    if args.only_big:
+        return run_big_all(v5, O.CanonicalOracle())
     torch.set_num_threads(1)       # what the reference's train() sets (scripts/train.py:57)
     orc = O.CanonicalOracle()
     # BASELINE config 1 (CPU plumbing case), full fwd + bwd + AdamW
@@ -348,6 +416,7 @@ def main():
     run_init(v5, vq)
     run_embed_all()
     run_bin_all(ref_root)
+    run_big_all(v5, orc)
 
 
 def run_init(v5, vq):

@@ -624,6 +624,20 @@ def make_params(seed, A, D, K, hidden=128, regime="trained", variant="llfq", ora
     return p
 
 
+def make_neartie_case(seed, N, K, D):
+    """Adversarial quantizer inputs: every row sits on (or within +-4e-8 of) the bisector of two random codes, with the
+    codebook in the trained regime's range -- rows whose two best codes are (nearly) equidistant, which only the exact
+    arithmetic of the reference decides (tests/golden/llfq_nearties_*.npz hold the reference's answers).
+    numpy PCG64 only: identical on every machine."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    cb = rng.uniform(0.0, 1.0, (K, D)).astype(np.float32)
+    a = rng.integers(0, K, N)
+    b = (a + 1 + rng.integers(0, K - 1, N)) % K
+    t = (np.float32(0.5) + ((np.arange(N) % 9) - 4).astype(np.float32) * np.float32(1e-8)).astype(np.float32)[:, None]
+    z = (cb[a] * t + cb[b] * (np.float32(1.0) - t)).astype(np.float32)
+    return z, cb
+
+
 def params_digest(p):
     h = hashlib.sha256()
     for k in sorted(p):

@@ -49,6 +49,12 @@ def _worker(rank, port, out_dir):
         tok = _OracleTokenizer(p, K)
         st = sharded.ShardedTokenizer(tok)
         idx, z = st.tokenize(x)
+        usage_after_one = tok.code_usage.clone()
+        # a second batch through the same (cumulative) histogram: only its delta may cross the ranks
+        x2 = torch.from_numpy(O.make_inputs(22, B * T, A)).reshape(B, T, A)
+        st.tokenize(x2)
+        usage_after_two = tok.code_usage.clone()
+        tok.code_usage = usage_after_one.clone()
         s, e = sharded.shard_bounds(B, rank, WORLD)
         assert idx.shape == (e - s, T) and z.shape == (e - s, T, D)
         # gradients of the global-mean loss from per-shard gradients
@@ -68,6 +74,7 @@ def _worker(rank, port, out_dir):
         sharded.all_reduce_ema_stats(counts, dw)
         ema_cs, ema_es, ema_cb = orc.ema_update(np.zeros(K, np.float32), p["quantizer.codebook"], counts.numpy(), dw.numpy())
         np.savez(Path(out_dir) / f"rank{rank}.npz", idx=idx.numpy(), usage=tok.code_usage.numpy(), ema_cb=ema_cb,
+                 usage2=usage_after_two.numpy(),
                  ema_counts=counts.numpy(), **{"g/" + k: prm.grad.numpy() for prm, k in zip(params, O.LLFQ_KEYS)})
     finally:
         dist.destroy_process_group()
@@ -86,6 +93,10 @@ def test_two_rank_sharding_usage_and_gradients(tmp_path, oracle):
     assert np.array_equal(np.concatenate([r0["idx"].reshape(-1), r1["idx"].reshape(-1)]), full["indices"])
     assert np.array_equal(r0["usage"], full["usage"]) and np.array_equal(r1["usage"], full["usage"])
     assert int(r0["usage"].sum()) == B * T
+    # two calls: the cumulative histogram is the single-process histogram of both batches, on every rank
+    full2 = oracle.llfq_forward(p, O.make_inputs(22, B * T, A))
+    assert np.array_equal(r0["usage2"], full["usage"] + full2["usage"]) and np.array_equal(r1["usage2"], r0["usage2"])
+    assert int(r0["usage2"].sum()) == 2 * B * T
     # weighted flat all-reduce == gradient of the loss over the whole batch, identical on both ranks
     # (holds for every term that is a mean over rows; the codebook term too, since scatter-add is linear)
     # EMA statistics: global counts on both ranks; the updated codebook equals the single-process update

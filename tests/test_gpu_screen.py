@@ -99,6 +99,44 @@ def test_near_ties_go_to_exact_kernel(ops, oracle):
     assert int(ws[0]) > N // 2
 
 
+@pytest.mark.parametrize("name", ["llfq_nearties_d128_k8192", "llfq_nearties_d208_k1024", "llfq_nearties_d64_k1024"])
+def test_adversarial_near_ties_match_the_reference(ops, oracle, name, golden_dir):
+    """Bisector rows (+- k * 1e-8) at D = 128 / K = 8192, D = 208 / K = 1024 and D = 64 / K = 1024 against indices the
+    REFERENCE quantizer produced (oracle/gen_golden.py::run_nearties): the certified screen must hand (nearly) all of them
+    to the exact kernel and the answers must be the reference's, bit for bit -- through both quantizer routes."""
+    g = np.load(golden_dir / f"{name}.npz")
+    N, K, D = int(g["N"]), int(g["K"]), int(g["D"])
+    z, cb = O.make_neartie_case(int(g["seed"]), N, K, D)
+    ref = g["indices"].astype(np.int64)
+    cbd, zd = dev(cb), dev(z)
+    idx, zq, ws = ops.nearest_screened(zd, cbd, ops.nearest_prepare(cbd), return_workspace=True)
+    assert np.array_equal(idx.cpu().numpy(), ref)
+    assert np.array_equal(zq.cpu().numpy(), cb[ref])
+    assert int(ws[0]) >= (99 * N) // 100, "near-ties were certified by the approximate screen"
+    idx2, _ = ops.nearest_rows(zd, cbd)
+    assert np.array_equal(idx2.cpu().numpy(), ref)
+    idx3, _, _ = ops.nearest(zd, cbd)
+    assert np.array_equal(idx3.cpu().numpy(), ref)
+
+
+def test_small_but_nonzero_gaps_at_the_widest_latent(ops, oracle):
+    """D = 208 (26 fma roundings per accumulator in the reference's own sum): rows with relative top-2 gaps from ~1e-6 to a
+    few 1e-5 -- above exact ties, around the margin -- are decided exactly, and most of them by the exact kernel."""
+    rng = np.random.default_rng(77)
+    K, D, N = 1024, 208, 2048
+    cb = rng.uniform(0, 1, (K, D)).astype(np.float32)
+    z = np.empty((N, D), np.float32)
+    for n in range(N):
+        a, b = rng.choice(K, 2, replace=False)
+        t = np.float32(0.5 + (1 + n % 16) * 2e-7)          # relative gaps from ~1e-7 to a few 1e-6 around the fp32 noise of D = 208
+        z[n] = cb[a] * t + cb[b] * (np.float32(1) - t)
+    idx_ref, _, _ = oracle.nearest(z, cb)
+    cbd = dev(cb)
+    idx, _, ws = ops.nearest_screened(dev(z), cbd, ops.nearest_prepare(cbd), return_workspace=True)
+    assert np.array_equal(idx.cpu().numpy(), idx_ref)
+    assert int(ws[0]) > N // 2
+
+
 def test_fp16_overflow_guard(ops, oracle):
     """Codebook entries beyond the fp16 range: nothing may be certified, results still exact."""
     z, cb = _case(11, 300, 128, 32)

@@ -16,7 +16,11 @@ from oracle import lipvq_oracle as O
 
 GOLD = Path(__file__).resolve().parent / "golden"
 TOL = 1e-5
-LLFQ = sorted(Path(p).stem for p in glob.glob(str(GOLD / "llfq_*.npz")) if "nearest_edge" not in p)
+LLFQ = sorted(Path(p).stem for p in glob.glob(str(GOLD / "llfq_*.npz"))
+              if "nearest_edge" not in p and "nearties" not in p and not p.endswith("_big.npz"))
+NEARTIES = sorted(Path(p).stem for p in glob.glob(str(GOLD / "llfq_nearties_*.npz")))
+BIG = sorted(Path(p).stem for p in glob.glob(str(GOLD / "llfq_*_big.npz")))
+NEAR_TIE = 1e-6      # relative top-2 distance gap (in the reference's own fp32 distances) below which an index may differ
 VQ = sorted(Path(p).stem for p in glob.glob(str(GOLD / "vq_*.npz")))
 
 
@@ -39,6 +43,38 @@ def _check_indices(got, g):
 
 def test_fixture_inventory():
     assert len(LLFQ) >= 9 and len(VQ) >= 3 and (GOLD / "llfq_nearest_edge.npz").exists()
+    assert {"llfq_cfg2_big", "llfq_cfg3_big", "llfq_icrt_big"} <= set(BIG)
+
+
+def big_fixture(name, oracle):
+    """(params, x, reference indices int64, relative top-2 gap per row) of a full-size fixture the REFERENCE produced
+    (oracle/gen_golden.py::run_llfq_big).  Shared with tests/test_gpu_big_parity.py."""
+    g = np.load(GOLD / f"{name}.npz")
+    A, D, K, N = int(g["A"]), int(g["D"]), int(g["K"]), int(g["N"])
+    p = O.make_params(int(g["seed"]), A, D, K, regime="trained", oracle=oracle)
+    assert O.params_digest(p) == str(g["params_sha256"]), "parameter generator drifted from the fixture"
+    x = O.make_inputs(int(g["seed"]), N, A)
+    gap = (g["d_second"] - g["d_best"]) / np.maximum(g["d_second"], 1e-30)
+    return p, x, g["indices"].astype(np.int64), gap
+
+
+def assert_indices_match_reference(got, ref, gap, what):
+    """Exact, except rows whose REFERENCE top-2 relative gap is below NEAR_TIE; returns (mismatches, near-tie rows)."""
+    bad = np.nonzero(got != ref)[0]
+    near = int((gap < NEAR_TIE).sum())
+    assert (gap[bad] < NEAR_TIE).all(), (f"{what}: {bad.size} index mismatches vs the reference, "
+                                         f"{int((gap[bad] >= NEAR_TIE).sum())} of them not near-ties (gaps {gap[bad][:8]})")
+    return int(bad.size), near
+
+
+@pytest.mark.parametrize("name", BIG)
+def test_canonical_oracle_vs_reference_full_size(name, oracle):
+    """The canonical C oracle -- what the GPU is held to bit for bit at ANY size -- against the reference itself on
+    65 536 / 4 096 / 16 384 rows: indices exact except reference near-ties (none exist in these fixtures)."""
+    p, x, ref, gap = big_fixture(name, oracle)
+    r_idx, _, _ = oracle.nearest(oracle.llfq_encode(p, x), p["quantizer.codebook"])
+    mism, near = assert_indices_match_reference(r_idx, ref, gap, name)
+    print(f"{name}: {mism} mismatches, {near} reference near-tie rows of {ref.size}")
 
 
 @pytest.mark.parametrize("name", LLFQ)
@@ -119,3 +155,15 @@ def test_quantizer_edge_cases_exact(oracle):
     assert idx[70] == 50        # sqrt merge: code 51 has the smaller square, but both share one fp32 root -> lower index
     d = g["distances"]
     assert d[70, 50] == d[70, 51]
+
+
+@pytest.mark.parametrize("name", NEARTIES)
+def test_adversarial_near_ties_exact(name, oracle):
+    """Rows on the bisector of two codes (+- k * 1e-8), D = 64/128/208, K up to 8192: every row is a near-tie (hundreds are
+    exact fp32 ties), so only the reference's exact arithmetic -- 8-accumulator sum, sqrt, first minimum -- decides them.
+    The canonical quantizer must reproduce the REFERENCE's index on every row."""
+    g = np.load(GOLD / f"{name}.npz")
+    z, cb = O.make_neartie_case(int(g["seed"]), int(g["N"]), int(g["K"]), int(g["D"]))
+    idx, _, _ = oracle.nearest(z, cb)
+    assert np.array_equal(idx, g["indices"].astype(np.int64))
+    assert len(NEARTIES) >= 3
