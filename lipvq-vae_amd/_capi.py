@@ -17,7 +17,10 @@ from pathlib import Path
 # and streams handed over by PyTorch are only meaningful to the runtime that created them).
 import torch  # noqa: F401  (import order matters)
 
-_LIB_PATH = Path(__file__).resolve().parent / "_lipvq_hip.so"
+import os as _os
+
+# LIPVQ_HIP_LIBRARY: development hook (A/B builds of the same library, scripts/ab_build.sh); the product loads the in-tree build
+_LIB_PATH = Path(_os.environ.get("LIPVQ_HIP_LIBRARY") or (Path(__file__).resolve().parent / "_lipvq_hip.so"))
 
 ACT_NONE, ACT_GELU, ACT_SIGMOID, ACT_RELU = 0, 1, 2, 3
 DIST_NORM, DIST_SQSUM = 0, 1

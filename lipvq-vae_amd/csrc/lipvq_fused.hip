@@ -33,11 +33,10 @@
 #define FUSED_THREADS (FUSED_WAVES * 64)
 // LDS budget: the D = 128 instance holds 105 KB of weights, so its codebook stages are one tile deep
 #define FUSED_HIST_MAX 2048
-#ifdef LQ_OPT_TC
-constexpr int fused_tc(int S) { return (S <= 4) ? LQ_OPT_TC : 1; }
-#else
-constexpr int fused_tc(int S) { return (S <= 2) ? 8 : (S <= 4) ? 4 : 1; }
-#endif
+// stage ring of the fused kernel (LDS left beside the encoder weights): S <= 4: four buffers of two/four tiles; S = 8: the
+// weights take 98 KB, three buffers of one tile
+constexpr int fused_ring_tc(int S) { return (S <= 2) ? 4 : (S <= 4) ? 2 : 1; }
+constexpr int fused_ring_nb(int S) { return (S <= 4) ? 4 : 3; }
 
 // lq_gelu_poly for two elements, cut into four stages so that one stage can follow each MFMA of a 4-MFMA group
 // (same operations in the same order as lq_gelu_poly: bit-identical values)
@@ -93,6 +92,7 @@ struct TokArgs {
 // percent of the indices differ, all between near-equidistant codes); everything after z_e is the parity path.
 template <int S, bool FAST>
 __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
+    constexpr int TCF = fused_ring_tc(S), NBF = fused_ring_nb(S);
     constexpr int T0 = 2, T1 = 4, T2 = S / 2;
     constexpr int S1 = 16 * T0, S2 = 16 * T1;               // k-steps (pairs) of layers 1 and 2
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -116,10 +116,13 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
     // per-workgroup usage histogram (K <= FUSED_HIST_MAX): LDS atomics per row, ONE global atomic per non-empty
     // bin at the end of this persistent workgroup -- skewed code distributions would otherwise serialise on a
     // few global addresses (see lq_usage_add)
-    unsigned* hist = reinterpret_cast<unsigned*>(stage0 + 2 * (size_t)ScreenCfg<S, fused_tc(S)>::STAGE_BYTES);
+    constexpr size_t STAGES_BYTES = lq_ring_bytes<S, TCF, NBF>();        // the ring + its dummy KiB
+    static_assert(STAGES_BYTES >= (size_t)FUSED_WAVES * 4096, "the decision's per-wave transposes live in the stage ring");
+    unsigned* hist = reinterpret_cast<unsigned*>(stage0 + ((STAGES_BYTES + 63) & ~(size_t)63));
     const bool use_hist = a.usage && a.K <= FUSED_HIST_MAX;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform (scalar row/address arithmetic)
     const int ln = lane & 31, h = lane >> 5;
 
     // ---- once per workgroup: weights (re-laid out 4 k-steps per 16-byte LDS read), biases, mu --------
@@ -163,7 +166,19 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
     const unsigned char* tiles = a.prep + L.o_tiles;
     const int64_t nblk = (a.N + FUSED_WAVES * 32 - 1) / (FUSED_WAVES * 32);
 
+#ifdef LQ_STAMPS
+    // diagnostic build only (scripts/stamps.py): per-wave cycles per segment, accumulated over the row blocks and written to
+    // the unused upper half of the row list; no output value depends on them
+    long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
+    const long long st_begin = __builtin_amdgcn_s_memtime();
+#define LQ_STAMP(i) do { const long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_prev; st_prev = t_; } while (0)
+#else
+#define LQ_STAMP(i) do { } while (0)
+#endif
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+#ifdef LQ_STAMPS
+        st_prev = __builtin_amdgcn_s_memtime();
+#endif
         const int64_t row0 = (blk * FUSED_WAVES + wave) * 32;
         const int64_t row = row0 + ln;
         const int64_t rowc = row < a.N ? row : a.N - 1;
@@ -242,6 +257,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) h0[t][r] = FUSED_GELU(h0[t][r]);
             }
+            LQ_STAMP(0);
             // ---- layer 1, software pipelined at source level: the GELU of tile t-1 is written between the MFMAs of tile t
             // (two elements per 4-MFMA group).  A 64-cycle fp32 MFMA leaves ~12 vector issue slots before its dependent
             // successor can start, so the polynomial (17 instructions per element) runs in the chain's shadow (ablation:
@@ -290,6 +306,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
 #endif
                 pend = acc;
             }
+            LQ_STAMP(1);
             // the last tile's GELU runs inside the first layer-2 chain: steps 0 .. 47 of that chain only read h1[0..2]
 #pragma unroll
             for (int t = 0; t < T2; ++t) {
@@ -383,6 +400,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
                 finish_tile(t, acc);
             }
         }
+        LQ_STAMP(2);
         n2 += __shfl_xor(n2, 32, 64);
         amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
         const int sz = lq_scale_exp(amax);                    // block floating point: see lipvq_screen.h
@@ -405,7 +423,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
         int k1[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { m1[r] = INFINITY; m2[r] = INFINITY; k1[r] = 0; }
-        lq_screen_core<S, FUSED_THREADS, fused_tc(S)>(ah, al, tiles, L.ntiles, stage0, tid, frow, m1, m2, k1);
+        LQ_STAMP(3);
+        lq_screen_core<S, FUSED_THREADS, TCF, NBF>(ah, al, tiles, L.ntiles, stage0, tid, frow, m1, m2, k1);
+        LQ_STAMP(4);
         int my_k;
         const bool certified = lq_screen_decide(m1, m2, k1, stage0 + (size_t)wave * 4096, hdr, n2, fown, a.gamma, a.K, a.D, lane, my_k);
         if (h == 0 && row < a.N) {
@@ -417,8 +437,19 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
             }
         }
         if (a.usage && !use_hist) lq_usage_add(a.usage, my_k, h == 0 && row < a.N && certified);
+        LQ_STAMP(5);
         if (a.zq) lq_screen_gather(a.cb, a.zq, my_k, certified, row0, a.N, a.D, lane);
+        LQ_STAMP(6);
     }
+#ifdef LQ_STAMPS
+    if (lane == 0) {
+        long long* dbg = reinterpret_cast<long long*>(a.amb_list + (a.N / 2 & ~1)) + ((size_t)blockIdx.x * FUSED_WAVES + wave) * 16;
+        for (int i = 0; i < 7; ++i) dbg[i] = st_acc[i];
+        dbg[7] = 0;
+        dbg[8] = __builtin_amdgcn_s_memtime() - st_begin;
+        dbg[9] = st_begin;
+    }
+#endif
     if (use_hist) {
         __syncthreads();
         for (int i = tid; i < a.K; i += FUSED_THREADS) {
@@ -436,7 +467,8 @@ static size_t fused_lds_bytes(int A, int K) {
     size_t fl = FAST ? (size_t)T0 * S0h * 256 + (size_t)T1 * (2 * T0) * 256 + (size_t)T2 * (2 * T1) * 256
                      : (size_t)T0 * S0q * 256 + (size_t)T1 * 8 * 256 + (size_t)T2 * 16 * 256;
     fl += 32 * T0 + 32 * T1 + 32 * T2 + 16 * S;
-    return fl * sizeof(float) + 2 * (size_t)ScreenCfg<S, fused_tc(S)>::STAGE_BYTES + (K <= FUSED_HIST_MAX ? (size_t)K * 4 : 0);
+    const size_t ring = (lq_ring_bytes<S, fused_ring_tc(S), fused_ring_nb(S)>() + 63) & ~(size_t)63;
+    return fl * sizeof(float) + ring + (K <= FUSED_HIST_MAX ? (size_t)K * 4 : 0);
 }
 
 template <int S, bool FAST>

@@ -4,6 +4,8 @@
 #define LIPVQ_SCREEN_H_
 #include <hip/hip_fp16.h>
 
+#include <type_traits>
+
 #include "lipvq_common.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -35,27 +37,13 @@ __host__ __device__ static inline PrepLayout prep_layout(int K, int D) {
 
 
 // ------------------------------------------------------------------------------------------
-// The screening main loop, shared by screen_kernel (lipvq_screen.hip) and tokenize_kernel
-// (lipvq_fused.hip).  NT threads stream the prepared codebook through two LDS stage buffers of TC
-// column tiles; each wave multiplies its 32 rows (fp16 hi/lo A fragments ah/al) against every
-// tile and keeps, per accumulator register (= row) and lane (= code mod 32), the smallest d~, its
-// code, and the second smallest d~.
-//
-// Measured (same-box A/B builds, scripts/ablate.sh; LQ_ABL_* macros below are those timing-only builds):
-//  * the bare LDS-read + MFMA chain takes the same ~0.17 ms (cfg2) at 1, 2 or 4 waves per SIMD, with or without
-//    reading B fragments a tile ahead: it is the matrix pipe at ~1.2 PF/s executed (MFMA-dense clocks);
-//  * variants that did NOT pay: book-keeping tile t-1 between the MFMAs of tile t in the same wave (VALU issue
-//    delays the dependent chain; the SIMD's other wave already fills those slots), deferring half the waves by
-//    one tile (helped with register-staged copies, hurt once staging became DMA), sched_group_barrier, 3-4
-//    waves per SIMD in the fused kernel (spills).
-// ------------------------------------------------------------------------------------------
 // Block floating point for the fp16 split (tests/test_gpu_screen.py::test_any_magnitude):  x = hi + lo carries 22
 // significant bits only while lo is a NORMAL fp16 number, i.e. |x| >= 2^-3.  So operands are multiplied by exact
 // powers of two before the split: the codebook by 2^se (global, max |-2e'| lands in [2^13, 2^14)), every latent row
 // by its own 2^sz (row max in [2^13, 2^14)).  Elements below 2^-17 of their row/codebook maximum then lose bits,
 // which is 2^-39 of that maximum -- negligible.  The MFMA result is in units of 2^(sz+se); since the argmin only
-// compares values of ONE row, the bookkeeping simply runs in those units (|e'|^2 is scaled on accumulator
-// initialisation) and the certification threshold is scaled the same way.
+// compares values of ONE row, the bookkeeping simply runs in those units (|e'|^2 is scaled when the bookkeeping adds
+// it) and the certification threshold is scaled the same way.
 __device__ __forceinline__ int lq_scale_exp(float maxabs) {
     // 2^k with maxabs * 2^k in [2^13, 2^14); clamped so that the factor stays an ordinary float
     const int e = (int)((__float_as_uint(maxabs) >> 23) & 0xff) - 127;       // floor(log2) for normal numbers
@@ -80,13 +68,26 @@ struct ScreenCfg {
     static constexpr int STAGE_VEC = STAGE_BYTES / 16;
 };
 
-__device__ __forceinline__ void lq_track(const f32x16& acc, int code, float (&m1)[16], float (&m2)[16], int (&k1)[16]) {
+// the stand-alone screen kernel: at most 80 KiB of stage ring, so that two workgroups share a CU
+template <int S>
+struct StandaloneScreen {
+    static constexpr int TC = (S <= 2) ? 4 : (S <= 4) ? 2 : 1;
+    static constexpr int NB = (S <= 8) ? 4 : 3;
+};
+
+// Bookkeeping of registers [lo, hi) of a finished 32 x 32 tile of d~ - |e'|^2 f (the chain starts from zero; the |e'|^2
+// term of the lane's code is added here, one fma per element, off the MFMA chain's critical path): per row (register)
+// and lane (code mod 32) the smallest value, its code and the second smallest.
+template <int LO, int HI>
+__device__ __forceinline__ void lq_track_part(const f32x16& acc, float e2, const float (&frow)[16], int code,
+                                              float (&m1)[16], float (&m2)[16], int (&k1)[16]) {
 #ifdef LQ_ABL_NOTRACK
-    m1[0] = fminf(m1[0], acc[0] + acc[5] + acc[10] + acc[15]); return;   // keeps the MFMAs alive
+    if (LO == 0) m1[0] = fminf(m1[0], acc[0] + acc[5] + acc[10] + acc[15]);   // keeps the MFMAs alive
+    return;
 #endif
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float v = acc[r];
+    for (int r = LO; r < HI; ++r) {
+        const float v = lq_fma(e2, frow[r], acc[r]);
         const bool lt = v < m1[r];              // one compare feeds both selects (fminf would cost two
         k1[r] = lt ? code : k1[r];              // NaN-canonicalising v_max as well)
         m2[r] = __builtin_amdgcn_fmed3f(v, m1[r], m2[r]);
@@ -94,74 +95,212 @@ __device__ __forceinline__ void lq_track(const f32x16& acc, int code, float (&m1
     }
 }
 
-template <int S, int NT, int TC_ = screen_default_tc(S)>
+// the pending tile's registers that are booked behind MFMA j of the 3 S MFMAs of the running tile: [16 j / 3S, 16 (j + 1) / 3S)
+// (j a compile-time constant after unrolling)
+template <int S>
+__device__ __forceinline__ void lq_track_after_mfma(int j, const f32x16& acc, float e2, const float (&frow)[16], int code,
+                                                    float (&m1)[16], float (&m2)[16], int (&k1)[16]) {
+#ifdef LQ_ABL_NOTRACK
+    if (j == 0) m1[0] = fminf(m1[0], acc[0] + acc[5] + acc[10] + acc[15]);
+    return;
+#endif
+    const int lo = (16 * j) / (3 * S), hi = (16 * (j + 1)) / (3 * S);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if (r >= lo && r < hi) {
+            const float v = lq_fma(e2, frow[r], acc[r]);
+            const bool lt = v < m1[r];
+            k1[r] = lt ? code : k1[r];
+            m2[r] = __builtin_amdgcn_fmed3f(v, m1[r], m2[r]);
+            m1[r] = lt ? v : m1[r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The screening main loop, shared by screen_kernel (lipvq_screen.hip) and tokenize_kernel (lipvq_fused.hip).
+// NT threads stream the prepared codebook through a ring of NB LDS stage buffers of TC column tiles each; every wave
+// multiplies its 32 rows (fp16 hi/lo A fragments ah/al) against every tile and keeps, per accumulator register (= row)
+// and lane (= code mod 32), the smallest d~, its code, and the second smallest d~.
+//
+// What in-kernel cycle stamps showed about the first version of this loop (scripts/stamps.py, round 2; 256 tiles per wave
+// at BASELINE config 2: 98 k cycles of MFMA issue, 380-520 k cycles measured): hipcc read each k-step's two B fragments
+// right before the three MFMAs that use them and waited for the LDS round trip four times per tile; the 80 bookkeeping
+// instructions of a tile ran after its chain; and a quarter of the loop was spent waiting, at the per-stage barrier, for a
+// stage copy issued only one stage earlier.  Hence:
+//  * B fragments (and |e'|^2) are read TWO k-steps ahead of the MFMAs that use them (ring of three fragment pairs);
+//  * the bookkeeping of tile t-1 (16/S registers per k-step) is issued between the MFMAs of tile t -- a wave's own vector
+//    instructions do run beside its fp16 MFMAs (scripts/probe/probe_pipes2.hip: four per MFMA are free; beside an fp32
+//    MFMA none are) -- the two chains alternate between two named accumulators, so nothing is copied;
+//  * a chain starts from C = 0 and |e'|^2 f is added by the bookkeeping (no accumulator initialisation on the chain);
+//  * stage copies run NB - 1 stages ahead (LDS-DMA stays in flight across barriers: raw s_barrier and COUNTED vmcnt, never
+//    __syncthreads, which drains it); the wait for stage st+1, the barrier and the issue of stage st+NB-1 sit in the MIDDLE
+//    of stage st, so that the last k-steps of a stage can already read the next stage's first fragments.
+// ------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void lq_wait_vmcnt() {            // all but the N youngest vector-memory operations of this wave are done
+    static_assert(N >= 0 && N < 64, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void lq_wg_barrier() {             // LDS accesses of this wave done, then the workgroup barrier (no vmcnt drain)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// LDS the ring needs: NB stage buffers + 1 KiB that absorbs the copies issued for stages past the end
+template <int S, int TC_, int NB>
+constexpr size_t lq_ring_bytes() { return (size_t)NB * ScreenCfg<S, TC_>::STAGE_BYTES + 1024; }
+
+template <int S, int NT, int TC_ = screen_default_tc(S), int NB = 4>
 __device__ __forceinline__ void lq_screen_core(const f16x8 (&ah)[S], const f16x8 (&al)[S],
                                                const unsigned char* __restrict__ tiles, int ntiles,
                                                unsigned char* stage0, int tid, const float (&frow)[16],
                                                float (&m1)[16], float (&m2)[16], int (&k1)[16]) {
     using C = ScreenCfg<S, TC_>;
-    constexpr int VPT = (C::STAGE_VEC + NT - 1) / NT;
+    static_assert(NB >= 2 && NB <= 4, "ring of 2..4 stage buffers");
+    constexpr int NW = NT / 64;
+    constexpr int CHUNKS = (C::STAGE_BYTES + 1023) / 1024;          // 1 KiB = one wave-instruction of the LDS-DMA
+    constexpr int CPW = (CHUNKS + NW - 1) / NW;                       // DMA instructions per wave and stage: the SAME for every wave
+    constexpr int PD = NB - 1;                                        // stages in flight ahead of the one being read
+    constexpr int NSTEP = C::TC * S;                                  // k-steps per stage
+    constexpr int MID = (C::TC >= 2) ? (C::TC / 2) * S : S / 2;       // the k-step in front of which the mid-stage hand-over sits
+    constexpr int PERIOD = ((C::TC & 1) || (NSTEP & 1)) ? 2 : 1;      // stages per loop trip: an even number of tiles and of k-steps
+    static_assert(C::STAGE_BYTES >= 1024 && C::STAGE_BYTES % 16 == 0, "stage copies are whole KiB pieces");
+    static_assert(NSTEP - 1 >= MID + 1 || NSTEP == 2, "next-stage fragments are read after the hand-over");
+    static_assert(CPW * PD < 64, "vmcnt immediate");
     const int lane = tid & 63, ln = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: DMA addresses stay scalar base + lane offset
 #ifdef LQ_ABL_NOLOOP
-    const int nstage = 0;            // ablation build only (scripts/ablate.sh)
+    const int nstage = 0;            // ablation build only
 #else
-    const int nstage = ntiles / C::TC;
+    const int nstage = ntiles / C::TC;                              // ntiles is a multiple of 8: nstage % PERIOD == 0
 #endif
-    // Stage copies go global -> LDS directly (global_load_lds_dwordx4: no VGPR round trip, no ds_write
-    // issue; ablation: the register-staged copy cost 84 us of a 440 us launch).  One wave-instruction
-    // moves 64 x 16 B to a wave-uniform LDS base + lane*16, which is exactly this linear copy.
+    unsigned char* dummy = stage0 + (size_t)NB * C::STAGE_BYTES;    // 1 KiB nobody reads
+    // Stage copies go global -> LDS directly (global_load_lds_dwordx4: no VGPR round trip, no ds_write issue).  One
+    // wave-instruction moves 64 x 16 B to a wave-uniform LDS base + lane*16.  Wave w copies KiB pieces w, w + NW, ...; the
+    // last piece of a stage is anchored at the stage's END (it overlaps its predecessor: same bytes), a wave whose piece
+    // index runs past the stage repeats the last piece, and a stage past the end of the codebook is "copied" as pieces of
+    // the first stage into the dummy KiB: EVERY wave issues exactly CPW full, unmasked instructions per call, so the loop
+    // body has no branch and the counted waits below mean the same thing in every wave at every stage.
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef const __attribute__((address_space(1))) void* glb_ptr_t;
     auto stage_dma = [&](int st, int buf) {
-        const unsigned char* src = tiles + (size_t)st * C::STAGE_BYTES;
-        unsigned char* dst = stage0 + (size_t)buf * C::STAGE_BYTES;
-        const int wbase = tid & ~63;                                     // first thread of this wave
-#pragma unroll
-        for (int v = 0; v < VPT; ++v) {
-            const int i = tid + v * NT;
-            if (i < C::STAGE_VEC)
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (size_t)i * 16),
-                                                 (lds_ptr_t)(dst + (size_t)(wbase + v * NT) * 16), 16, 0, 0);
-        }
-    };
-    __syncthreads();                              // earlier readers of the stage buffers are done
-    stage_dma(0, 0);
-    __syncthreads();                              // (drains the DMA: hipcc waits vmcnt(0) before the barrier)
-    for (int st = 0; st < nstage; ++st) {
 #ifndef LQ_ABL_NOSTAGE
-        if (st + 1 < nstage) stage_dma(st + 1, (st + 1) & 1);     // its last readers passed the previous barrier
-#endif
-#ifdef LQ_ABL_NOSTAGE
-        const unsigned char* sb = stage0;
-#else
-        const unsigned char* sb = stage0 + (size_t)(st & 1) * C::STAGE_BYTES;
-#endif
+        const bool real = st < nstage;
+        const unsigned char* src = tiles + (real ? (size_t)st * C::STAGE_BYTES : (size_t)0);
+        unsigned char* dst = stage0 + (size_t)buf * C::STAGE_BYTES;
 #pragma unroll
-        for (int c = 0; c < C::TC; ++c) {
-            const unsigned char* tb = sb + (size_t)c * C::TILE_BYTES;
-            const int code = (st * C::TC + c) * 32 + ln;
-            const float e2 = reinterpret_cast<const float*>(tb + S * 2048)[ln];
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = e2 * frow[r];      // |e'|^2 in the units of row (r, h)
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-#ifdef LQ_ABL_NOLDSB
-                const f16x8 bh = ah[(s + 1) % S], bl = al[(s + 1) % S];      // ablation only: no LDS fragment reads (wrong results)
-#else
-                const f16x8 bh = *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 0) * 64 + lane) * 16);
-                const f16x8 bl = *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 1) * 64 + lane) * 16);
-#endif
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl, acc, 0, 0, 0);
-            }
-            lq_track(acc, code, m1, m2, k1);
+        for (int j = 0; j < CPW; ++j) {
+            int chunk = wave + j * NW;
+            chunk = chunk < CHUNKS ? chunk : CHUNKS - 1;
+            int off = chunk * 1024;
+            off = off + 1024 <= C::STAGE_BYTES ? off : C::STAGE_BYTES - 1024;
+            unsigned char* d = real ? dst + off : dummy;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + off + lane * 16), (lds_ptr_t)d, 16, 0, 0);
         }
-#ifndef LQ_ABL_NOBARRIER
-        __syncthreads();
 #endif
+    };
+    auto frag = [&](const unsigned char* tb, int s, int hl) {
+        return *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + hl) * 64 + lane) * 16);
+    };
+    lq_wg_barrier();                              // earlier users of the stage buffers (previous row block) are done
+    // prologue: stages 0 .. PD-1 in flight, stage 0 landed
+#pragma unroll
+    for (int p = 0; p < PD; ++p) stage_dma(p, p);
+#ifndef LQ_ABL_NOSTAGE
+    lq_wait_vmcnt<(PD - 1) * CPW>();
+#endif
+    lq_wg_barrier();
+
+    // two named accumulators: the chain of tile i runs into one while the other (tile i-1) is booked
+    f32x16 accA, accB;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accB[r] = INFINITY;      // "no previous tile": INFINITY never beats anything
+    float e2A = 0.0f, e2B = 0.0f;
+    int codeA = 0, codeB = 0;
+    // fragment ring: slot ((g + so) & 1) holds k-step g of the current stage (g = NSTEP: k-step 0 of the next stage); so = 0,
+    // or the stage's position in the loop trip when NSTEP is odd
+    f16x8 fh[2], fl[2];
+    float e2q[2] = {0.0f, 0.0f};                  // |e'|^2 of the tile in accumulator A / B
+#ifndef LQ_ABL_NOLDSB
+    fh[0] = frag(stage0, 0, 0); fl[0] = frag(stage0, 0, 1);
+    e2q[0] = reinterpret_cast<const float*>(stage0 + S * 2048)[ln];
+#endif
+    int buf = 0;                                  // ring position of stage st
+    auto do_stage = [&](auto POS, int st) {
+        constexpr int par = (decltype(POS)::value * C::TC) & 1;    // 0: the stage's first tile runs into accA, 1: into accB
+        constexpr int so = (decltype(POS)::value * NSTEP) & 1;     // fragment slot of the stage's k-step 0
+        const unsigned char* sb = stage0 + (size_t)buf * C::STAGE_BYTES;
+        int nbuf = buf + 1; nbuf = nbuf == NB ? 0 : nbuf;
+        const unsigned char* nsb = stage0 + (size_t)nbuf * C::STAGE_BYTES;
+#pragma unroll
+        for (int g = 0; g < NSTEP; ++g) {
+            const int c = g / S, s = g % S;
+            if (g == MID) {
+                // ---- mid-stage hand-over: stage st+1 has landed everywhere (the PD-2 younger stages may still fly); everyone has
+                // left stage st-1, whose buffer is the one stage st+PD goes to
+#ifndef LQ_ABL_NOSTAGE
+                lq_wait_vmcnt<(PD >= 2 ? (PD - 2) * CPW : 0)>();
+#endif
+#ifndef LQ_ABL_NOBARRIER
+                lq_wg_barrier();
+#endif
+                int b = buf + PD; b = b >= NB ? b - NB : b;
+                stage_dma(st + PD, b);
+            }
+            f32x16& acc = (((c + par) & 1) == 0) ? accA : accB;
+            const f32x16& prev = (((c + par) & 1) == 0) ? accB : accA;
+            const float e2_prev = (((c + par) & 1) == 0) ? e2B : e2A;
+            const int code_prev = (((c + par) & 1) == 0) ? codeB : codeA;
+            if (s == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                const float e2c = e2q[(c + par) & 1];
+                const int code = (st * C::TC + c) * 32 + ln;
+                if (((c + par) & 1) == 0) { e2A = e2c; codeA = code; } else { e2B = e2c; codeB = code; }
+            }
+            const f16x8 bh = fh[(g + so) & 1], bl = fl[(g + so) & 1];
+#ifndef LQ_ABL_NOLDSB
+            // k-step g + 1 of this stage, or (g + 1 = NSTEP > MID: the hand-over has passed) k-step 0 of the next stage.
+            // Unconditional: behind the last stage it reads bytes of the ring that nobody uses (no branch in the loop body).
+            {
+                const int g1 = g + 1;
+                const unsigned char* base = (g1 < NSTEP) ? sb : nsb;
+                const int gg = (g1 < NSTEP) ? g1 : 0;
+                const unsigned char* tb = base + (size_t)(gg / S) * C::TILE_BYTES;
+                fh[(g1 + so) & 1] = frag(tb, gg % S, 0);
+                fl[(g1 + so) & 1] = frag(tb, gg % S, 1);
+                if (gg % S == 0) e2q[(g1 / S + par) & 1] = reinterpret_cast<const float*>(tb + S * 2048)[ln];   // g1 / S = TC: next stage
+            }
+#endif
+            // pinned order: reads, then (MFMA, its share of the pending tile's bookkeeping) x 3 -- left alone, hipcc lumps the
+            // bookkeeping behind the chain, where nothing hides it
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh, acc, 0, 0, 0);
+            lq_track_after_mfma<S>(3 * s + 0, prev, e2_prev, frow, code_prev, m1, m2, k1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh, acc, 0, 0, 0);
+            lq_track_after_mfma<S>(3 * s + 1, prev, e2_prev, frow, code_prev, m1, m2, k1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl, acc, 0, 0, 0);
+            lq_track_after_mfma<S>(3 * s + 2, prev, e2_prev, frow, code_prev, m1, m2, k1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        buf = nbuf;
+    };
+    for (int st = 0; st < nstage; st += PERIOD) {
+        do_stage(std::integral_constant<int, 0>{}, st);
+        if constexpr (PERIOD == 2) do_stage(std::integral_constant<int, 1>{}, st + 1);
     }
+    // the last tile's chain: ntiles is even, so it ran into accB
+    lq_track_part<0, 16>(accB, e2B, frow, codeB, m1, m2, k1);
+    // the copies issued for stages past the end go to the dummy KiB, but they count: drain them, then every wave has left
+    // the stage buffers (the callers reuse them as per-wave scratch: lq_screen_decide)
+#ifndef LQ_ABL_NOSTAGE
+    lq_wait_vmcnt<0>();
+#endif
+    lq_wg_barrier();
 }
 
 // frow[r] = factor of row (r, h) = the row this lane's accumulator register r belongs to, fetched from the lane that

@@ -124,13 +124,15 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
     int64_t* __restrict__ idx, float* __restrict__ zq, unsigned long long* __restrict__ usage,
     int* __restrict__ amb_list, int* __restrict__ amb_count, float* __restrict__ dbg, int64_t N, int K, int D,
     float gamma) {
-    using C = ScreenCfg<S>;
+    using SC = StandaloneScreen<S>;
+    using C = ScreenCfg<S, SC::TC>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const PrepLayout L = prep_layout(K, D);
     const unsigned* hdr = reinterpret_cast<const unsigned*>(prep);
     const float* mu = reinterpret_cast<const float*>(prep + L.o_mu);
     const unsigned char* tiles = prep + L.o_tiles;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ln = lane & 31, h = lane >> 5;
     const int64_t row0 = ((int64_t)blockIdx.x * SCREEN_WAVES + wave) * 32;
     const int64_t row = row0 + ln;
@@ -181,9 +183,9 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
         for (int ct = 0; ct < L.ntiles; ++ct) {
             const unsigned char* tb = tiles + (size_t)ct * C::TILE_BYTES;
             const float e2 = reinterpret_cast<const float*>(tb + S * 2048)[ln];
-            f32x16 acc;
+            f32x16 acc;                                   // same arithmetic as lq_screen_core: chain from zero, |e'|^2 f added last
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = e2 * frow[r];
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 const f16x8 bh = *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 0) * 64 + lane) * 16);
@@ -197,13 +199,13 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int64_t rr = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (rr < N) dbg[(size_t)rr * L.Kpad + code] = acc[r] / frow[r];      // back to unscaled units
+                    if (rr < N) dbg[(size_t)rr * L.Kpad + code] = lq_fma(e2, frow[r], acc[r]) / frow[r];      // back to unscaled units
                 }
             }
-            lq_track(acc, code, m1, m2, k1);
+            lq_track_part<0, 16>(acc, e2, frow, code, m1, m2, k1);
         }
     } else {
-        lq_screen_core<S, SCREEN_WAVES * 64>(ah, al, tiles, L.ntiles, lds, tid, frow, m1, m2, k1);
+        lq_screen_core<S, SCREEN_WAVES * 64, SC::TC, SC::NB>(ah, al, tiles, L.ntiles, lds, tid, frow, m1, m2, k1);
     }
     int my_k;
     const bool certified = lq_screen_decide(m1, m2, k1, lds + (size_t)wave * 4096, hdr, n2, fown, gamma, K, D, lane, my_k);
@@ -453,8 +455,9 @@ template <int S>
 static int launch_screen(const float* z, const unsigned char* prep, const float* cb, int64_t* idx, float* zq,
                          int64_t* usage, int* amb_list, int* amb_count, float* dbg, int64_t N, int K, int D,
                          float gamma, hipStream_t st) {
-    using C = ScreenCfg<S>;
-    size_t lds = (size_t)2 * C::STAGE_BYTES;
+    using SC = StandaloneScreen<S>;
+    using C = ScreenCfg<S, SC::TC>;
+    size_t lds = lq_ring_bytes<S, SC::TC, SC::NB>();
     if (lds < (size_t)SCREEN_WAVES * 4096) lds = (size_t)SCREEN_WAVES * 4096;      // per-wave transpose slices reuse the stages
     const int64_t rows_per_block = SCREEN_WAVES * 32;
     unsigned blocks = (unsigned)((N + rows_per_block - 1) / rows_per_block);
