@@ -117,7 +117,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
     // bin at the end of this persistent workgroup -- skewed code distributions would otherwise serialise on a
     // few global addresses (see lq_usage_add)
     constexpr size_t STAGES_BYTES = lq_ring_bytes<S, TCF, NBF>();        // the ring + its dummy KiB
-    static_assert(STAGES_BYTES >= (size_t)FUSED_WAVES * 4096, "the decision's per-wave transposes live in the stage ring");
+    static_assert(STAGES_BYTES >= (size_t)FUSED_WAVES * LQ_DECIDE_BYTES, "the decision's per-wave transposes live in the stage ring");
     unsigned* hist = reinterpret_cast<unsigned*>(stage0 + ((STAGES_BYTES + 63) & ~(size_t)63));
     const bool use_hist = a.usage && a.K <= FUSED_HIST_MAX;
 
@@ -152,9 +152,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
                 w_P2[i] = P2[((size_t)t * S2 + 4 * sq + q) * 64 + l];
             }
         }
-        for (int i = tid; i < 32 * T0; i += FUSED_THREADS) w_B0[i] = a.packed[PL.oB0 + i];
-        for (int i = tid; i < 32 * T1; i += FUSED_THREADS) w_B1[i] = a.packed[PL.oB1 + i];
-        for (int i = tid; i < 32 * T2; i += FUSED_THREADS) w_B2[i] = a.packed[PL.oB2 + i];
+        // biases re-laid out [t][h][r] = b[32 t + 2 r + h]: the 16 values of a lane's accumulator tile are 64 contiguous bytes
+        // (four 16-byte LDS reads, broadcast within the half-wave) instead of sixteen 4-byte reads
+        for (int i = tid; i < 32 * T0; i += FUSED_THREADS) w_B0[i] = a.packed[PL.oB0 + 32 * (i >> 5) + 2 * (i & 15) + ((i >> 4) & 1)];
+        for (int i = tid; i < 32 * T1; i += FUSED_THREADS) w_B1[i] = a.packed[PL.oB1 + 32 * (i >> 5) + 2 * (i & 15) + ((i >> 4) & 1)];
+        for (int i = tid; i < 32 * T2; i += FUSED_THREADS) w_B2[i] = a.packed[PL.oB2 + 32 * (i >> 5) + 2 * (i & 15) + ((i >> 4) & 1)];
         const float* mu = reinterpret_cast<const float*>(a.prep + L.o_mu);
         for (int i = tid; i < 16 * S; i += FUSED_THREADS) w_mu[i] = mu[i];
         if (use_hist)
@@ -175,6 +177,25 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
 #else
 #define LQ_STAMP(i) do { } while (0)
 #endif
+    // this lane's inputs of the NEXT row block (k = 2 q + h, q < XPF), fetched a whole screening phase ahead: the first version
+    // loaded each x value right in front of the MFMA that consumed it (four serialised HBM round trips per block)
+    constexpr int XPF = 8;                                   // fan-in up to 16 is prefetched; wider inputs load at block start
+    const bool x_pref = !FAST && a.A <= 2 * XPF;
+    float xq[XPF];
+    auto load_x = [&](int64_t blk_) {
+        int64_t r_ = (blk_ * FUSED_WAVES + wave) * 32 + ln;
+        r_ = r_ < a.N ? r_ : a.N - 1;
+        const int64_t last = a.N * a.A - 1;
+#pragma unroll
+        for (int q = 0; q < XPF; ++q) {
+            const int k = 2 * q + h;
+            int64_t i_ = r_ * a.A + k;
+            i_ = i_ < last ? i_ : last;                      // always a valid address; masked below (no divergent branch)
+            const float v = a.x[i_];
+            xq[q] = (k < a.A) ? v : 0.0f;
+        }
+    };
+    if (x_pref) load_x(blockIdx.x);
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
 #ifdef LQ_STAMPS
         st_prev = __builtin_amdgcn_s_memtime();
@@ -229,60 +250,113 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
 
         if constexpr (!FAST) {
             // ================= phase A: encoder + Lipschitz layer, fp32 MFMA ====================
-            f32x16 h0[T0];
-            {
-                const float* xr = a.x + (size_t)rowc * a.A;
-#pragma unroll
-                for (int t = 0; t < T0; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) h0[t][r] = w_B0[32 * t + 2 * r + h];
-                for (int sq = 0; sq < S0q; ++sq) {
-                    float4 av[T0];
-#pragma unroll
-                    for (int t = 0; t < T0; ++t) av[t] = *reinterpret_cast<const float4*>(w_P0 + ((t * S0q + sq) * 64 + lane) * 4);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int k = 2 * (4 * sq + q) + h;
-                        const float bv = (k < a.A) ? xr[k] : 0.0f;
-#pragma unroll
-                        for (int t = 0; t < T0; ++t) {
-                            const float aq = q == 0 ? av[t].x : q == 1 ? av[t].y : q == 2 ? av[t].z : av[t].w;
-                            // padded k-steps (s >= S0) multiply zeros: acc + 0*0 = acc (oracle pads odd fan-in the same way)
-                            h0[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq, bv, h0[t], 0, 0, 0);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int t = 0; t < T0; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) h0[t][r] = FUSED_GELU(h0[t][r]);
-            }
-            LQ_STAMP(0);
-            // ---- layer 1, software pipelined at source level: the GELU of tile t-1 is written between the MFMAs of tile t
-            // (two elements per 4-MFMA group).  A 64-cycle fp32 MFMA leaves ~12 vector issue slots before its dependent
-            // successor can start, so the polynomial (17 instructions per element) runs in the chain's shadow (ablation:
-            // GELU cost 87 us of a 407 us encoder-only launch when it ran after each chain).  The rare |x| >= sqrt(18)
-            // elements are fixed up behind a wave-uniform branch so that the pipelined region stays straight-line code.
-            f32x16 h1[T1];
-            f32x16 pend;                      // pre-activations of the previous tile, GELU pending
+            // An fp32 MFMA blocks its own wave's vector instructions for its whole duration (scripts/probe/probe_pipes2.hip:
+            // 64 + 8 + 4.4 n cycles for an MFMA followed by n independent v_fma), so GELU / sigmoid work cannot hide under
+            // the chain; what CAN be hidden is latency: the LDS reads of the weights (16 bytes per lane feed four MFMAs) and
+            // of the biases are issued one group ahead of the MFMAs that use them (sched_barrier keeps hipcc from sinking them
+            // back in front of their use, where it waits for each LDS round trip), and x comes from the prefetch above.
             auto gelu_fixup = [&](f32x16& out, const f32x16& pre) {
-                bool slow = false;
+                // largest |pre| of the tile by v_max3 (half an instruction per element instead of a multiply and a compare);
+                // a NaN is skipped by max3, but the polynomial has already turned it into a NaN, as the tail would
+                float mx = 0.0f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) slow |= !(pre[r] * pre[r] < 18.0f);
-                if (__builtin_amdgcn_ballot_w64(slow) != 0ull) {          // wave-uniform, practically never taken
+                for (int r = 0; r < 16; r += 2) asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(mx) : "v"(mx), "v"(pre[r]), "v"(pre[r + 1]));
+                if (__builtin_amdgcn_ballot_w64(!(mx * mx < 18.0f)) != 0ull) {          // wave-uniform, practically never taken
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         if (!(pre[r] * pre[r] < 18.0f)) out[r] = lq_gelu_tail(pre[r]);
                 }
             };
+            auto bias16 = [&](const float* wb, int t) {                   // the lane's 16 bias values of tile t (see the LDS fill)
+                f32x16 b;
+                const float4* p4 = reinterpret_cast<const float4*>(wb + (2 * t + h) * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const float4 v = p4[q]; b[4 * q] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w; }
+                return b;
+            };
+            f32x16 h0[T0];
+            {
+#pragma unroll
+                for (int t = 0; t < T0; ++t) h0[t] = bias16(w_B0, t);
+                if (x_pref) {
+#pragma unroll
+                    for (int sq = 0; sq < XPF / 4; ++sq) {
+                        if (sq < S0q) {                                    // wave-uniform
+                            float4 av[T0];
+#pragma unroll
+                            for (int t = 0; t < T0; ++t) av[t] = *reinterpret_cast<const float4*>(w_P0 + ((t * S0q + sq) * 64 + lane) * 4);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float bv = xq[4 * sq + q];
+#pragma unroll
+                                for (int t = 0; t < T0; ++t) {
+                                    const float aq = q == 0 ? av[t].x : q == 1 ? av[t].y : q == 2 ? av[t].z : av[t].w;
+                                    // padded k-steps (s >= S0) multiply zeros: acc + 0*0 = acc (oracle pads odd fan-in the same way)
+                                    h0[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq, bv, h0[t], 0, 0, 0);
+                                }
+                            }
+                        }
+                    }
+                } else {
+                    const float* xr = a.x + (size_t)rowc * a.A;
+                    for (int sq = 0; sq < S0q; ++sq) {
+                        float4 av[T0];
+                        float bvv[4];
+#pragma unroll
+                        for (int t = 0; t < T0; ++t) av[t] = *reinterpret_cast<const float4*>(w_P0 + ((t * S0q + sq) * 64 + lane) * 4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int k = 2 * (4 * sq + q) + h;
+                            bvv[q] = (k < a.A) ? xr[k] : 0.0f;
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int t = 0; t < T0; ++t) {
+                                const float aq = q == 0 ? av[t].x : q == 1 ? av[t].y : q == 2 ? av[t].z : av[t].w;
+                                h0[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq, bvv[q], h0[t], 0, 0, 0);
+                            }
+                    }
+                }
+                // GELU: the straight-line polynomial on every element, the rare |x| >= sqrt(18) ones fixed up behind a wave-uniform
+                // branch (lq_gelu's per-element branch cost a divergent-branch sequence per value)
+#pragma unroll
+                for (int t = 0; t < T0; ++t) {
+                    const f32x16 pre = h0[t];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+#ifndef LQ_ABL_NOGELU
+                        h0[t][r] = lq_gelu_poly(pre[r]);
+#endif
+                    }
+#ifndef LQ_ABL_NOGELU
+                    gelu_fixup(h0[t], pre);
+#endif
+                }
+            }
+            LQ_STAMP(0);
+            // ---- layers 1 and 2: one stream of 16-byte weight reads (T1 S1/4 of layer 1, then T2 S2/4 of layer 2), each read
+            // issued one 4-MFMA group ahead of its use.  The GELU of tile t-1 is written between the MFMAs of tile t (two
+            // elements per group): it cannot overlap the MFMAs (see above), but it keeps the polynomial out of a lumped
+            // 16 x 17-instruction block behind each chain.
+            f32x16 h1[T1];
+            f32x16 pend;                      // pre-activations of the previous tile, GELU pending
+            constexpr int G1 = S1 / 4, G2 = S2 / 4;             // groups per tile
+            auto wread = [&](int gidx) {                        // group gidx of the stream (compile-time after unrolling)
+                return (gidx < T1 * G1) ? *reinterpret_cast<const float4*>(w_P1 + (gidx * 64 + lane) * 4)
+                                        : *reinterpret_cast<const float4*>(w_P2 + ((gidx - T1 * G1) * 64 + lane) * 4);
+            };
+            float4 wn = wread(0);
+            f32x16 bnext = bias16(w_B1, 0);
 #pragma unroll
             for (int t = 0; t < T1; ++t) {
-                f32x16 acc;
+                f32x16 acc = bnext;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = w_B1[32 * t + 2 * r + h];
-#pragma unroll
-                for (int sq = 0; sq < S1 / 4; ++sq) {
-                    const float4 av = *reinterpret_cast<const float4*>(w_P1 + ((t * (S1 / 4) + sq) * 64 + lane) * 4);
+                for (int sq = 0; sq < G1; ++sq) {
+                    const float4 av = wn;
+                    wn = wread(t * G1 + sq + 1);                 // the next group's weights (layer 2's first group after the last)
+                    if (sq == G1 - 1) bnext = (t + 1 < T1) ? bias16(w_B1, t + 1) : bias16(w_B2, 0);
+                    __builtin_amdgcn_sched_barrier(0x6);         // reads stay in front of this group's MFMAs (VALU/SALU may move)
                     Gelu2 g;
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, h0[(4 * sq + 0) / 16][(4 * sq + 0) % 16], acc, 0, 0, 0);
                     if (t > 0) g.stage0(pend[2 * sq], pend[2 * sq + 1]);
@@ -300,6 +374,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
                         h1[t - 1][2 * sq] = pend[2 * sq]; h1[t - 1][2 * sq + 1] = pend[2 * sq + 1];
 #endif
                     }
+                    __builtin_amdgcn_sched_barrier(0x6);
                 }
 #ifndef LQ_ABL_NOGELU
                 if (t > 0) gelu_fixup(h1[t - 1], pend);
@@ -310,18 +385,19 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
             // the last tile's GELU runs inside the first layer-2 chain: steps 0 .. 47 of that chain only read h1[0..2]
 #pragma unroll
             for (int t = 0; t < T2; ++t) {
-                f32x16 acc;
+                f32x16 acc = bnext;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = w_B2[32 * t + 2 * r + h];
-#pragma unroll
-                for (int sq = 0; sq < S2 / 4; ++sq) {
+                for (int sq = 0; sq < G2; ++sq) {
                     if (t == 0 && sq == 3 * (S2 / 16)) {
                         // h1[T1-1] is needed from here on (k-steps 48..63 of a 128-wide layer): finish its GELU
 #ifndef LQ_ABL_NOGELU
                         gelu_fixup(h1[T1 - 1], pend);
 #endif
                     }
-                    const float4 av = *reinterpret_cast<const float4*>(w_P2 + ((t * (S2 / 4) + sq) * 64 + lane) * 4);
+                    const float4 av = wn;
+                    if (t * G2 + sq + 1 < T2 * G2) wn = wread(T1 * G1 + t * G2 + sq + 1);
+                    if (sq == G2 - 1 && t + 1 < T2) bnext = bias16(w_B2, t + 1);
+                    __builtin_amdgcn_sched_barrier(0x6);
                     const bool pg = (t == 0 && sq < 8);          // the 16 pending GELUs ride on groups 0..7 (< 12: they only read h1[0..2])
                     Gelu2 g;
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, h1[(4 * sq + 0) / 16][(4 * sq + 0) % 16], acc, 0, 0, 0);
@@ -340,6 +416,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
                         h1[T1 - 1][(2 * sq) & 15] = pend[(2 * sq) & 15]; h1[T1 - 1][(2 * sq + 1) & 15] = pend[(2 * sq + 1) & 15];
 #endif
                     }
+                    __builtin_amdgcn_sched_barrier(0x6);
                 }
                 finish_tile(t, acc);
             }
@@ -354,7 +431,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
 #pragma unroll
             for (int t = 0; t < T0; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) h0[t][r] = w_B0[32 * t + 2 * r + h];
+                for (int r = 0; r < 16; ++r) h0[t][r] = w_B0[(2 * t + h) * 16 + r];
             for (int s2 = 0; s2 < S0h; ++s2) {
                 f16x8 bx;
 #pragma unroll
@@ -378,7 +455,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
             for (int t = 0; t < T1; ++t) {
                 f32x16 acc;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = w_B1[32 * t + 2 * r + h];
+                for (int r = 0; r < 16; ++r) acc[r] = w_B1[(2 * t + h) * 16 + r];
 #pragma unroll
                 for (int s2 = 0; s2 < 2 * T0; ++s2) {
                     const f16x8 av = *reinterpret_cast<const f16x8*>(wh1 + ((size_t)(t * (2 * T0) + s2) * 64 + lane) * 8);
@@ -391,7 +468,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
             for (int t = 0; t < T2; ++t) {
                 f32x16 acc;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = w_B2[32 * t + 2 * r + h];
+                for (int r = 0; r < 16; ++r) acc[r] = w_B2[(2 * t + h) * 16 + r];
 #pragma unroll
                 for (int s2 = 0; s2 < 2 * T1; ++s2) {
                     const f16x8 av = *reinterpret_cast<const f16x8*>(wh2 + ((size_t)(t * (2 * T1) + s2) * 64 + lane) * 8);
@@ -424,10 +501,14 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { m1[r] = INFINITY; m2[r] = INFINITY; k1[r] = 0; }
         LQ_STAMP(3);
-        lq_screen_core<S, FUSED_THREADS, TCF, NBF>(ah, al, tiles, L.ntiles, stage0, tid, frow, m1, m2, k1);
+        if (x_pref) load_x(blk + gridDim.x < nblk ? blk + gridDim.x : blk);      // next row block's inputs: a whole phase ahead
+        constexpr bool PACKF = LQ_PACK_FOR(S);
+        lq_screen_core<S, FUSED_THREADS, TCF, NBF, PACKF>(ah, al, tiles, L.ntiles, stage0, tid, frow, m1, m2, k1);
         LQ_STAMP(4);
         int my_k;
-        const bool certified = lq_screen_decide(m1, m2, k1, stage0 + (size_t)wave * 4096, hdr, n2, fown, a.gamma, a.K, a.D, lane, my_k);
+        const bool certified = lq_screen_decide<PACKF>(m1, m2, k1, stage0 + (size_t)wave * LQ_DECIDE_BYTES, hdr, n2, fown, a.gamma, a.K,
+                                                       a.D, lane, my_k, PACKF ? lq_pow2f(lq_pack_bits(L.ntiles) - 23) : 0.0f,
+                                                       PACKF ? ~((1u << lq_pack_bits(L.ntiles)) - 1u) : 0xffffffffu);
         if (h == 0 && row < a.N) {
             if (certified) {
                 a.idx[row] = (int64_t)my_k;

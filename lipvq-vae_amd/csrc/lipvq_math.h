@@ -145,7 +145,31 @@ LQ_HD float lq_gelu_grad(float x) {
     return lq_fma(x, pdf, cdf);
 }
 
-LQ_HD float lq_sigmoid(float x) { return 1.0f / (1.0f + lq_expf(-x)); }
+/* torch.sigmoid: 1 / (1 + exp(-x)), straight-line (the fused kernel evaluates it 16 times per accumulator tile: lq_expf's two
+ * early returns cost a divergent-branch sequence per value).  The argument of exp is clamped to [-87, 87], where exp stays
+ * a NORMAL fp32 number: one exact scaling by 2^n instead of lq_expf's two, same polynomial, hence the same bits as
+ * 1 / (1 + lq_expf(-x)) for |x| <= 87; beyond, the result is 1 or below 2e-38 either way.  NaN propagates (a NaN fails both
+ * clamp comparisons and poisons p). */
+LQ_HD float lq_sigmoid(float x) {
+    float t = -x;
+    t = (t > 87.0f) ? 87.0f : t;
+    t = (t < -87.0f) ? -87.0f : t;
+    const float magic = 12582912.0f;         /* 1.5 * 2^23 */
+    const float nf = lq_fma(t, 1.44269504088896341f, magic);
+    const uint32_t nb = lq_f2u(nf) - 0x4B400000u + 127u;          /* rint(t / ln 2) + 127 from the low mantissa bits: in [1, 253] */
+    const float n = nf - magic;
+    float r = lq_fma(n, -0.693145751953125f, t);
+    r = lq_fma(n, -1.42860682030941723e-6f, r);
+    float q = 0.00019907570094801486f;
+    q = lq_fma(q, r, 0.0013933652080595493f);
+    q = lq_fma(q, r, 0.00833328627049923f);
+    q = lq_fma(q, r, 0.04166646674275398f);
+    q = lq_fma(q, r, 0.1666666716337204f);
+    q = lq_fma(q, r, 0.5f);
+    const float p = lq_fma(r * r, q, r) + 1.0f;
+    const float e = p * lq_u2f(nb << 23);
+    return 1.0f / (1.0f + e);
+}
 
 /* log(u) for finite u >= 1 (only use: softplus). */
 LQ_HD float lq_logf_ge1(float u) {

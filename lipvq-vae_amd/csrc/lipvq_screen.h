@@ -68,53 +68,70 @@ struct ScreenCfg {
     static constexpr int STAGE_VEC = STAGE_BYTES / 16;
 };
 
+// PACK bookkeeping (tile index in the low mantissa bits, lq_track_one) where the bookkeeping is the bottleneck: few MFMAs per
+// tile (S <= 4: 12 or fewer MFMAs against 80 bookkeeping instructions); wider latents hide it under 24+ MFMAs
+#ifndef LQ_PACK_FOR
+#define LQ_PACK_FOR(S) ((S) <= 4)
+#endif
 // the stand-alone screen kernel: at most 80 KiB of stage ring, so that two workgroups share a CU
 template <int S>
 struct StandaloneScreen {
     static constexpr int TC = (S <= 2) ? 4 : (S <= 4) ? 2 : 1;
     static constexpr int NB = (S <= 8) ? 4 : 3;
+    static constexpr bool PACK = LQ_PACK_FOR(S);
 };
 
 // Bookkeeping of registers [lo, hi) of a finished 32 x 32 tile of d~ - |e'|^2 f (the chain starts from zero; the |e'|^2
 // term of the lane's code is added here, one fma per element, off the MFMA chain's critical path): per row (register)
 // and lane (code mod 32) the smallest value, its code and the second smallest.
-template <int LO, int HI>
-__device__ __forceinline__ void lq_track_part(const f32x16& acc, float e2, const float (&frow)[16], int code,
+// One element of the bookkeeping.  PACK: the tile index is written into the low bits of the value (v_and_or_b32), so the
+// smallest value carries its own code and no index array is kept: med3 + min on the packed floats (3 instructions + the fma
+// instead of 4 + the fma, and 16 registers less).  The perturbation, below 2^(TB-23) of the value's own magnitude, is part of
+// the certification margin (lq_screen_decide, pack_eps).  id = the code (unpacked) or the tile index (packed).
+template <bool PACK>
+__device__ __forceinline__ void lq_track_one(float v, int id, unsigned keep_mask, float& m1, float& m2, int& k1) {
+    if constexpr (PACK) {
+        // one instruction each (hipcc splits the and/or when both constants sit in scalar registers, and wraps fminf in two
+        // NaN-canonicalising v_max): the tile index is kept in a vector register by the caller
+        float key;
+        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(v), "s"(keep_mask), "v"(id));
+        m2 = __builtin_amdgcn_fmed3f(key, m1, m2);
+        asm("v_min_f32 %0, %1, %2" : "=v"(m1) : "v"(key), "v"(m1));
+    } else {
+        const bool lt = v < m1;                 // one compare feeds both selects (fminf would cost two
+        k1 = lt ? id : k1;                      // NaN-canonicalising v_max as well)
+        m2 = __builtin_amdgcn_fmed3f(v, m1, m2);
+        m1 = lt ? v : m1;
+    }
+}
+
+// Bookkeeping of registers [LO, HI) of a finished 32 x 32 tile of d~ - |e'|^2 f (the chain starts from zero; the |e'|^2
+// term of the lane's code is added here, one fma per element, off the MFMA chain's critical path): per row (register)
+// and lane (code mod 32) the smallest value, its code and the second smallest.
+template <int LO, int HI, bool PACK = false>
+__device__ __forceinline__ void lq_track_part(const f32x16& acc, float e2, const float (&frow)[16], int id, unsigned keep_mask,
                                               float (&m1)[16], float (&m2)[16], int (&k1)[16]) {
 #ifdef LQ_ABL_NOTRACK
     if (LO == 0) m1[0] = fminf(m1[0], acc[0] + acc[5] + acc[10] + acc[15]);   // keeps the MFMAs alive
     return;
 #endif
 #pragma unroll
-    for (int r = LO; r < HI; ++r) {
-        const float v = lq_fma(e2, frow[r], acc[r]);
-        const bool lt = v < m1[r];              // one compare feeds both selects (fminf would cost two
-        k1[r] = lt ? code : k1[r];              // NaN-canonicalising v_max as well)
-        m2[r] = __builtin_amdgcn_fmed3f(v, m1[r], m2[r]);
-        m1[r] = lt ? v : m1[r];
-    }
+    for (int r = LO; r < HI; ++r) lq_track_one<PACK>(lq_fma(e2, frow[r], acc[r]), id, keep_mask, m1[r], m2[r], k1[r]);
 }
 
 // the pending tile's registers that are booked behind MFMA j of the 3 S MFMAs of the running tile: [16 j / 3S, 16 (j + 1) / 3S)
 // (j a compile-time constant after unrolling)
-template <int S>
-__device__ __forceinline__ void lq_track_after_mfma(int j, const f32x16& acc, float e2, const float (&frow)[16], int code,
-                                                    float (&m1)[16], float (&m2)[16], int (&k1)[16]) {
+template <int S, bool PACK>
+__device__ __forceinline__ void lq_track_after_mfma(int j, const f32x16& acc, float e2, const float (&frow)[16], int id,
+                                                    unsigned keep_mask, float (&m1)[16], float (&m2)[16], int (&k1)[16]) {
 #ifdef LQ_ABL_NOTRACK
     if (j == 0) m1[0] = fminf(m1[0], acc[0] + acc[5] + acc[10] + acc[15]);
     return;
 #endif
     const int lo = (16 * j) / (3 * S), hi = (16 * (j + 1)) / (3 * S);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        if (r >= lo && r < hi) {
-            const float v = lq_fma(e2, frow[r], acc[r]);
-            const bool lt = v < m1[r];
-            k1[r] = lt ? code : k1[r];
-            m2[r] = __builtin_amdgcn_fmed3f(v, m1[r], m2[r]);
-            m1[r] = lt ? v : m1[r];
-        }
-    }
+    for (int r = 0; r < 16; ++r)
+        if (r >= lo && r < hi) lq_track_one<PACK>(lq_fma(e2, frow[r], acc[r]), id, keep_mask, m1[r], m2[r], k1[r]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -152,7 +169,10 @@ __device__ __forceinline__ void lq_wg_barrier() {             // LDS accesses of
 template <int S, int TC_, int NB>
 constexpr size_t lq_ring_bytes() { return (size_t)NB * ScreenCfg<S, TC_>::STAGE_BYTES + 1024; }
 
-template <int S, int NT, int TC_ = screen_default_tc(S), int NB = 4>
+// number of low mantissa bits that hold the tile index in PACK mode, and the relative perturbation that costs
+__host__ __device__ static inline int lq_pack_bits(int ntiles) { int b = 1; while ((1 << b) < ntiles) ++b; return b; }
+
+template <int S, int NT, int TC_ = screen_default_tc(S), int NB = 4, bool PACK = false>
 __device__ __forceinline__ void lq_screen_core(const f16x8 (&ah)[S], const f16x8 (&al)[S],
                                                const unsigned char* __restrict__ tiles, int ntiles,
                                                unsigned char* stage0, int tid, const float (&frow)[16],
@@ -165,9 +185,15 @@ __device__ __forceinline__ void lq_screen_core(const f16x8 (&ah)[S], const f16x8
     constexpr int PD = NB - 1;                                        // stages in flight ahead of the one being read
     constexpr int NSTEP = C::TC * S;                                  // k-steps per stage
     constexpr int MID = (C::TC >= 2) ? (C::TC / 2) * S : S / 2;       // the k-step in front of which the mid-stage hand-over sits
-    constexpr int PERIOD = ((C::TC & 1) || (NSTEP & 1)) ? 2 : 1;      // stages per loop trip: an even number of tiles and of k-steps
+#ifndef LQ_FRAG_RING_S4
+#define LQ_FRAG_RING_S4 2      /* measured: 4 slots (reads three k-steps ahead) change nothing */
+#endif
+    constexpr int FR = (S == 4 && NSTEP % LQ_FRAG_RING_S4 == 0) ? LQ_FRAG_RING_S4 : 2;     // fragment ring slots; reads run FR - 1 k-steps ahead
+    constexpr int FD = FR - 1;
+    constexpr int PERIOD = ((C::TC & 1) || (NSTEP % FR)) ? 2 : 1;     // stages per loop trip: an even number of tiles, whole fragment rings
+    static_assert(FR == 2 || NSTEP % FR == 0, "a wider fragment ring needs whole rings per stage");
     static_assert(C::STAGE_BYTES >= 1024 && C::STAGE_BYTES % 16 == 0, "stage copies are whole KiB pieces");
-    static_assert(NSTEP - 1 >= MID + 1 || NSTEP == 2, "next-stage fragments are read after the hand-over");
+    static_assert(NSTEP - FD >= MID, "next-stage fragments are read after the hand-over");
     static_assert(CPW * PD < 64, "vmcnt immediate");
     const int lane = tid & 63, ln = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: DMA addresses stay scalar base + lane offset
@@ -218,19 +244,24 @@ __device__ __forceinline__ void lq_screen_core(const f16x8 (&ah)[S], const f16x8
 #pragma unroll
     for (int r = 0; r < 16; ++r) accB[r] = INFINITY;      // "no previous tile": INFINITY never beats anything
     float e2A = 0.0f, e2B = 0.0f;
-    int codeA = 0, codeB = 0;
-    // fragment ring: slot ((g + so) & 1) holds k-step g of the current stage (g = NSTEP: k-step 0 of the next stage); so = 0,
+    int codeA = 0, codeB = 0;                     // the code of the lane in the tile (unpacked) or the tile index (PACK)
+    const unsigned keep_mask = PACK ? ~((1u << lq_pack_bits(ntiles)) - 1u) : 0xffffffffu;
+    // fragment ring: slot ((g + so) % FR) holds k-step g of the current stage (g = NSTEP: k-step 0 of the next stage); so = 0,
     // or the stage's position in the loop trip when NSTEP is odd
-    f16x8 fh[2], fl[2];
+    f16x8 fh[FR], fl[FR];
     float e2q[2] = {0.0f, 0.0f};                  // |e'|^2 of the tile in accumulator A / B
 #ifndef LQ_ABL_NOLDSB
-    fh[0] = frag(stage0, 0, 0); fl[0] = frag(stage0, 0, 1);
+#pragma unroll
+    for (int g = 0; g < FD; ++g) {                // k-steps 0 .. FD-1 of stage 0 (FD <= S: all in tile 0)
+        fh[g] = frag(stage0, g, 0); fl[g] = frag(stage0, g, 1);
+    }
     e2q[0] = reinterpret_cast<const float*>(stage0 + S * 2048)[ln];
+    static_assert(FD <= S, "prologue reads stay in tile 0");
 #endif
     int buf = 0;                                  // ring position of stage st
     auto do_stage = [&](auto POS, int st) {
         constexpr int par = (decltype(POS)::value * C::TC) & 1;    // 0: the stage's first tile runs into accA, 1: into accB
-        constexpr int so = (decltype(POS)::value * NSTEP) & 1;     // fragment slot of the stage's k-step 0
+        constexpr int so = (decltype(POS)::value * NSTEP) % FR;    // fragment slot of the stage's k-step 0
         const unsigned char* sb = stage0 + (size_t)buf * C::STAGE_BYTES;
         int nbuf = buf + 1; nbuf = nbuf == NB ? 0 : nbuf;
         const unsigned char* nsb = stage0 + (size_t)nbuf * C::STAGE_BYTES;
@@ -257,34 +288,35 @@ __device__ __forceinline__ void lq_screen_core(const f16x8 (&ah)[S], const f16x8
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
                 const float e2c = e2q[(c + par) & 1];
-                const int code = (st * C::TC + c) * 32 + ln;
+                int code = PACK ? (st * C::TC + c) : (st * C::TC + c) * 32 + ln;
+                if constexpr (PACK) asm volatile("" : "+v"(code));      // the tile index lives in a vector register (lq_track_one)
                 if (((c + par) & 1) == 0) { e2A = e2c; codeA = code; } else { e2B = e2c; codeB = code; }
             }
-            const f16x8 bh = fh[(g + so) & 1], bl = fl[(g + so) & 1];
+            const f16x8 bh = fh[(g + so) % FR], bl = fl[(g + so) % FR];
 #ifndef LQ_ABL_NOLDSB
-            // k-step g + 1 of this stage, or (g + 1 = NSTEP > MID: the hand-over has passed) k-step 0 of the next stage.
+            // k-step g + FD of this stage, or (g + FD >= NSTEP > MID: the hand-over has passed) of the next stage's first tile.
             // Unconditional: behind the last stage it reads bytes of the ring that nobody uses (no branch in the loop body).
             {
-                const int g1 = g + 1;
+                const int g1 = g + FD;
                 const unsigned char* base = (g1 < NSTEP) ? sb : nsb;
-                const int gg = (g1 < NSTEP) ? g1 : 0;
+                const int gg = (g1 < NSTEP) ? g1 : g1 - NSTEP;
                 const unsigned char* tb = base + (size_t)(gg / S) * C::TILE_BYTES;
-                fh[(g1 + so) & 1] = frag(tb, gg % S, 0);
-                fl[(g1 + so) & 1] = frag(tb, gg % S, 1);
-                if (gg % S == 0) e2q[(g1 / S + par) & 1] = reinterpret_cast<const float*>(tb + S * 2048)[ln];   // g1 / S = TC: next stage
+                fh[(g1 + so) % FR] = frag(tb, gg % S, 0);
+                fl[(g1 + so) % FR] = frag(tb, gg % S, 1);
+                if (gg % S == 0) e2q[(g1 / S + par) & 1] = reinterpret_cast<const float*>(tb + S * 2048)[ln];   // g1 / S >= TC: next stage
             }
 #endif
             // pinned order: reads, then (MFMA, its share of the pending tile's bookkeeping) x 3 -- left alone, hipcc lumps the
             // bookkeeping behind the chain, where nothing hides it
             __builtin_amdgcn_sched_barrier(0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh, acc, 0, 0, 0);
-            lq_track_after_mfma<S>(3 * s + 0, prev, e2_prev, frow, code_prev, m1, m2, k1);
+            lq_track_after_mfma<S, PACK>(3 * s + 0, prev, e2_prev, frow, code_prev, keep_mask, m1, m2, k1);
             __builtin_amdgcn_sched_barrier(0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh, acc, 0, 0, 0);
-            lq_track_after_mfma<S>(3 * s + 1, prev, e2_prev, frow, code_prev, m1, m2, k1);
+            lq_track_after_mfma<S, PACK>(3 * s + 1, prev, e2_prev, frow, code_prev, keep_mask, m1, m2, k1);
             __builtin_amdgcn_sched_barrier(0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl, acc, 0, 0, 0);
-            lq_track_after_mfma<S>(3 * s + 2, prev, e2_prev, frow, code_prev, m1, m2, k1);
+            lq_track_after_mfma<S, PACK>(3 * s + 2, prev, e2_prev, frow, code_prev, keep_mask, m1, m2, k1);
             __builtin_amdgcn_sched_barrier(0);
         }
         buf = nbuf;
@@ -294,7 +326,7 @@ __device__ __forceinline__ void lq_screen_core(const f16x8 (&ah)[S], const f16x8
         if constexpr (PERIOD == 2) do_stage(std::integral_constant<int, 1>{}, st + 1);
     }
     // the last tile's chain: ntiles is even, so it ran into accB
-    lq_track_part<0, 16>(accB, e2B, frow, codeB, m1, m2, k1);
+    lq_track_part<0, 16, PACK>(accB, e2B, frow, codeB, keep_mask, m1, m2, k1);
     // the copies issued for stages past the end go to the dummy KiB, but they count: drain them, then every wave has left
     // the stage buffers (the callers reuse them as per-wave scratch: lq_screen_decide)
 #ifndef LQ_ABL_NOSTAGE
@@ -311,6 +343,11 @@ __device__ __forceinline__ void lq_row_factors(float fown, int lane, float (&fro
     for (int r = 0; r < 16; ++r) frow[r] = __shfl(fown, (r & 3) + 8 * (r >> 2) + 4 * h, 64);
 }
 
+// LDS scratch per wave of lq_screen_decide: 32 rows of 32 values, row stride 36 floats (16-byte aligned rows whose float4 reads
+// fall on distinct bank groups: a 32-float stride made every 16-byte read of the transposed image an 8-way bank conflict)
+#define LQ_DECIDE_STRIDE 36
+#define LQ_DECIDE_BYTES (32 * LQ_DECIDE_STRIDE * 4)
+
 // After the last tile: per row, the global (smallest, its code, second smallest) over the 32 lanes of the
 // half-wave that holds the row -- and the certification decision.
 //
@@ -321,21 +358,23 @@ __device__ __forceinline__ void lq_row_factors(float fown, int lane, float (&fro
 // 32-row tile instead of ~720 for a 5-step shuffle butterfly over 16 registers x 3 values (ablation: the
 // butterfly + its LDS hand-off cost 46 us of a 350 us launch), and no workgroup barrier.
 // Returns certified (valid in every lane, duplicated across the halves); my_k = the row's code.
+template <bool PACK = false>
 __device__ __forceinline__ bool lq_screen_decide(const float (&m1)[16], const float (&m2)[16], const int (&k1)[16],
-                                                 unsigned char* wave_lds /* 4 KiB, this wave only */,
+                                                 unsigned char* wave_lds /* LQ_DECIDE_BYTES, this wave only */,
                                                  const unsigned* hdr, float n2, float fown, float gamma, int K, int D,
-                                                 int lane, int& my_k) {
+                                                 int lane, int& my_k, float pack_eps = 0.0f, unsigned keep_mask = 0xffffffffu) {
+    constexpr int TS = LQ_DECIDE_STRIDE;
     const int ln = lane & 31, h = lane >> 5;
-    float* tv = reinterpret_cast<float*>(wave_lds);           // [32 rows][32 lanes], reused by the three passes
+    float* tv = reinterpret_cast<float*>(wave_lds);           // [32 rows][TS], reused by the passes
     // ---- pass 1: m1 -> best value, its position among my 16 entries, second smallest m1 ----------------------
 #pragma unroll
-    for (int r = 0; r < 16; ++r) tv[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + ln] = m1[r];
+    for (int r = 0; r < 16; ++r) tv[((r & 3) + 8 * (r >> 2) + 4 * h) * TS + ln] = m1[r];
     __builtin_amdgcn_s_waitcnt(0xC07F);                       // lgkmcnt(0): this wave's LDS writes have landed
     __builtin_amdgcn_wave_barrier();
     float best = INFINITY, second = INFINITY;
     int pos = 0;
     {
-        const float4* pv = reinterpret_cast<const float4*>(tv + ln * 32 + 16 * h);
+        const float4* pv = reinterpret_cast<const float4*>(tv + ln * TS + 16 * h);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 v4 = pv[q];
@@ -349,22 +388,28 @@ __device__ __forceinline__ bool lq_screen_decide(const float (&m1)[16], const fl
             }
         }
     }
-    __builtin_amdgcn_wave_barrier();                          // pass-1 reads are issued before pass 2 overwrites
-    // ---- pass 2: k1 -> the code at that position ------------------------------------------------------------
-    int* tk = reinterpret_cast<int*>(wave_lds);
+    __builtin_amdgcn_wave_barrier();                          // pass-1 reads are issued before the next pass overwrites
+    int bk;
+    if constexpr (PACK) {
+        // the smallest value carries its tile index; its lane (= code mod 32) is the column it was read from
+        bk = (int)(__float_as_uint(best) & ~keep_mask) * 32 + 16 * h + pos;
+    } else {
+        // ---- pass 2: k1 -> the code at that position --------------------------------------------------------
+        int* tk = reinterpret_cast<int*>(wave_lds);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) tk[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + ln] = k1[r];
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();
-    int bk = tk[ln * 32 + 16 * h + pos];
-    __builtin_amdgcn_wave_barrier();
+        for (int r = 0; r < 16; ++r) tk[((r & 3) + 8 * (r >> 2) + 4 * h) * TS + ln] = k1[r];
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        bk = tk[ln * TS + 16 * h + pos];
+        __builtin_amdgcn_wave_barrier();
+    }
     // ---- pass 3: m2 -----------------------------------------------------------------------------------------
 #pragma unroll
-    for (int r = 0; r < 16; ++r) tv[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + ln] = m2[r];
+    for (int r = 0; r < 16; ++r) tv[((r & 3) + 8 * (r >> 2) + 4 * h) * TS + ln] = m2[r];
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
     {
-        const float4* pv = reinterpret_cast<const float4*>(tv + ln * 32 + 16 * h);
+        const float4* pv = reinterpret_cast<const float4*>(tv + ln * TS + 16 * h);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 v4 = pv[q];
@@ -404,7 +449,9 @@ __device__ __forceinline__ bool lq_screen_decide(const float (&m1)[16], const fl
     const float eps_s = gamma * (E2max + cross) * fown;
     const float n2s = n2 * fown;
     const float s1 = fmaxf(0.0f, best + n2s) + eps_s + (float)(Dpad16 + 2) * u24 * n2s;
-    const float thr = 2.0f * eps_s + 2.125f * (float)(Dpad16 / 8 + 12) * u24 * s1;
+    //  (3) PACK bookkeeping (lq_track_one): best and second carry the tile index in their low bits, a perturbation below
+    //      pack_eps = 2^(TB-23) of each value's own magnitude, and so does every other code's value that `second` bounds.
+    const float thr = 2.0f * eps_s + 2.125f * (float)(Dpad16 / 8 + 12) * u24 * s1 + 2.125f * pack_eps * (lq_abs(best) + lq_abs(second));
     // non-finite inputs make the comparison false
     bool certified = (twoemax < INFINITY) && (second - best > thr) && (bk >= 0) && (bk < K);
 #ifdef LQ_ABL_CERT_ALL
@@ -438,16 +485,25 @@ __device__ __forceinline__ void lq_screen_gather(const float* __restrict__ cb, f
 #ifdef LQ_ABL_NOGATHER
     return;
 #endif
+    // 16 lanes copy one codebook row (16 B each per pass), 4 rows per pass of the wave; the loads of all eight passes are
+    // issued before the first store (the first version waited for each pass's load before storing: eight L2 round trips)
     const int nvec = D / 4;
-    for (int rr = 0; rr < 32; rr += 4) {
-        const int src_lane = rr + (lane >> 4);
-        const int kk = __shfl(my_k, src_lane, 64);
-        const bool ok = __shfl((int)certified, src_lane, 64) != 0;
-        const int64_t orow = row0 + src_lane;
-        if (ok && orow < N) {
-            const float4* src = reinterpret_cast<const float4*>(cb + (size_t)kk * D);
-            float4* dst = reinterpret_cast<float4*>(zq + (size_t)orow * D);
-            for (int v = lane & 15; v < nvec; v += 16) dst[v] = src[v];
+    for (int v0 = 0; v0 < nvec; v0 += 16) {                     // 64 floats of the row per trip (one trip for D <= 64)
+        const int v = v0 + (lane & 15);
+        float4 val[8];
+        bool okv[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int src_lane = 4 * p + (lane >> 4);
+            const int kk = __shfl(my_k, src_lane, 64);
+            okv[p] = (__shfl((int)certified, src_lane, 64) != 0) && (row0 + src_lane < N) && (v < nvec);
+            const int vc = v < nvec ? v : nvec - 1;             // always a valid address (certified rows have 0 <= kk < K)
+            val[p] = reinterpret_cast<const float4*>(cb + (size_t)(okv[p] ? kk : 0) * D)[vc];
+        }
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int src_lane = 4 * p + (lane >> 4);
+            if (okv[p]) reinterpret_cast<float4*>(zq + (size_t)(row0 + src_lane) * D)[v] = val[p];
         }
     }
 }

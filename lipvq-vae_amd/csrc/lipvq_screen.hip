@@ -202,13 +202,19 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
                     if (rr < N) dbg[(size_t)rr * L.Kpad + code] = lq_fma(e2, frow[r], acc[r]) / frow[r];      // back to unscaled units
                 }
             }
-            lq_track_part<0, 16>(acc, e2, frow, code, m1, m2, k1);
+            lq_track_part<0, 16>(acc, e2, frow, code, 0xffffffffu, m1, m2, k1);
         }
     } else {
-        lq_screen_core<S, SCREEN_WAVES * 64, SC::TC, SC::NB>(ah, al, tiles, L.ntiles, lds, tid, frow, m1, m2, k1);
+        lq_screen_core<S, SCREEN_WAVES * 64, SC::TC, SC::NB, SC::PACK>(ah, al, tiles, L.ntiles, lds, tid, frow, m1, m2, k1);
     }
     int my_k;
-    const bool certified = lq_screen_decide(m1, m2, k1, lds + (size_t)wave * 4096, hdr, n2, fown, gamma, K, D, lane, my_k);
+    const float pack_eps = (SC::PACK && !DBG) ? lq_pow2f(lq_pack_bits(L.ntiles) - 23) : 0.0f;
+    bool certified;
+    if (SC::PACK && !DBG)
+        certified = lq_screen_decide<true>(m1, m2, k1, lds + (size_t)wave * LQ_DECIDE_BYTES, hdr, n2, fown, gamma, K, D, lane, my_k, pack_eps,
+                                           ~((1u << lq_pack_bits(L.ntiles)) - 1u));
+    else
+        certified = lq_screen_decide<false>(m1, m2, k1, lds + (size_t)wave * LQ_DECIDE_BYTES, hdr, n2, fown, gamma, K, D, lane, my_k, 0.0f);
     if (h == 0 && row < N) {
         if (certified) {
             idx[row] = (int64_t)my_k;
@@ -456,9 +462,8 @@ static int launch_screen(const float* z, const unsigned char* prep, const float*
                          int64_t* usage, int* amb_list, int* amb_count, float* dbg, int64_t N, int K, int D,
                          float gamma, hipStream_t st) {
     using SC = StandaloneScreen<S>;
-    using C = ScreenCfg<S, SC::TC>;
     size_t lds = lq_ring_bytes<S, SC::TC, SC::NB>();
-    if (lds < (size_t)SCREEN_WAVES * 4096) lds = (size_t)SCREEN_WAVES * 4096;      // per-wave transpose slices reuse the stages
+    if (lds < (size_t)SCREEN_WAVES * LQ_DECIDE_BYTES) lds = (size_t)SCREEN_WAVES * LQ_DECIDE_BYTES;      // per-wave transpose slices reuse the stages
     const int64_t rows_per_block = SCREEN_WAVES * 32;
     unsigned blocks = (unsigned)((N + rows_per_block - 1) / rows_per_block);
     auto kfn = dbg ? screen_kernel<S, true> : screen_kernel<S, false>;
