@@ -514,7 +514,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
                 a.idx[row] = (int64_t)my_k;
                 if (use_hist) atomicAdd(&hist[my_k], 1u);              // LDS atomic
             } else {
-                a.amb_list[atomicAdd(a.amb_count, 1)] = (int)row;
+                const int slot = atomicAdd(a.amb_count, 1);
+                a.amb_list[slot] = (int)row;
+                a.amb_list[lq_list_ints(a.N) + slot] = my_k;      // the screen's best candidate: bounds the exact scan
             }
         }
         if (a.usage && !use_hist) lq_usage_add(a.usage, my_k, h == 0 && row < a.N && certified);
@@ -615,7 +617,7 @@ extern "C" int lipvq_tokenize_supported(int A, int J0, int J1, int D, int K) {
 
 extern "C" size_t lipvq_tokenize_workspace_bytes(int64_t N, int D) {
     if (N <= 0 || D <= 0) return 0;
-    return 64 + (((sizeof(int) * (size_t)N) + 63) & ~(size_t)63);       // uncertified-row counter + list
+    return 64 + 2 * sizeof(int) * lq_list_ints(N);                      // uncertified-row counter, row list, candidate list
 }
 
 // Fused encode + quantize (reference v5:71-74).  packed: lipvq_mlp3_pack_f32 of the encoder stack

@@ -508,6 +508,9 @@ __device__ __forceinline__ void lq_screen_gather(const float* __restrict__ cb, f
     }
 }
 
+// workspace of the screened routes: [64 B: counter] [row list: lq_list_ints(N) ints] [candidate list: the same]
+__host__ __device__ static inline size_t lq_list_ints(int64_t N) { return ((size_t)N + 15) & ~(size_t)15; }
+
 // exact decision for listed rows (lipvq_screen.hip); z_by_slot: z is a compact [count][D] buffer
 int lipvq_launch_rows(const float* z, int z_by_slot, const float* cb, int64_t* idx, float* zq, int64_t* usage,
                       const int* amb_list, const int* amb_count, int64_t N, int K, int D, hipStream_t st);

@@ -221,6 +221,7 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
         } else {
             const int slot = atomicAdd(amb_count, 1);
             amb_list[slot] = (int)row;
+            amb_list[lq_list_ints(N) + slot] = my_k;             // the screen's best candidate: bounds the exact scan
         }
     }
     if (usage) lq_usage_add(usage, my_k, h == 0 && row < N && certified);
@@ -233,9 +234,9 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
 // already reaches the best square so far proves the full square does too, and the rest of that code's row is not
 // fetched.  Same results bit for bit; the scan is bound by re-reading the codebook (1.15 ms for 3 317 rows at K = 8192,
 // D = 128 without the early exit).
-template <int DCH>
+template <int DCH, bool SEEDED = false>
 __device__ __forceinline__ void lq_exact_scan(const float (&zr)[DCH * 8], const float* __restrict__ cb, int kb, int ke,
-                                              float& best_v, float& best_s, int& best_k) {
+                                              float& best_v, float& best_s, int& best_k, float s_prune = INFINITY) {
     constexpr int D = DCH * 8;
 #ifdef LQ_SCAN_G
     constexpr int G = LQ_SCAN_G;
@@ -243,7 +244,10 @@ __device__ __forceinline__ void lq_exact_scan(const float (&zr)[DCH * 8], const 
     // chunks of 8 dimensions between two early-exit tests.  Measured (same-run builds): every 32 dimensions pays at D = 128,
     // K = 8192 (cfg3 launch 4.74 -> 4.10 ms) and is neutral at D = 64; at D = 208 -- the training-step route, where every row
     // of a small batch is scanned and uniform-random data prunes nothing -- six tests per code cost 18 %, so none there.
-    constexpr int G = (DCH > 16) ? DCH : 4;
+    // SEEDED (rows listed by the screen, which hands over its best candidate): the candidate's exact square bounds the scan
+    // from the first chunk on, so the test pays at every width.  (Tried and dropped: loading code k+1's first 32 dimensions
+    // while code k is tested -- 64 more registers beside the 128 of the row: 345 -> 531 us at K = 8192, D = 128.)
+    constexpr int G = (DCH > 16 && !SEEDED) ? DCH : 4;
 #endif
     for (int k = kb; k < ke; ++k) {
         const float4* c4 = reinterpret_cast<const float4*>(cb + (size_t)k * D);
@@ -266,7 +270,7 @@ __device__ __forceinline__ void lq_exact_scan(const float (&zr)[DCH * 8], const 
 #ifndef LQ_NO_EARLY_EXIT
             if (g + G < DCH) {
                 const float part = ((((((a0 + a1) + a2) + a3) + a4) + a5) + a6) + a7;
-                if (part >= best_s) { dead = true; break; }
+                if (part >= best_s || part > s_prune) { dead = true; break; }
             }
 #endif
         }
@@ -279,6 +283,31 @@ __device__ __forceinline__ void lq_exact_scan(const float (&zr)[DCH * 8], const 
     }
 }
 
+// The screen's best candidate of a listed row bounds the exact scan: with s* the candidate's exact square (same 8-accumulator
+// order), no code whose square exceeds s* (1 + 2^-21) can reach the candidate's square ROOT -- one ulp of the root spans at most
+// 2^-22 of the square, so the slack also covers squares that differ from s* but share its root (the first-index rule then still
+// sees them).  The bound only prunes; the result is what the unbounded scan finds.
+template <int DCH>
+__device__ __forceinline__ float lq_seed_bound(const float (&zr)[DCH * 8], const float* __restrict__ cb, int seed) {
+    const float4* c4 = reinterpret_cast<const float4*>(cb + (size_t)seed * (DCH * 8));
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+#pragma unroll
+    for (int i = 0; i < DCH; ++i) {
+        const float4 lo = c4[2 * i], hi = c4[2 * i + 1];
+        const float d0 = zr[8 * i + 0] - lo.x, d1 = zr[8 * i + 1] - lo.y;
+        const float d2 = zr[8 * i + 2] - lo.z, d3 = zr[8 * i + 3] - lo.w;
+        const float d4 = zr[8 * i + 4] - hi.x, d5 = zr[8 * i + 5] - hi.y;
+        const float d6 = zr[8 * i + 6] - hi.z, d7 = zr[8 * i + 7] - hi.w;
+        a0 = lq_fma(d0, d0, a0); a1 = lq_fma(d1, d1, a1);
+        a2 = lq_fma(d2, d2, a2); a3 = lq_fma(d3, d3, a3);
+        a4 = lq_fma(d4, d4, a4); a5 = lq_fma(d5, d5, a5);
+        a6 = lq_fma(d6, d6, a6); a7 = lq_fma(d7, d7, a7);
+    }
+    const float s = ((((((a0 + a1) + a2) + a3) + a4) + a5) + a6) + a7;
+    const float b = lq_fma(s, 4.76837158203125e-07f, s) + 1.1754944e-38f;      // s (1 + 2^-21), never below s itself
+    return (b == b) ? b : INFINITY;                                            // a NaN square prunes nothing
+}
+
 // ------------------------------------------------------------------------------------------
 // exact decision for the listed rows: 4 rows x 64 code slices per workgroup
 // ------------------------------------------------------------------------------------------
@@ -286,7 +315,7 @@ template <int DCH>
 __global__ __launch_bounds__(256) void nearest_rows_kernel(
     const float* __restrict__ z, const float* __restrict__ cb, int64_t* __restrict__ idx, float* __restrict__ zq,
     unsigned long long* __restrict__ usage, const int* __restrict__ row_list, const int* __restrict__ row_count,
-    int K, int z_by_slot, int count_direct) {
+    int K, int z_by_slot, int count_direct, const int* __restrict__ seed_list) {
     constexpr int D = DCH * 8;
     constexpr int RB = 4, SL = 64;               // rows per workgroup, code slices per row
     __shared__ float s_v[RB][SL];
@@ -312,7 +341,13 @@ __global__ __launch_bounds__(256) void nearest_rows_kernel(
     float best_v = INFINITY, best_s = INFINITY;
     int best_k = kb < K ? kb : 0;            // always a valid code, even if every distance is NaN (torch.argmin
                                              // of an all-NaN row is unspecified; an out-of-range index is not an option)
-    lq_exact_scan<DCH>(zr, cb, kb, ke, best_v, best_s, best_k);
+    if (seed_list) {                         // wave-uniform: rows listed by the screen come with its best candidate
+        int seed = seed_list[cslot];
+        seed = (seed >= 0 && seed < K) ? seed : 0;
+        lq_exact_scan<DCH, true>(zr, cb, kb, ke, best_v, best_s, best_k, lq_seed_bound<DCH>(zr, cb, seed));
+    } else {
+        lq_exact_scan<DCH>(zr, cb, kb, ke, best_v, best_s, best_k);
+    }
     s_v[r][sl] = best_v; s_k[r][sl] = best_k;
     __syncthreads();
     if (sl == 0 && valid) {
@@ -349,7 +384,7 @@ template <int DCH>
 __global__ __launch_bounds__(256) void nearest_rows_encode_kernel(
     const float* __restrict__ x, RawEncoder w, int A, const float* __restrict__ cb, int64_t* __restrict__ idx,
     float* __restrict__ zq, unsigned long long* __restrict__ usage, const int* __restrict__ row_list,
-    const int* __restrict__ row_count, int K) {
+    const int* __restrict__ row_count, int K, const int* __restrict__ seed_list) {
     constexpr int D = DCH * 8;
     constexpr int RB = 4, SL = 64;
     __shared__ float s_x[RB][64];
@@ -407,7 +442,11 @@ __global__ __launch_bounds__(256) void nearest_rows_encode_kernel(
     const int kb = sl * per, ke = (kb + per < K) ? kb + per : K;
     float best_v = INFINITY, best_s = INFINITY;
     int best_k = kb < K ? kb : 0;
-    lq_exact_scan<DCH>(zr, cb, kb, ke, best_v, best_s, best_k);
+    {
+        int seed = seed_list[valid ? slot : count - 1];
+        seed = (seed >= 0 && seed < K) ? seed : 0;
+        lq_exact_scan<DCH, true>(zr, cb, kb, ke, best_v, best_s, best_k, lq_seed_bound<DCH>(zr, cb, seed));
+    }
     s_v[r][sl] = best_v; s_k[r][sl] = best_k;
     __syncthreads();
     if (sl == 0 && valid) {
@@ -433,12 +472,13 @@ __global__ __launch_bounds__(256) void nearest_rows_encode_kernel(
 int lipvq_launch_rows_encode(const float* x, const float* const* raw6, int A, const float* cb, int64_t* idx, float* zq,
                              int64_t* usage, const int* amb_list, const int* amb_count, int64_t N, int K, int D,
                              hipStream_t st) {
+    const int* amb_seed = amb_list + lq_list_ints(N);
     RawEncoder w{raw6[0], raw6[1], raw6[2], raw6[3], raw6[4], raw6[5]};
     int64_t blocks = (N + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     auto go = [&](auto kfn) {
         hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(256), 0, st, x, w, A, cb, idx, zq,
-                           (unsigned long long*)usage, amb_list, amb_count, K);
+                           (unsigned long long*)usage, amb_list, amb_count, K, amb_seed);
     };
     switch (D) {
         case 32: go(nearest_rows_encode_kernel<4>); break;
@@ -454,7 +494,7 @@ int lipvq_launch_rows_encode(const float* x, const float* const* raw6, int A, co
 // ------------------------------------------------------------------------------------------
 extern "C" size_t lipvq_nearest_workspace_bytes(int64_t N) {
     if (N <= 0) return 0;
-    return 64 + sizeof(int) * (size_t)N;          // [0] ambiguous-row counter, then the row list
+    return 64 + 2 * sizeof(int) * lq_list_ints(N);    // [0] uncertified-row counter, then the row list and the candidate list
 }
 
 template <int S>
@@ -485,7 +525,8 @@ static int launch_rows_t(const float* z, int z_by_slot, const float* cb, int64_t
     int64_t blocks = (N + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL((nearest_rows_kernel<DCH>), dim3((unsigned)blocks), dim3(256), 0, st, z, cb, idx, zq,
-                       (unsigned long long*)usage, amb_list, amb_count, K, z_by_slot, amb_list ? 0 : (int)N);
+                       (unsigned long long*)usage, amb_list, amb_count, K, z_by_slot, amb_list ? 0 : (int)N,
+                       amb_list ? amb_list + lq_list_ints(N) : nullptr);
     return check_launch("nearest_rows");
 }
 
