@@ -166,6 +166,17 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
 
     const unsigned* hdr = reinterpret_cast<const unsigned*>(a.prep);
     const unsigned char* tiles = a.prep + L.o_tiles;
+    // Scale of the fp16 split.  The stand-alone screen scales every latent row by its own power of two (block floating point,
+    // lipvq_screen.h: it must cope with latents of any magnitude).  Here z_e is a sigmoid output, so |z_e - mu| <= 1 + max|mu|
+    // =: Bz for EVERY row, and ONE power of two fz (Bz fz in [2^13, 2^14)) serves the whole launch: the split happens tile by
+    // tile as the encoder finishes (no fp32 copy of z_e, no second pass, one row factor instead of sixteen).  What a per-row
+    // scale bought -- "lo" pieces staying normal fp16 numbers for rows of small magnitude -- is replaced by a rule: a row with
+    // |z'|^2 below tiny2 (its elements' 2^-25 fz^-1 absolute split error would no longer be 2^-20 |z'| Emax / sqrt(D)) is
+    // never certified and goes to the exact kernel.  No such row exists unless z_e collapses onto the codebook mean.
+    const int sz = lq_scale_exp(1.0f + __uint_as_float(hdr[4]));
+    const float fz = lq_pow2f(sz);
+    const float fown = lq_pow2f(sz + (int)hdr[3]);
+    const float tiny2 = (float)(16 * S) * lq_pow2f(-10 - 2 * sz);
     const int64_t nblk = (a.N + FUSED_WAVES * 32 - 1) / (FUSED_WAVES * 32);
 
 #ifdef LQ_STAMPS
@@ -205,8 +216,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
         const int64_t rowc = row < a.N ? row : a.N - 1;
 
         f16x8 ah[S], al[S];
-        float n2 = 0.0f, amax = 0.0f;
-        f32x16 zc[T2];                   // centred z_e (fp32) until the row's scale is known
+        float n2 = 0.0f;
         // sigmoid, centring, row statistics and the optional z_e store of one finished 32-feature tile
         auto finish_tile = [&](const int t, f32x16& acc) {
 #pragma unroll
@@ -216,9 +226,13 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
                                       : FUSED_SIGMOID(acc[r]);
                 acc[r] = zv;
                 const float v = zv - w_mu[32 * t + 2 * r + h];
-                zc[t][r] = v;
                 n2 = lq_fma(v, v, n2);
-                amax = fmaxf(amax, lq_abs(v));
+                // register r of tile t is feature 32t + 2r + h = screen slot (step 2t + (r >> 3), element r & 7): scaled by the
+                // kernel-wide power of two fz and split into fp16 hi + lo right here (nothing of z_e is kept in fp32)
+                const float vs = v * fz;
+                const _Float16 vh = (_Float16)vs;
+                ah[2 * t + (r >> 3)][r & 7] = vh;
+                al[2 * t + (r >> 3)][r & 7] = (_Float16)(vs - (float)vh);
             }
             // z_e row store.  Lane (n, h) holds features 32t + 2r + h (r = 0..15) of row n: the even ones in
             // the low half-wave, the odd ones in the high half.  One v_permlane32_swap per register pair
@@ -479,22 +493,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
         }
         LQ_STAMP(2);
         n2 += __shfl_xor(n2, 32, 64);
-        amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
-        const int sz = lq_scale_exp(amax);                    // block floating point: see lipvq_screen.h
-        const float fz = lq_pow2f(sz);
-        const float fown = lq_pow2f(sz + (int)hdr[3]);
+        float frow[16];                                       // one scale for every row here (see fz): a single register
 #pragma unroll
-        for (int t = 0; t < T2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                // register r of tile t is feature 32t + 2r + h = screen slot (step 2t + (r >> 3), element r & 7)
-                const float v = zc[t][r] * fz;
-                const _Float16 vh = (_Float16)v;
-                ah[2 * t + (r >> 3)][r & 7] = vh;
-                al[2 * t + (r >> 3)][r & 7] = (_Float16)(v - (float)vh);
-            }
-        float frow[16];
-        lq_row_factors(fown, lane, frow);
+        for (int r = 0; r < 16; ++r) frow[r] = fown;
         // ================= phase B: MFMA screen (lq_screen_core, lipvq_screen.h) ==============
         float m1[16], m2[16];
         int k1[16];
@@ -506,9 +507,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
         lq_screen_core<S, FUSED_THREADS, TCF, NBF, PACKF>(ah, al, tiles, L.ntiles, stage0, tid, frow, m1, m2, k1);
         LQ_STAMP(4);
         int my_k;
-        const bool certified = lq_screen_decide<PACKF>(m1, m2, k1, stage0 + (size_t)wave * LQ_DECIDE_BYTES, hdr, n2, fown, a.gamma, a.K,
+        bool certified = lq_screen_decide<PACKF>(m1, m2, k1, stage0 + (size_t)wave * LQ_DECIDE_BYTES, hdr, n2, fown, a.gamma, a.K,
                                                        a.D, lane, my_k, PACKF ? lq_pow2f(lq_pack_bits(L.ntiles) - 23) : 0.0f,
                                                        PACKF ? ~((1u << lq_pack_bits(L.ntiles)) - 1u) : 0xffffffffu);
+        certified = certified && (n2 >= tiny2);
         if (h == 0 && row < a.N) {
             if (certified) {
                 a.idx[row] = (int64_t)my_k;

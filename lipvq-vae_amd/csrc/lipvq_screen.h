@@ -26,7 +26,7 @@ __host__ __device__ static inline PrepLayout prep_layout(int K, int D) {
     L.Dpad = L.S * 16;
     L.Kpad = ((K + 31) / 32) * 32;
     L.ntiles = ((L.Kpad / 32 + 7) / 8) * 8;   // whole LDS stages: pad tiles carry e2 = +inf, zero fragments
-    L.o_hdr = 0;                       // 16 words: [0] E2max bits, [1] Emax^2 bits, [2] max|2e'| bits, [3] se (int)
+    L.o_hdr = 0;                       // 16 words: [0] E2max bits, [1] Emax^2 bits, [2] max|2e'| bits, [3] se (int), [4] max|mu| bits
     L.o_mu = 64;
     L.o_tiles = L.o_mu + sizeof(float) * (size_t)L.Dpad;
     L.o_tiles = (L.o_tiles + 255) & ~(size_t)255;

@@ -31,8 +31,8 @@ extern "C" size_t lipvq_nearest_prep_bytes(int K, int D) {
 }
 
 // column means: 64 columns x 4 row groups per workgroup, double accumulation in a fixed order (deterministic)
-__global__ __launch_bounds__(256) void prep_mean_kernel(const float* __restrict__ cb, float* __restrict__ mu, int K, int D,
-                                                        int Dpad) {
+__global__ __launch_bounds__(256) void prep_mean_kernel(const float* __restrict__ cb, float* __restrict__ mu,
+                                                        unsigned* __restrict__ hdr, int K, int D, int Dpad) {
     __shared__ double part[4][64];
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int d = blockIdx.x * 64 + c;
@@ -41,8 +41,11 @@ __global__ __launch_bounds__(256) void prep_mean_kernel(const float* __restrict_
         for (int k = g; k < K; k += 4) s += (double)cb[(size_t)k * D + d];
     part[g][c] = s;
     __syncthreads();
-    if (g == 0 && d < Dpad)
-        mu[d] = (d < D) ? (float)((((part[0][c] + part[1][c]) + part[2][c]) + part[3][c]) / (double)K) : 0.0f;
+    if (g == 0 && d < Dpad) {
+        const float m = (d < D) ? (float)((((part[0][c] + part[1][c]) + part[2][c]) + part[3][c]) / (double)K) : 0.0f;
+        mu[d] = m;
+        atomicMax(&hdr[4], __float_as_uint(fabsf(m)));          // max |mu|: the fused kernel's launch-wide scale (lipvq_fused.hip)
+    }
 }
 
 // one thread per (code, step, half): 8 centred, -2-scaled elements -> fp16 hi/lo fragments
@@ -105,7 +108,7 @@ extern "C" int lipvq_nearest_prepare_f32(const float* codebook, void* prep, int 
     hipError_t e = hipMemsetAsync(base, 0, 64, st);
     if (e != hipSuccess) return fail(LIPVQ_EHIP, "nearest_prepare: %s", hipGetErrorString(e));
     float* mu = (float*)(base + L.o_mu);
-    hipLaunchKernelGGL(prep_mean_kernel, dim3((L.Dpad + 63) / 64), dim3(256), 0, st, codebook, mu, K, D, L.Dpad);
+    hipLaunchKernelGGL(prep_mean_kernel, dim3((L.Dpad + 63) / 64), dim3(256), 0, st, codebook, mu, (unsigned*)base, K, D, L.Dpad);
     hipLaunchKernelGGL(prep_e2_kernel, dim3((L.ntiles * 32 + 255) / 256), dim3(256), 0, st, codebook, mu, base + L.o_tiles,
                        (unsigned*)base, K, D, L);
     hipLaunchKernelGGL(prep_scale_kernel, dim3(1), dim3(1), 0, st, (unsigned*)base);
