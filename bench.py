@@ -375,7 +375,7 @@ def main():
     }
     if sustained is not None:
         out["sustained"] = sustained
-    if world == 1 and fused:
+    if world == 1 and ops.tokenize_fast_supported(A, 64, model.hidden_dim, D, K):
         # reported beside the metric, never as `value`: the opt-in fast mode (fp16 encoder GEMMs, fp32 accumulation and
         # quantizer) on the same batch, with the fraction of indices that differ from the parity run above
         for _ in range(3):

@@ -118,11 +118,13 @@ int lipvq_screen_debug_f32(const float* z, const float* codebook, const void* pr
  * NULL).  Same results as lipvq_mlp3_f32(gelu, gelu, sigmoid) followed by lipvq_nearest_f32(LIPVQ_DIST_NORM);
  * z_e stays in registers.  packed = lipvq_mlp3_pack_f32 of the encoder stack (A -> J0 -> J1 -> D, W2 already
  * Lipschitz-normalised); prep = lipvq_nearest_prepare_f32 of the codebook.  Supported: J0 = 64, J1 = 128
- * (the reference's widths), D in {32, 64, 128}, A <= 64.  raw6 = host array of the six device pointers {W0, b0, W1, b1,
+ * (the reference's widths), D in {32, 64, 128, 208} (208 = the width the reference itself runs, v5:89-92 / obs_nets.py:1225-1227:
+ * its 112 KB of Lipschitz-layer weights are streamed through LDS), A <= 64.  raw6 = host array of the six device pointers {W0, b0, W1, b1,
  * W2 (normalised), b2}: the exact kernel re-encodes the few uncertified rows from x with them, so z_e is written to
  * HBM only when ze_out is given.  After the call the first int of `workspace` holds the number of rows decided by the
  * exact kernel. */
 int lipvq_tokenize_supported(int A, int J0, int J1, int D, int K);
+int lipvq_tokenize_fast_supported(int A, int J0, int J1, int D, int K);      /* lipvq_tokenize_fast_f32: D in {32, 64, 128} */
 size_t lipvq_tokenize_workspace_bytes(int64_t N, int D);
 int lipvq_tokenize_f32(const float* x, const float* packed, const float* const* raw6, const float* codebook,
                        const void* prep, int64_t* idx, float* zq, int64_t* usage, float* ze_out, void* workspace,

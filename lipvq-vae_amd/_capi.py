@@ -48,6 +48,7 @@ SIGNATURES = {
     "lipvq_nearest_rows_f32": (_i, [_vp] * 5 + [_i64, _i, _i, _vp]),
     "lipvq_screen_debug_f32": (_i, [_vp] * 8 + [C.c_float, _i64, _i, _i, _vp]),
     "lipvq_tokenize_supported": (_i, [_i] * 5),
+    "lipvq_tokenize_fast_supported": (_i, [_i] * 5),
     "lipvq_tokenize_workspace_bytes": (_sz, [_i64, _i]),
     "lipvq_tokenize_f32": (_i, [_vp] * 10 + [_i64] + [_i] * 5 + [_vp]),
     "lipvq_mlp3_packed_f16_bytes": (_sz, [_i] * 4),

@@ -81,6 +81,7 @@ struct TokArgs {
     float* ze_out;               // [N][D] or NULL
     int* amb_count;              // workspace[0]
     int* amb_list;               // [N]
+    const float* w2q;            // layer-2 weights re-laid out for streaming (S > 8 only; lives in the workspace)
     int64_t N;
     int A, D, K;
     float gamma;
@@ -93,8 +94,13 @@ struct TokArgs {
 template <int S, bool FAST>
 __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
     constexpr int TCF = fused_ring_tc(S), NBF = fused_ring_nb(S);
-    constexpr int T0 = 2, T1 = 4, T2 = S / 2;
+    constexpr int T0 = 2, T1 = 4, T2 = (S + 1) / 2;         // S odd (D = 208): the last 32-feature tile is half used
     constexpr int S1 = 16 * T0, S2 = 16 * T1;               // k-steps (pairs) of layers 1 and 2
+    // STREAM2: the Lipschitz layer's weights (T2 x 16 KB of fp32 MFMA A operands: 112 KB at D = 208) do not fit beside the stage
+    // ring, so they are streamed, one 16 KB output-tile slab at a time, through that ring -- which is idle during the encoder
+    // phase -- by the same LDS-DMA + counted-vmcnt mechanism as the codebook (all eight waves work on the same tile).
+    constexpr bool STREAM2 = !FAST && S > 8;
+    static_assert(!FAST || (S % 2 == 0 && S <= 8), "fast mode: D in {32, 64, 128}");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const PackedLayout PL = packed_layout(a.A, 32 * T0, 32 * T1, 16 * S);
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
     float* w_P1 = w_B0 + 32 * T0;                                      // [T1][S1/4][64][4]
     float* w_B1 = w_P1 + (FAST ? T1 * (2 * T0) * 256 : T1 * (S1 / 4) * 256);
     float* w_P2 = w_B1 + 32 * T1;                                      // [T2][S2/4][64][4]
-    float* w_B2 = w_P2 + (FAST ? T2 * (2 * T1) * 256 : T2 * (S2 / 4) * 256);
+    float* w_B2 = w_P2 + (FAST ? T2 * (2 * T1) * 256 : STREAM2 ? 0 : T2 * (S2 / 4) * 256);
     float* w_mu = w_B2 + 32 * T2;                                      // [16*S]
     unsigned char* stage0 = reinterpret_cast<unsigned char*>(w_mu + 16 * S);   // 2 stage buffers (also the
                                                                                 // per-wave transpose slices of the decision)
@@ -146,10 +152,12 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
                 const int q = i & 3, l = (i >> 2) & 63, sq = (i >> 8) % (S1 / 4), t = (i >> 8) / (S1 / 4);
                 w_P1[i] = P1[((size_t)t * S1 + 4 * sq + q) * 64 + l];
             }
-            const float* P2 = a.packed + PL.oP2;
-            for (int i = tid; i < T2 * (S2 / 4) * 256; i += FUSED_THREADS) {
-                const int q = i & 3, l = (i >> 2) & 63, sq = (i >> 8) % (S2 / 4), t = (i >> 8) / (S2 / 4);
-                w_P2[i] = P2[((size_t)t * S2 + 4 * sq + q) * 64 + l];
+            if constexpr (!STREAM2) {
+                const float* P2 = a.packed + PL.oP2;
+                for (int i = tid; i < T2 * (S2 / 4) * 256; i += FUSED_THREADS) {
+                    const int q = i & 3, l = (i >> 2) & 63, sq = (i >> 8) % (S2 / 4), t = (i >> 8) / (S2 / 4);
+                    w_P2[i] = P2[((size_t)t * S2 + 4 * sq + q) * 64 + l];
+                }
             }
         }
         // biases re-laid out [t][h][r] = b[32 t + 2 r + h]: the 16 values of a lane's accumulator tile are 64 contiguous bytes
@@ -221,6 +229,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
         auto finish_tile = [&](const int t, f32x16& acc) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+                if (2 * t + (r >> 3) >= S) continue;             // S odd: features past D in the last tile (zero weights) are not z_e
                 // fast mode: hardware exp2 / rcp (1 ulp each) instead of the canonical exp polynomial + IEEE division
                 const float zv = FAST ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[r] * -1.44269504088896341f))
                                       : FUSED_SIGMOID(acc[r]);
@@ -253,7 +262,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
                 }
                 // low lanes : lo8[j] = feat 2j (own, even), hi8[j] = feat 2j+1 (from the high lane)        -> base 32t
                 // high lanes: lo8[j] = feat 16+2j (from the low lane, even), hi8[j] = feat 16+2j+1 (own) -> base 32t+16
-                if (row < a.N) {
+                if (row < a.N && 2 * t + h < S) {                // (the high lanes' 16 features of a half-used last tile do not exist)
                     float4* dst = reinterpret_cast<float4*>(a.ze_out + (size_t)row * a.D + 32 * t + 16 * h);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) dst[q] = make_float4(lo8[2 * q], hi8[2 * q], lo8[2 * q + 1], hi8[2 * q + 1]);
@@ -357,9 +366,28 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
             f32x16 pend;                      // pre-activations of the previous tile, GELU pending
             constexpr int G1 = S1 / 4, G2 = S2 / 4;             // groups per tile
             auto wread = [&](int gidx) {                        // group gidx of the stream (compile-time after unrolling)
+                if (STREAM2 && gidx >= T1 * G1) gidx = T1 * G1 - 1;             // streamed layer 2: its groups are read from the slab ring
                 return (gidx < T1 * G1) ? *reinterpret_cast<const float4*>(w_P1 + (gidx * 64 + lane) * 4)
                                         : *reinterpret_cast<const float4*>(w_P2 + ((gidx - T1 * G1) * 64 + lane) * 4);
             };
+            auto slab_dma = [&](int t_, int buf_) {             // one 16 KB output-tile slab of layer 2 into a ring buffer: 2 KiB per wave
+                typedef __attribute__((address_space(3))) void* lds_ptr_e;
+                typedef const __attribute__((address_space(1))) void* glb_ptr_e;
+                const unsigned char* src = reinterpret_cast<const unsigned char*>(a.w2q) + (size_t)t_ * (G2 * 1024);
+                unsigned char* dst = stage0 + (size_t)buf_ * ScreenCfg<S, TCF>::STAGE_BYTES;
+#pragma unroll
+                for (int j = 0; j < G2 * 1024 / 1024 / FUSED_WAVES; ++j) {
+                    const int off = (wave + j * FUSED_WAVES) * 1024;
+                    __builtin_amdgcn_global_load_lds((glb_ptr_e)(src + off + lane * 16), (lds_ptr_e)(dst + off), 16, 0, 0);
+                }
+            };
+            if constexpr (STREAM2) {
+                // everyone is past the previous row block's decision scratch (it lives in ring buffers 0 and 1), then the first two
+                // slabs start: they have the whole of layer 1 to land
+                lq_wg_barrier();
+                slab_dma(0, 0);
+                slab_dma(1, 1);
+            }
             float4 wn = wread(0);
             f32x16 bnext = bias16(w_B1, 0);
 #pragma unroll
@@ -369,7 +397,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
                 for (int sq = 0; sq < G1; ++sq) {
                     const float4 av = wn;
                     wn = wread(t * G1 + sq + 1);                 // the next group's weights (layer 2's first group after the last)
-                    if (sq == G1 - 1) bnext = (t + 1 < T1) ? bias16(w_B1, t + 1) : bias16(w_B2, 0);
+                    if (sq == G1 - 1 && (t + 1 < T1 || !STREAM2)) bnext = (t + 1 < T1) ? bias16(w_B1, t + 1) : bias16(w_B2, 0);
                     __builtin_amdgcn_sched_barrier(0x6);         // reads stay in front of this group's MFMAs (VALU/SALU may move)
                     Gelu2 g;
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, h0[(4 * sq + 0) / 16][(4 * sq + 0) % 16], acc, 0, 0, 0);
@@ -397,8 +425,23 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
             }
             LQ_STAMP(1);
             // the last tile's GELU runs inside the first layer-2 chain: steps 0 .. 47 of that chain only read h1[0..2]
+            constexpr int SLAB_BYTES = G2 * 1024;                          // one output tile's A operands: 16 KB
+            constexpr int SLAB_CPW = SLAB_BYTES / 1024 / FUSED_WAVES;
+            static_assert(!STREAM2 || (SLAB_BYTES % (1024 * FUSED_WAVES) == 0 && SLAB_BYTES <= ScreenCfg<S, TCF>::STAGE_BYTES && NBF >= 3),
+                          "slabs ride in the stage ring");
 #pragma unroll
             for (int t = 0; t < T2; ++t) {
+                const float* wslab = w_P2;
+                if constexpr (STREAM2) {
+                    // slab t has landed in every wave's part (slab t+1 may still fly); everyone has left tile t-1, whose buffer
+                    // slab t+2 goes to.  (Slabs 0 and 1 were issued in front of layer 1.)
+                    if (t + 1 < T2) lq_wait_vmcnt<SLAB_CPW>(); else lq_wait_vmcnt<0>();
+                    lq_wg_barrier();
+                    if (t + 2 < T2) slab_dma(t + 2, (t + 2) % 3);
+                    wslab = reinterpret_cast<const float*>(stage0 + (size_t)(t % 3) * ScreenCfg<S, TCF>::STAGE_BYTES);
+                    wn = *reinterpret_cast<const float4*>(wslab + lane * 4);          // the tile's first group (read after the barrier)
+                    bnext = bias16(w_B2, t);                                            // (no bias prefetch here: registers)
+                }
                 f32x16 acc = bnext;
 #pragma unroll
                 for (int sq = 0; sq < G2; ++sq) {
@@ -409,8 +452,12 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
 #endif
                     }
                     const float4 av = wn;
-                    if (t * G2 + sq + 1 < T2 * G2) wn = wread(T1 * G1 + t * G2 + sq + 1);
-                    if (sq == G2 - 1 && t + 1 < T2) bnext = bias16(w_B2, t + 1);
+                    if constexpr (STREAM2) {
+                        if (sq + 1 < G2) wn = *reinterpret_cast<const float4*>(wslab + ((sq + 1) * 64 + lane) * 4);
+                    } else {
+                        if (t * G2 + sq + 1 < T2 * G2) wn = wread(T1 * G1 + t * G2 + sq + 1);
+                    }
+                    if (!STREAM2 && sq == G2 - 1 && t + 1 < T2) bnext = bias16(w_B2, t + 1);
                     __builtin_amdgcn_sched_barrier(0x6);
                     const bool pg = (t == 0 && sq < 8);          // the 16 pending GELUs ride on groups 0..7 (< 12: they only read h1[0..2])
                     Gelu2 g;
@@ -503,7 +550,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
         for (int r = 0; r < 16; ++r) { m1[r] = INFINITY; m2[r] = INFINITY; k1[r] = 0; }
         LQ_STAMP(3);
         if (x_pref) load_x(blk + gridDim.x < nblk ? blk + gridDim.x : blk);      // next row block's inputs: a whole phase ahead
-        constexpr bool PACKF = LQ_PACK_FOR(S);
+        constexpr bool PACKF = LQ_PACK_FOR(S) || S > 8;      // (S = 13: 104 registers of A fragments leave no room for an index array)
         lq_screen_core<S, FUSED_THREADS, TCF, NBF, PACKF>(ah, al, tiles, L.ntiles, stage0, tid, frow, m1, m2, k1);
         LQ_STAMP(4);
         int my_k;
@@ -546,11 +593,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
 
 template <int S, bool FAST>
 static size_t fused_lds_bytes(int A, int K) {
-    constexpr int T0 = 2, T1 = 4, T2 = S / 2;
+    constexpr int T0 = 2, T1 = 4, T2 = (S + 1) / 2;
     const int S0q = ((A + 1) / 2 + 3) / 4;
     const int S0h = (A + 15) / 16;
     size_t fl = FAST ? (size_t)T0 * S0h * 256 + (size_t)T1 * (2 * T0) * 256 + (size_t)T2 * (2 * T1) * 256
-                     : (size_t)T0 * S0q * 256 + (size_t)T1 * 8 * 256 + (size_t)T2 * 16 * 256;
+                     : (size_t)T0 * S0q * 256 + (size_t)T1 * 8 * 256 + (S > 8 ? (size_t)0 : (size_t)T2 * 16 * 256);
     fl += 32 * T0 + 32 * T1 + 32 * T2 + 16 * S;
     const size_t ring = (lq_ring_bytes<S, fused_ring_tc(S), fused_ring_nb(S)>() + 63) & ~(size_t)63;
     return fl * sizeof(float) + ring + (K <= FUSED_HIST_MAX ? (size_t)K * 4 : 0);
@@ -614,12 +661,29 @@ extern "C" int lipvq_mlp3_pack_f16_f32(const float* W0, const float* W1, const f
 }
 
 extern "C" int lipvq_tokenize_supported(int A, int J0, int J1, int D, int K) {
-    return (A > 0 && A <= 64 && J0 == 64 && J1 == 128 && K > 0 && (D == 32 || D == 64 || D == 128)) ? 1 : 0;
+    return (A > 0 && A <= 64 && J0 == 64 && J1 == 128 && K > 0 && (D == 32 || D == 64 || D == 128 || D == 208)) ? 1 : 0;
+}
+
+// the fast mode has no D = 208 instance (its fp16 weights would fit, but the mode exists for BASELINE config 2's shapes)
+extern "C" int lipvq_tokenize_fast_supported(int A, int J0, int J1, int D, int K) {
+    return (lipvq_tokenize_supported(A, J0, J1, D, K) && D != 208) ? 1 : 0;
+}
+
+// layer-2 weights of the streamed instance (D = 208): [t][16 groups][64 lanes][4 k-steps], i.e. the LDS image of one output
+// tile's A operands as contiguous 16 KB slabs, so that the kernel can copy them with the LDS-DMA
+static size_t w2q_floats(int D) { return D > 128 ? (size_t)((D + 31) / 32) * 16 * 256 : 0; }
+
+__global__ void w2q_pack_kernel(const float* __restrict__ P2, float* __restrict__ out, int T2, int S2) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)T2 * (S2 / 4) * 256) return;
+    const int q = (int)(i & 3), l = (int)((i >> 2) & 63), sq = (int)((i >> 8) % (S2 / 4)), t = (int)((i >> 8) / (S2 / 4));
+    out[i] = P2[((size_t)t * S2 + 4 * sq + q) * 64 + l];
 }
 
 extern "C" size_t lipvq_tokenize_workspace_bytes(int64_t N, int D) {
     if (N <= 0 || D <= 0) return 0;
-    return 64 + 2 * sizeof(int) * lq_list_ints(N);                      // uncertified-row counter, row list, candidate list
+    // uncertified-row counter, row list, candidate list, then (D = 208) the streamed layer-2 weights
+    return 64 + 2 * sizeof(int) * lq_list_ints(N) + sizeof(float) * w2q_floats(D);
 }
 
 // Fused encode + quantize (reference v5:71-74).  packed: lipvq_mlp3_pack_f32 of the encoder stack
@@ -650,20 +714,31 @@ static int tokenize_impl(const float* x, const float* packed, const void* packed
     float* ze_buf = ze_out;
     hipError_t e = hipMemsetAsync(amb_count, 0, 64, st);
     if (e != hipSuccess) return fail(LIPVQ_EHIP, "tokenize: %s", hipGetErrorString(e));
+    float* w2q = nullptr;
+    if (w2q_floats(D)) {
+        // the streamed instance: re-lay out layer 2's packed weights into the workspace (one small launch; the weights may have
+        // changed since the last call and the library keeps no state)
+        w2q = reinterpret_cast<float*>(ws + 64 + 2 * sizeof(int) * lq_list_ints(N));
+        const PackedLayout PL = packed_layout(A, J0, J1, D);
+        const size_t n = w2q_floats(D);
+        hipLaunchKernelGGL(w2q_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, packed + PL.oP2, w2q, PL.T2, PL.S2);
+    }
     TokArgs a{x, packed, (const unsigned char*)packed16, (const unsigned char*)prep, codebook, idx, zq,
-              (unsigned long long*)usage, ze_buf, amb_count, amb_list, N, A, D, K, LIPVQ_SCREEN_GAMMA};
+              (unsigned long long*)usage, ze_buf, amb_count, amb_list, w2q, N, A, D, K, LIPVQ_SCREEN_GAMMA};
     int rc;
     if (packed16) {
         switch (D) {
             case 32: rc = launch_tokenize<2, true>(a, st); break;
             case 64: rc = launch_tokenize<4, true>(a, st); break;
-            default: rc = launch_tokenize<8, true>(a, st); break;
+            case 128: rc = launch_tokenize<8, true>(a, st); break;
+            default: return fail(LIPVQ_EUNSUPPORTED, "tokenize_fast: D=%d has no fast instance (32, 64, 128)", D);
         }
     } else {
         switch (D) {
             case 32: rc = launch_tokenize<2, false>(a, st); break;
             case 64: rc = launch_tokenize<4, false>(a, st); break;
-            default: rc = launch_tokenize<8, false>(a, st); break;
+            case 128: rc = launch_tokenize<8, false>(a, st); break;
+            default: rc = launch_tokenize<13, false>(a, st); break;
         }
     }
     if (rc) return rc;

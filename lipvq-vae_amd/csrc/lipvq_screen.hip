@@ -487,6 +487,7 @@ int lipvq_launch_rows_encode(const float* x, const float* const* raw6, int A, co
         case 32: go(nearest_rows_encode_kernel<4>); break;
         case 64: go(nearest_rows_encode_kernel<8>); break;
         case 128: go(nearest_rows_encode_kernel<16>); break;
+        case 208: go(nearest_rows_encode_kernel<26>); break;
         default: return fail(LIPVQ_EUNSUPPORTED, "nearest_rows_encode: D=%d has no instance", D);
     }
     return check_launch("nearest_rows_encode");

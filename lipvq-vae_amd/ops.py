@@ -343,6 +343,10 @@ def tokenize_supported(A, J0, J1, D, K) -> bool:
     return bool(lib.lipvq_tokenize_supported(int(A), int(J0), int(J1), int(D), int(K)))
 
 
+def tokenize_fast_supported(A, J0, J1, D, K) -> bool:
+    return bool(lib.lipvq_tokenize_fast_supported(int(A), int(J0), int(J1), int(D), int(K)))
+
+
 def tokenize_workspace(N: int, D: int, device) -> torch.Tensor:
     """int32 workspace of lipvq_tokenize_f32 (row list + z_e scratch); callers may keep and reuse it."""
     return torch.empty(max(16, (lib.lipvq_tokenize_workspace_bytes(N, D) + 3) // 4), device=device, dtype=torch.int32)

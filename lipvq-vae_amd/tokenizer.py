@@ -198,10 +198,11 @@ class LLFQVAE_V4(_TokenizerBase):
             raise ValueError(f"unknown tokenize mode {mode!r}")
         x = self._as_rows(x)
         usage = self.code_usage if count_usage else None
-        if x.shape[0] > 0 and ops.tokenize_supported(self.feature_dim, 64, self.hidden_dim, self.latent_dim, self.num_codes):
+        shape = (self.feature_dim, 64, self.hidden_dim, self.latent_dim, self.num_codes)
+        if mode == "fast" and not ops.tokenize_fast_supported(*shape):
+            raise RuntimeError("tokenize(mode='fast') needs the fast kernel's shapes (hidden 64/128, D in {32, 64, 128})")
+        if x.shape[0] > 0 and ops.tokenize_supported(*shape):
             idx, zq, _ = self._tokenize_fused(x, usage, fast=(mode == "fast"))
-        elif mode == "fast":
-            raise RuntimeError("tokenize(mode='fast') needs the fused kernel's shapes (hidden 64/128, D in {32, 64, 128})")
         else:
             idx, zq = self._quantize(self.encode(x), usage)
         self.last_indices = idx
