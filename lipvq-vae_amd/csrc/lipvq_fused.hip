@@ -215,6 +215,13 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
         }
     };
     if (x_pref) load_x(blockIdx.x);
+    // the z_q copy of a row block is deferred to the start of the NEXT block (parity kernel) and routed through LDS (lq_gather_dma):
+    // its first round overlaps layer 0, further rounds (wider latents) follow
+    constexpr bool DEFER_GATHER = !FAST;
+    int pend_k = 0;
+    bool pend_ok = false;
+    int64_t pend_row0 = 0;
+    bool have_pend = false;
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
 #ifdef LQ_STAMPS
         st_prev = __builtin_amdgcn_s_memtime();
@@ -298,6 +305,16 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
                 return b;
             };
             f32x16 h0[T0];
+            // the previous block's z_q rows: round 0 of the copy travels codebook -> LDS staging while layer 0 runs
+            constexpr int NTRIP = (16 * S + 63) / 64;                    // 64 floats of every row per gather trip
+            constexpr int GP = (STAGES_BYTES >= (size_t)FUSED_WAVES * 8192) ? 8 : 4;      // passes (KiB per wave) per round
+            constexpr int NROUND = NTRIP * (8 / GP);
+            unsigned char* gstage = stage0 + (size_t)wave * GP * 1024;
+            const bool gnow = DEFER_GATHER && have_pend && a.zq;         // wave-uniform
+            if (gnow) {
+                lq_wg_barrier();                                         // every wave has left the previous block's decision scratch (same ring)
+                lq_gather_dma<GP>(gstage, a.cb, pend_k, pend_ok, pend_row0, a.N, a.D, lane, 0, 0);
+            }
             {
 #pragma unroll
                 for (int t = 0; t < T0; ++t) h0[t] = bias16(w_B0, t);
@@ -355,6 +372,18 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
 #ifndef LQ_ABL_NOGELU
                     gelu_fixup(h0[t], pre);
 #endif
+                }
+            }
+            if (gnow) {
+#pragma unroll
+                for (int rd = 0; rd < NROUND; ++rd) {                    // round rd = (trip rd / (8 / GP), passes GP (rd % (8 / GP)) ...)
+                    lq_wait_vmcnt<0>();
+                    lq_gather_flush<GP>(gstage, a.zq, pend_ok, pend_row0, a.N, a.D, lane, rd / (8 / GP), GP * (rd % (8 / GP)));
+                    if (rd + 1 < NROUND) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // my staging reads are done before it is refilled
+                        lq_gather_dma<GP>(gstage, a.cb, pend_k, pend_ok, pend_row0, a.N, a.D, lane, (rd + 1) / (8 / GP),
+                                          GP * ((rd + 1) % (8 / GP)));
+                    }
                 }
             }
             LQ_STAMP(0);
@@ -570,9 +599,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
         }
         if (a.usage && !use_hist) lq_usage_add(a.usage, my_k, h == 0 && row < a.N && certified);
         LQ_STAMP(5);
-        if (a.zq) lq_screen_gather(a.cb, a.zq, my_k, certified, row0, a.N, a.D, lane);
+        if (DEFER_GATHER) { pend_k = my_k; pend_ok = certified; pend_row0 = row0; have_pend = true; }
+        else if (a.zq) lq_screen_gather(a.cb, a.zq, my_k, certified, row0, a.N, a.D, lane);
         LQ_STAMP(6);
     }
+    if (DEFER_GATHER && have_pend && a.zq) lq_screen_gather(a.cb, a.zq, pend_k, pend_ok, pend_row0, a.N, a.D, lane);   // the last block's
 #ifdef LQ_STAMPS
     if (lane == 0) {
         long long* dbg = reinterpret_cast<long long*>(a.amb_list + (a.N / 2 & ~1)) + ((size_t)blockIdx.x * FUSED_WAVES + wave) * 16;

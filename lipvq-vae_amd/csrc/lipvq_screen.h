@@ -480,31 +480,79 @@ __device__ __forceinline__ void lq_usage_add(unsigned long long* __restrict__ us
 }
 
 // z_q rows of certified rows: 16 lanes copy one codebook row (16 B each), 4 rows per pass
+// z_q rows of certified rows: 16 lanes copy 64 floats of one codebook row (16 B each per pass), 4 rows per pass of the wave, 8
+// passes = the wave's 32 rows; a "trip" covers floats [64 trip, 64 trip + 64) of the rows.
+//  * lq_screen_gather: loads of all eight passes of a trip, then the stores (the first version waited for each pass's load
+//    before storing: eight L2 round trips).
+//  * lq_gather_dma / lq_gather_flush (fused kernel): the copy goes THROUGH LDS -- LDS-DMA with per-lane source addresses (the
+//    gather) into a per-wave staging area, later LDS -> registers -> global stores -- so that no registers hold the rows while
+//    the encoder's first layer runs in between (held in registers, hipcc spilled them to scratch and waited for every load).
+struct LqGatherTrip { float4 val[8]; };
+__device__ __forceinline__ void lq_gather_load(LqGatherTrip& g, const float* __restrict__ cb, int my_k, bool row_ok, int64_t row0,
+                                               int64_t N, int D, int lane, int trip) {
+    const int nvec = D / 4;
+    const int v = 16 * trip + (lane & 15);
+    const int vc = v < nvec ? v : nvec - 1;                     // always a valid address
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int src_lane = 4 * p + (lane >> 4);
+        const int kk = __shfl(my_k, src_lane, 64);
+        const bool ok = (__shfl((int)row_ok, src_lane, 64) != 0) && (row0 + src_lane < N);
+        g.val[p] = reinterpret_cast<const float4*>(cb + (size_t)(ok ? kk : 0) * D)[vc];     // certified rows have 0 <= kk < K
+    }
+}
+__device__ __forceinline__ void lq_gather_store(const LqGatherTrip& g, float* __restrict__ zq, bool row_ok, int64_t row0, int64_t N,
+                                                int D, int lane, int trip) {
+    const int nvec = D / 4;
+    const int v = 16 * trip + (lane & 15);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int src_lane = 4 * p + (lane >> 4);
+        const bool ok = (__shfl((int)row_ok, src_lane, 64) != 0) && (row0 + src_lane < N) && (v < nvec);
+        if (ok) reinterpret_cast<float4*>(zq + (size_t)(row0 + src_lane) * D)[v] = g.val[p];
+    }
+}
+// passes [p0, p0 + NP) of one trip: codebook bytes -> this wave's LDS staging area (NP KiB), no registers
+template <int NP>
+__device__ __forceinline__ void lq_gather_dma(unsigned char* wave_stage, const float* __restrict__ cb, int my_k, bool row_ok,
+                                              int64_t row0, int64_t N, int D, int lane, int trip, int p0) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+    const int nvec = D / 4;
+    const int v = 16 * trip + (lane & 15);
+    const int vc = v < nvec ? v : nvec - 1;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int src_lane = 4 * (p0 + p) + (lane >> 4);
+        const int kk = __shfl(my_k, src_lane, 64);
+        const bool ok = (__shfl((int)row_ok, src_lane, 64) != 0) && (row0 + src_lane < N);
+        const float4* src = reinterpret_cast<const float4*>(cb + (size_t)(ok ? kk : 0) * D) + vc;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(wave_stage + p * 1024), 16, 0, 0);
+    }
+}
+// ... and from the staging area to z_q (call after the copies have landed: vmcnt)
+template <int NP>
+__device__ __forceinline__ void lq_gather_flush(const unsigned char* wave_stage, float* __restrict__ zq, bool row_ok, int64_t row0,
+                                                int64_t N, int D, int lane, int trip, int p0) {
+    const int nvec = D / 4;
+    const int v = 16 * trip + (lane & 15);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int src_lane = 4 * (p0 + p) + (lane >> 4);
+        const bool ok = (__shfl((int)row_ok, src_lane, 64) != 0) && (row0 + src_lane < N) && (v < nvec);
+        const float4 val = *reinterpret_cast<const float4*>(wave_stage + p * 1024 + lane * 16);
+        if (ok) reinterpret_cast<float4*>(zq + (size_t)(row0 + src_lane) * D)[v] = val;
+    }
+}
 __device__ __forceinline__ void lq_screen_gather(const float* __restrict__ cb, float* __restrict__ zq, int my_k,
                                                  bool certified, int64_t row0, int64_t N, int D, int lane) {
 #ifdef LQ_ABL_NOGATHER
     return;
 #endif
-    // 16 lanes copy one codebook row (16 B each per pass), 4 rows per pass of the wave; the loads of all eight passes are
-    // issued before the first store (the first version waited for each pass's load before storing: eight L2 round trips)
-    const int nvec = D / 4;
-    for (int v0 = 0; v0 < nvec; v0 += 16) {                     // 64 floats of the row per trip (one trip for D <= 64)
-        const int v = v0 + (lane & 15);
-        float4 val[8];
-        bool okv[8];
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int src_lane = 4 * p + (lane >> 4);
-            const int kk = __shfl(my_k, src_lane, 64);
-            okv[p] = (__shfl((int)certified, src_lane, 64) != 0) && (row0 + src_lane < N) && (v < nvec);
-            const int vc = v < nvec ? v : nvec - 1;             // always a valid address (certified rows have 0 <= kk < K)
-            val[p] = reinterpret_cast<const float4*>(cb + (size_t)(okv[p] ? kk : 0) * D)[vc];
-        }
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int src_lane = 4 * p + (lane >> 4);
-            if (okv[p]) reinterpret_cast<float4*>(zq + (size_t)(row0 + src_lane) * D)[v] = val[p];
-        }
+    for (int trip = 0; 64 * trip < D; ++trip) {
+        LqGatherTrip g;
+        lq_gather_load(g, cb, my_k, certified, row0, N, D, lane, trip);
+        lq_gather_store(g, zq, certified, row0, N, D, lane, trip);
     }
 }
 
