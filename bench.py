@@ -195,6 +195,8 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sustained", type=int, default=1000, help="back-to-back launches of the sustained reading (0 = skip)")
+    ap.add_argument("--metric-only", action="store_true",
+                    help="skip the fast-mode / full-forward / training-step side readings (profiling runs: every dispatch is then the metric's)")
     ap.add_argument("--rehearse-launcher", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -375,7 +377,7 @@ def main():
     }
     if sustained is not None:
         out["sustained"] = sustained
-    if world == 1 and ops.tokenize_fast_supported(A, 64, model.hidden_dim, D, K):
+    if world == 1 and not args.metric_only and ops.tokenize_fast_supported(A, 64, model.hidden_dim, D, K):
         # reported beside the metric, never as `value`: the opt-in fast mode (fp16 encoder GEMMs, fp32 accumulation and
         # quantizer) on the same batch, with the fraction of indices that differ from the parity run above
         for _ in range(3):
@@ -392,7 +394,7 @@ def main():
                             "dtype": "f16 encoder operands, f32 accumulation, f32 quantizer",
                             "index_flip_rate_vs_parity": float((idx_fast != idx_timed).float().mean().item()),
                             "note": "opt-in (tokenize(mode='fast')); not bit-identical, hence not the reported value"}
-    if world == 1:
+    if world == 1 and not args.metric_only:
         # "report also full fwd (+decode+loss) and fwd+bwd+AdamW step" -- same batch, a few steps each,
         # beside the metric (never `value`)
         def timed_ms(fn, n):

@@ -217,7 +217,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
     if (x_pref) load_x(blockIdx.x);
     // the z_q copy of a row block is deferred to the start of the NEXT block (parity kernel) and routed through LDS (lq_gather_dma):
     // its first round overlaps layer 0, further rounds (wider latents) follow
+#ifdef LQ_NO_DEFER_GATHER
+    constexpr bool DEFER_GATHER = false;
+#else
     constexpr bool DEFER_GATHER = !FAST;
+#endif
     int pend_k = 0;
     bool pend_ok = false;
     int64_t pend_row0 = 0;

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 OUT=gpurun_out/$1; shift
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline --sustained 0 $@"
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --sustained 0 --metric-only $@"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES \
   --output-format csv -d $OUT/pmc_a -- python3 bench.py $ARGS > $OUT/pmc_a.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA \
