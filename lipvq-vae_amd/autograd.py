@@ -22,6 +22,17 @@ _DEC_ACTS = (ACT_GELU, ACT_GELU, ACT_NONE)
 _RELU3 = (ACT_RELU, ACT_RELU, ACT_RELU)
 
 
+def _check_versions(ctx, params):
+    """The backward kernels read the module's LIVE weights; refuse to run if one was modified in place since the forward."""
+    saved = getattr(ctx, "param_versions", None)
+    if saved is None:
+        return
+    for i, (p, v) in enumerate(zip(params, saved)):
+        if p._version != v:
+            raise RuntimeError(f"lipvq: parameter #{i} (shape {tuple(p.shape)}) was modified in place between forward and "
+                               f"backward (version {v} -> {p._version}); the gradient would be computed with the new weights")
+
+
 class _LLFQFn(torch.autograd.Function):
     """(z_latent, loss) = f(x, 14 parameters).  z_latent is non-differentiable (v5:74)."""
 
@@ -53,13 +64,18 @@ class _LLFQFn(torch.autograd.Function):
         ctx.module = module
         if need_grad:
             ctx.save_for_backward(x, z_e, z_q, idx, x_rec, Wn, scale, *pre_e, *pre_d)
+            # backward() re-reads the module's live weights (decoder, codebook, encoder, to_latent): remember their versions, so
+            # that a parameter update between forward and backward raises, as torch's saved-tensor check would
+            ctx.param_versions = tuple(p._version for p in params)
         ctx.mark_non_differentiable(z_q)
         return z_q, loss
 
     @staticmethod
     def backward(ctx, _g_latent, g_loss):
         from .backward import llfq_backward
-        grads = llfq_backward(ctx.module, ctx.saved_tensors, g_loss)
+        m = ctx.module
+        _check_versions(ctx, (*m._enc_params(), m.quantizer.codebook, *m._dec_params()))
+        grads = llfq_backward(m, ctx.saved_tensors, g_loss)
         return (None, None) + tuple(grads)
 
 
@@ -112,13 +128,16 @@ class _VQFn(torch.autograd.Function):
         ctx.module = module
         if need_grad:
             ctx.save_for_backward(x, z_e, z_q, z_st, idx, x_rec, *pre_e, *pre_d)
+            ctx.param_versions = tuple(p._version for p in params)
         ctx.mark_non_differentiable(z_st)
         return z_st, loss
 
     @staticmethod
     def backward(ctx, _g_latent, g_loss):
         from .backward import vq_backward
-        grads = vq_backward(ctx.module, ctx.saved_tensors, g_loss)
+        m = ctx.module
+        _check_versions(ctx, (*m._enc_params(), *m._dec_params(), m.embedding.weight))
+        grads = vq_backward(m, ctx.saved_tensors, g_loss)
         return (None, None) + tuple(grads)
 
 
@@ -140,6 +159,7 @@ class _ManualCtx:
         self.needs_input_grad = (False, False) + (True,) * n
         self.saved_tensors = ()
         self.module = None
+        self.param_versions = None
 
     def save_for_backward(self, *tensors):
         self.saved_tensors = tensors

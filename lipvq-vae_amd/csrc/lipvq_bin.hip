@@ -216,13 +216,9 @@ int lipvq_bin_hidden_f32(const int64_t* bins, const float* P, const float* b1, f
     const int Hpad = (H + 63) / 64 * 64;
     if (SW > Hpad) SW = Hpad;
     const int slices = (int)((H + SW - 1) / SW);
-    static bool attr_set = false;
     const size_t lds = (size_t)rowsP * SW * sizeof(float);
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)bin_hidden_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess)
-            return fail(LIPVQ_EHIP, "lipvq_bin_hidden_f32: cannot raise the dynamic LDS limit");
-        attr_set = true;
-    }
+    static LqLdsReserve reserved;               // per-device, thread-safe (lipvq_common.h)
+    if (int rc = lipvq_reserve_lds(reserved, (const void*)bin_hidden_kernel, 160 * 1024 - 64, "lipvq_bin_hidden_f32")) return rc;
     int gx = 512 / slices;                               // two 16-wave workgroups per CU
     if (gx < 1) gx = 1;
     const int64_t need = (N + 16 * BINH_ROWS - 1) / (16 * BINH_ROWS);

@@ -12,6 +12,20 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Dynamic-LDS reservation of a kernel (hipFuncAttributeMaxDynamicSharedMemorySize): the attribute belongs to the (function,
+// device) pair, so the "already raised to" bookkeeping is kept PER DEVICE and in atomics -- a process that drives several
+// GPUs, or several host threads, must not launch with more LDS than the current device has been told about.  (The first
+// version kept one `static size_t` per kernel: per process, unsynchronised.)  The attribute call costs ~10 us of host
+// time, hence the bookkeeping; a lost race only repeats the call.
+#ifdef __cplusplus
+#include <atomic>
+struct LqLdsReserve {
+    static constexpr int kMaxDev = 64;
+    std::atomic<size_t> got[kMaxDev];
+};
+int lipvq_reserve_lds(LqLdsReserve& r, const void* kernel, size_t bytes, const char* what);
+#endif
+
 // error plumbing (defined in lipvq_misc.hip)
 int lipvq_fail(int code, const char* fmt, ...);
 int lipvq_check_launch(const char* what);

@@ -643,12 +643,8 @@ static int launch_tokenize(const TokArgs& a, hipStream_t st) {
     const size_t lds = fused_lds_bytes<S, FAST>(a.A, a.K);
     if (lds > 160 * 1024) return fail(LIPVQ_EUNSUPPORTED, "tokenize: %zu B of LDS needed", lds);
     auto kfn = tokenize_kernel<S, FAST>;
-    static size_t reserved = 0;                 // per instantiation; the attribute call costs ~10 us of host time
-    if (lds > reserved) {
-        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(LIPVQ_EHIP, "tokenize: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-        reserved = lds;
-    }
+    static LqLdsReserve reserved;               // per instantiation: per-device, thread-safe (lipvq_common.h)
+    if (int rc = lipvq_reserve_lds(reserved, (const void*)kfn, lds, "tokenize")) return rc;
     int64_t nblk = (a.N + FUSED_WAVES * 32 - 1) / (FUSED_WAVES * 32);
     int64_t blocks = nblk < 256 ? nblk : 256;            // one persistent workgroup per CU
     hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(FUSED_THREADS), lds, st, a);

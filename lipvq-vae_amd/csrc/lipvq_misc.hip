@@ -128,3 +128,18 @@ extern "C" int lipvq_mse_pair_f32(const float* xr, const float* x, int64_t nx, c
     hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, st, part, nx, nz, out2);
     return check_launch("mse_pair");
 }
+
+
+int lipvq_reserve_lds(LqLdsReserve& r, const void* kernel, size_t bytes, const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(LIPVQ_EHIP, "%s: no current device", what);
+    const bool tracked = dev >= 0 && dev < LqLdsReserve::kMaxDev;
+    if (tracked && bytes <= r.got[dev].load(std::memory_order_acquire)) return LIPVQ_OK;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return fail(LIPVQ_EHIP, "%s: cannot reserve %zu B of LDS: %s", what, bytes, hipGetErrorString(e));
+    if (tracked) {
+        size_t cur = r.got[dev].load(std::memory_order_relaxed);
+        while (cur < bytes && !r.got[dev].compare_exchange_weak(cur, bytes, std::memory_order_release)) {}
+    }
+    return LIPVQ_OK;
+}

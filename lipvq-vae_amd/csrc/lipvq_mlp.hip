@@ -425,12 +425,8 @@ static int launch_mlp3_wg(const Mlp3Args& a, hipStream_t st, const char* what, b
     const int64_t ntiles = (a.N + 31) / 32;
     const size_t lds = ((size_t)2 * ((a.K0 + 1) / 2) + a.J0 + a.J1) * MLPS_LD * sizeof(float);
     if (ntiles > mlp3_small_tiles() || lds > 150 * 1024) return LIPVQ_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)mlp3_wg_kernel<BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
-            return fail(LIPVQ_EHIP, "%s: cannot raise the dynamic LDS limit", what);
-        attr_set = true;
-    }
+    static LqLdsReserve reserved;               // per-device, thread-safe (lipvq_common.h)
+    if (int rc = lipvq_reserve_lds(reserved, (const void*)mlp3_wg_kernel<BWD>, 150 * 1024, what)) return rc;
     if (ntiles > 0x7fffffffLL) return LIPVQ_OK;
     hipLaunchKernelGGL(mlp3_wg_kernel<BWD>, dim3((unsigned)ntiles), dim3(64 * MLPS_WAVES), lds, st, a);
     *done = true;

@@ -511,12 +511,9 @@ static int launch_screen(const float* z, const unsigned char* prep, const float*
     const int64_t rows_per_block = SCREEN_WAVES * 32;
     unsigned blocks = (unsigned)((N + rows_per_block - 1) / rows_per_block);
     auto kfn = dbg ? screen_kernel<S, true> : screen_kernel<S, false>;
-    static size_t reserved[2] = {64 * 1024, 64 * 1024};      // per instantiation and kernel flavour
-    if (lds > reserved[dbg ? 1 : 0]) {
-        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(LIPVQ_EHIP, "screen: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-        reserved[dbg ? 1 : 0] = lds;
-    }
+    static LqLdsReserve reserved[2];            // per instantiation and kernel flavour: per-device, thread-safe (lipvq_common.h)
+    if (lds > 64 * 1024)
+        if (int rc = lipvq_reserve_lds(reserved[dbg ? 1 : 0], (const void*)kfn, lds, "screen")) return rc;
     hipLaunchKernelGGL(kfn, dim3(blocks), dim3(SCREEN_WAVES * 64), lds, st, z, prep, cb, idx, zq,
                        (unsigned long long*)usage, amb_list, amb_count, dbg, N, K, D, gamma);
     return check_launch("screen");

@@ -70,3 +70,77 @@ class VQTokenizerTrainer:
             sharded.all_reduce_gradients(self.model.parameters(), prompt_actions.shape[0], n_global, self.group)
         self.vq_optimizer.step()
         return context_actions, loss.detach()
+
+
+class GraphedTokenizerStep:
+    """The tokenizer's training step (icl.py:913-914 zero_grad, forward, :968-970 backward + AdamW) captured ONCE into a HIP
+    graph and replayed: at the ICRT step shape (N = 80) the eager step is host bound (~60 launches of 7-10 us of Python +
+    ctypes each), a replay is one call.
+
+    What makes the capture safe (round 1's attempt faulted on replay "when the model had been trained eagerly before capture"):
+    a captured graph refers to every buffer BY ADDRESS.  The eager steps had left derived buffers behind -- packed weights,
+    the prepared codebook, the fused launch's workspace, all owned by Python-side caches keyed on the parameters' version --
+    in the ordinary allocator; the capture recorded their addresses, and the next eager call (or the cache refresh that an
+    optimizer step triggers) freed them, so a replay read and wrote memory the allocator had handed to someone else.  Here
+
+      * ``invalidate_caches()`` runs before the capture, so that every derived buffer is rebuilt INSIDE it: the pack /
+        prepare kernels become graph nodes (each replay re-packs the weights the previous replay's AdamW wrote) and their
+        buffers live in the graph's private pool, at addresses nobody else is ever given;
+      * the step is the engine-free ``autograd.forward_backward`` (no autograd-engine streams or AccumulateGrad nodes),
+        gradients are assigned to ``p.grad`` once, at capture (graph-pool tensors that every replay rewrites), and AdamW is
+        ``capturable`` (its step counter lives on the device);
+      * warm-up steps (real training steps, on a side stream) run before the capture, so that lazy one-time work -- the
+        per-device LDS reservations (hipFuncSetAttribute), AdamW's state -- is not issued while capturing;
+      * ``invalidate_caches()`` runs again after the capture and after every replay: a replayed optimizer step does not
+        bump ``Tensor._version``, so eager code must never trust caches that predate it.
+    The input is copied into a static buffer; shapes are fixed at construction."""
+
+    def __init__(self, vq_vae_model: nn.Module, example_actions: torch.Tensor, lr: float = 1e-3, weight_decay: float = 1e-4,
+                 optimizer_state: dict | None = None, warmup: int = 2):
+        from .autograd import forward_backward
+        self.model = vq_vae_model
+        self._fb = forward_backward
+        self.static_x = example_actions.detach().clone().contiguous()
+        self.vq_optimizer = torch.optim.AdamW(vq_vae_model.parameters(), lr=lr, weight_decay=weight_decay, capturable=True)
+        if optimizer_state is not None:
+            import copy
+            # continue an eager run: moments and step count carry over.  Deep copy: Optimizer.load_state_dict keeps the very
+            # tensors it is handed when they already have the right device and dtype -- two optimizers would share moments
+            self.vq_optimizer.load_state_dict(copy.deepcopy(optimizer_state))
+            for grp in self.vq_optimizer.param_groups:
+                grp["capturable"] = True
+                for prm in grp["params"]:                            # an eager AdamW keeps `step` on the host
+                    st = self.vq_optimizer.state.get(prm)
+                    if st and "step" in st:
+                        st["step"] = torch.as_tensor(float(st["step"]), dtype=torch.float32, device=prm.device)
+        self.warmup_steps = int(warmup)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(self.warmup_steps):
+                self._eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.model.invalidate_caches()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._loss = self._eager_step()
+        self.model.invalidate_caches()
+
+    def _eager_step(self):
+        z, loss, params, grads = self._fb(self.model, self.static_x)
+        for p, g in zip(params, grads):
+            p.grad = g
+        self.vq_optimizer.step()
+        self._z = z
+        return loss
+
+    def step(self, prompt_actions: torch.Tensor):
+        """One training step on a batch of the captured shape: (context_actions, loss) -- static tensors, valid until the
+        next step."""
+        if prompt_actions.shape != self.static_x.shape:
+            raise ValueError(f"graphed step was captured for {tuple(self.static_x.shape)}, got {tuple(prompt_actions.shape)}")
+        self.static_x.copy_(prompt_actions)
+        self.graph.replay()
+        self.model.invalidate_caches()
+        return self._z, self._loss

@@ -32,7 +32,12 @@ __all__ = ["LLFQVAE_V4", "VQVAE", "LipschitzMLP", "LFQQuantizer"]
 
 class _PackCache:
     """Re-lays weights out for the MFMA kernels only when a parameter changed (an optimizer
-    step bumps ``Tensor._version``; ``.to()``/``load_state_dict`` change data_ptr/version)."""
+    step bumps ``Tensor._version``; ``.to()``/``load_state_dict`` change data_ptr/version).
+
+    What the key CANNOT see: writes that bypass autograd's version counter -- ``p.data.add_(..)`` (the reference's own
+    ``embedding.weight.data.uniform_()`` idiom), a captured optimizer step replayed from a HIP graph, a raw-pointer writer.
+    After such a write call ``module.invalidate_caches()``; ``load_state_dict``, ``_apply`` (``.to()``, ``.cuda()``,
+    ``.float()``) and ``train()`` / ``eval()`` do it by themselves."""
 
     def __init__(self):
         self._key = None
@@ -44,6 +49,10 @@ class _PackCache:
             self._val = build()
             self._key = key
         return self._val
+
+    def invalidate(self):
+        self._key = None
+        self._val = None
 
 
 class LipschitzMLP(nn.Module):
@@ -84,10 +93,36 @@ class _TokenizerBase(nn.Module):
         self._dec_cache = _PackCache()
         self._cb_cache = _PackCache()
         self._enc16_cache = _PackCache()
+        self._tok_ws, self._tok_ws_key = None, None
         self.last_exact_rows = None      # int32 device tensor: element 0 = rows the screen could not certify
 
     def reset_usage(self):
         self.code_usage.zero_()
+
+    # -- derived buffers (packed weights, prepared codebook, fused-launch workspace) -------------------
+    def invalidate_caches(self):
+        """Drop everything derived from the parameters; the next call rebuilds it.  Needed after a write the version
+        counter does not see (see _PackCache); cheap (a few small launches on the next forward)."""
+        for c in (self._enc_cache, self._dec_cache, self._cb_cache, self._enc16_cache):
+            c.invalidate()
+        self._tok_ws, self._tok_ws_key = None, None
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_caches()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        if hasattr(self, "_enc_cache"):
+            self.invalidate_caches()
+        return out
+
+    def train(self, mode: bool = True):
+        out = super().train(mode)
+        if hasattr(self, "_enc_cache"):
+            self.invalidate_caches()
+        return out
 
     def perplexity(self):
         """exp(entropy) of the accumulated code-usage histogram."""
@@ -176,7 +211,7 @@ class LLFQVAE_V4(_TokenizerBase):
         w0, b0, w1, b1, _, b2, _ = (t.detach() for t in self._enc_params())
         prep = self._cb_cache.get((self.quantizer.codebook,), lambda: ops.nearest_prepare(cb))
         key = (x.shape[0], x.device)
-        if getattr(self, "_tok_ws_key", None) != key:        # the scratch (row list) is reused across calls
+        if self._tok_ws_key != key:                          # the scratch (row list) is reused across calls
             self._tok_ws, self._tok_ws_key = ops.tokenize_workspace(x.shape[0], self.latent_dim, x.device), key
         packed16 = None
         if fast:

@@ -179,7 +179,56 @@ def run_nearties(ref, name, seed, N, K, D, chunk):
           f"{int(((d2 - d1) / np.maximum(d2, 1e-30) < 1e-6).sum())}")
 
 
+def run_llfq_train_compact(ref, name, seed, N, A, D, K, steps=3, oracle=None):
+    """BASELINE config 5's tokenizer step at the REAL shape (obs_nets.py:2411 A = 12, latent = 208, K = 1024, N = 8 x 10 prompt
+    actions): `steps` iterations of the reference's choreography (icl.py:913-914 zero_grad, forward, :968-970 backward + AdamW).
+    The codebook alone is 852 KB, so the fixture keeps, per step, the loss and the indices, and after the LAST step every
+    parameter except the codebook in full, the codebook rows the batches touched (+ 32 untouched ones) and a float64 checksum of
+    the whole codebook; the first step's gradients are kept the same way.  Inputs: make_inputs(seed + step)."""
+    p = O.make_params(seed, A, D, K, regime="trained", variant="llfq", oracle=oracle)
+    model = ref.LLFQVAE_V4(A, D, num_codes=K)
+    model.load_state_dict(O.to_torch(p), strict=True)
+    model = model.float()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)      # icl.py:887-889
+    out = dict(meta=meta_of(name=name, seed=seed, N=N, A=A, D=D, K=K, regime="trained", variant="llfq-train-compact", steps=steps),
+               seed=seed, N=N, A=A, D=D, K=K, steps=steps, params_sha256=np.array(O.params_digest(p)))
+    touched = set()
+    for st in range(steps):
+        x = torch.from_numpy(O.make_inputs(seed + st, N, A).copy())
+        opt.zero_grad()
+        z_latent, loss = model(x)
+        with torch.no_grad():
+            _, idx = model.quantizer(model.to_latent(model.encoder(x)))
+        loss.backward()
+        out[f"loss{st}"] = np.float32(loss.item())
+        out[f"indices{st}"] = idx.numpy().astype(np.uint16)
+        touched |= set(idx.numpy().tolist())
+        if st == 0:
+            rows0 = np.array(sorted(set(idx.numpy().tolist())), dtype=np.int32)
+            for k, v in model.named_parameters():
+                g = v.grad.numpy()
+                if k == "quantizer.codebook":
+                    out["grad0_rows"] = rows0
+                    out["grad0/" + k] = g[rows0].copy()
+                    out["grad0_codebook_abs_sum"] = np.float64(np.abs(g.astype(np.float64)).sum())
+                else:
+                    out["grad0/" + k] = g.copy()
+        opt.step()
+    rows = np.array(sorted(touched | set(range(K - 32, K))), dtype=np.int32)
+    for k, v in model.state_dict().items():
+        if k == "quantizer.codebook":
+            out["post_rows"] = rows
+            out["post/" + k] = v.numpy()[rows].copy()
+            out["post_codebook_sum"] = np.float64(v.numpy().astype(np.float64).sum())
+        else:
+            out["post/" + k] = v.numpy().copy()
+    np.savez_compressed(GOLD / f"{name}.npz", **out)
+    print(f"{name}: N={N} A={A} D={D} K={K} steps={steps} codes touched={len(touched)} losses="
+          f"{[float(out[f'loss{i}']) for i in range(steps)]}")
+
+
 def run_big_all(v5, orc):
+    run_llfq_train_compact(v5, "llfq_icrt_train_k1024", 701, 80, 12, 208, 1024, steps=3, oracle=orc)
     run_nearties(v5, "llfq_nearties_d128_k8192", 601, 1024, 8192, 128, chunk=32)
     run_nearties(v5, "llfq_nearties_d208_k1024", 602, 2048, 1024, 208, chunk=128)
     run_nearties(v5, "llfq_nearties_d64_k1024", 603, 2048, 1024, 64, chunk=256)

@@ -9,14 +9,17 @@ from oracle import lipvq_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def test_action_branch_training_loop_tracks_reference(oracle):
+@pytest.mark.parametrize("K", [128, 1024])
+def test_action_branch_training_loop_tracks_reference(oracle, K):
     from lipvq_vae_amd.icl import ICLActionBranch, VQTokenizerTrainer, time_distributed
-    A, D, K, B, T = 12, 208, 128, 8, 10           # the real ICRT step shape (image mode: 8 x 10 prompt actions)
+    A, D, B, T = 12, 208, 8, 10                   # the real ICRT step shape (image mode: 8 x 10 prompt actions)
     p = O.make_params(31, A, D, K, oracle=oracle)
     branch = ICLActionBranch(A, D).cuda()
-    # the branch builds the default K=1024 tokenizer; swap in a K=128 one to keep the CPU side quick
+    # the branch builds the reference's default K = 1024 tokenizer (v5:52); K = 128 is the authors' __main__ width (v5:92)
     from lipvq_vae_amd.tokenizer import LLFQVAE_V4
-    branch.action_network = LLFQVAE_V4(A, D, num_codes=K).cuda()
+    if K != 1024:
+        branch.action_network = LLFQVAE_V4(A, D, num_codes=K).cuda()
+    assert branch.action_network.num_codes == K
     branch.action_network.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in p.items()})
     trainer = VQTokenizerTrainer(branch.action_network)
     tp = {k: v.requires_grad_(True) for k, v in O.to_torch(p).items()}
@@ -94,3 +97,109 @@ def test_bin_branch_feeds_the_embedding_stage(oracle, golden_dir):
     oracle.embed_rows(oracle.linear(r["out"], W, b), None, ep["embed_timestep"][0], ep["embed_ln.weight"], ep["embed_ln.bias"],
                       1e-5, want, T, 3 * T * E, 2 * E, E)
     assert np.array_equal(out.detach().cpu().numpy()[:, 1:2 * T:2], want[:, 1:2 * T:2])
+
+
+def test_icrt_training_steps_k1024_vs_reference_fixture(oracle, golden_dir):
+    """BASELINE config 5 at the REAL shape (A = 12, D = 208, K = 1024, N = 8 x 10): three tokenizer steps through the product
+    (ICLActionBranch + VQTokenizerTrainer: icl.py:913-914, 968-970) against what the REFERENCE module produced
+    (tests/golden/llfq_icrt_train_k1024.npz): losses, indices, first-step gradients, final parameters."""
+    from lipvq_vae_amd.icl import ICLActionBranch, VQTokenizerTrainer
+    g = np.load(golden_dir / "llfq_icrt_train_k1024.npz")
+    A, D, K, N, steps, seed = (int(g[k]) for k in ("A", "D", "K", "N", "steps", "seed"))
+    p = O.make_params(seed, A, D, K, regime="trained", oracle=oracle)
+    assert O.params_digest(p) == str(g["params_sha256"])
+    branch = ICLActionBranch(A, D).cuda()
+    net = branch.action_network
+    assert net.num_codes == K
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in p.items()})
+    trainer = VQTokenizerTrainer(net)
+    for st in range(steps):
+        xt = torch.from_numpy(O.make_inputs(seed + st, N, A)).cuda()
+        if st == 0:                                                    # first step by hand, to look at its gradients
+            trainer.vq_optimizer.zero_grad()
+            _, loss = net(xt)
+            loss.backward()
+            for k, v in net.named_parameters():
+                ref = g["grad0/" + k]
+                got = v.grad.cpu().numpy()
+                if k == "quantizer.codebook":
+                    assert abs(np.abs(got.astype(np.float64)).sum() - float(g["grad0_codebook_abs_sum"])) <= 1e-5 * float(g["grad0_codebook_abs_sum"])
+                    got = got[g["grad0_rows"]]
+                assert np.abs(got - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-12), k
+            trainer.vq_optimizer.step()
+        else:
+            _, loss = trainer.train_on_actions(xt)
+        assert abs(loss.item() - float(g[f"loss{st}"])) <= 2e-5 * abs(float(g[f"loss{st}"])), st
+        assert np.array_equal(net.last_indices.cpu().numpy(), g[f"indices{st}"].astype(np.int64)), st
+    sd = net.state_dict()
+    for k in O.LLFQ_KEYS:
+        got = sd[k].cpu().numpy()
+        if k == "quantizer.codebook":
+            assert abs(got.astype(np.float64).sum() - float(g["post_codebook_sum"])) <= 1e-6 * abs(float(g["post_codebook_sum"]))
+            got = got[g["post_rows"]]
+        ref = g["post/" + k]
+        assert np.abs(got - ref).max() <= 3.2e-3, k                   # three AdamW steps move a weight by <= 3e-3
+        assert np.isclose(got, ref, rtol=0, atol=2e-5).mean() > 0.995, k
+
+
+def test_graphed_training_step_after_eager_training_equals_eager_trajectory(oracle):
+    """Round 1's HIP-graph attempt faulted on replay when the model had been trained eagerly before the capture.  Three eager
+    steps, then capture (GraphedTokenizerStep: caches invalidated so that every derived buffer lives in the graph's pool), then
+    three replays -- interleaved with eager calls that rebuild the Python-side caches, the pattern that used to free buffers the
+    graph still referred to -- must follow the all-eager trajectory of a twin model."""
+    import copy
+    from lipvq_vae_amd.icl import GraphedTokenizerStep, VQTokenizerTrainer
+    from lipvq_vae_amd.tokenizer import LLFQVAE_V4
+    A, D, K, N = 12, 208, 1024, 80
+    p = O.make_params(77, A, D, K, oracle=oracle)
+    model = LLFQVAE_V4(A, D, num_codes=K).cuda()
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in p.items()})
+    xs = [torch.from_numpy(O.make_inputs(300 + i, N, A)).cuda() for i in range(8)]
+    tr = VQTokenizerTrainer(model)
+    for i in range(3):
+        tr.train_on_actions(xs[i])
+    twin = copy.deepcopy(model)
+    twin.invalidate_caches()
+    tw = VQTokenizerTrainer(twin)
+    tw.vq_optimizer.load_state_dict(copy.deepcopy(tr.vq_optimizer.state_dict()))     # (load_state_dict would alias the moments)
+    # capture: two warm-up steps on xs[3] (real steps), then the graph
+    g = GraphedTokenizerStep(model, xs[3], optimizer_state=tr.vq_optimizer.state_dict(), warmup=2)
+    for _ in range(2):
+        tw.train_on_actions(xs[3])
+    losses = []
+    for i in range(4, 7):
+        _, loss = g.step(xs[i])
+        losses.append(float(loss))
+        # eager use of the SAME model between replays (rebuilds packed weights / prepared codebook in the ordinary allocator)
+        idx_e, _ = model.tokenize(xs[7], count_usage=False)
+        _, ref_loss = tw.train_on_actions(xs[i])
+        assert abs(losses[-1] - float(ref_loss)) <= 2e-5 * abs(float(ref_loss)), i
+        idx_t, _ = twin.tokenize(xs[7], count_usage=False)
+        assert (idx_e != idx_t).float().mean().item() < 0.02          # same parameters up to fp32 noise -> same codes (near-ties aside)
+    torch.cuda.synchronize()
+    for (k, a), (_, b) in zip(model.state_dict().items(), twin.state_dict().items()):
+        assert torch.isfinite(a).all(), k
+        assert float((a - b).abs().max()) <= 5e-5, (k, float((a - b).abs().max()))     # 8 AdamW steps of <= 1e-3 each
+    with pytest.raises(ValueError):
+        g.step(xs[0][:40])
+
+
+def test_backward_refuses_parameters_changed_since_forward(oracle):
+    from lipvq_vae_amd.tokenizer import LLFQVAE_V4
+    p = O.make_params(5, 7, 32, 128, oracle=oracle)
+    m = LLFQVAE_V4(7, 32, num_codes=128).cuda()
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in p.items()})
+    x = torch.from_numpy(O.make_inputs(5, 64, 7)).cuda()
+    _, loss = m(x)
+    with torch.no_grad():
+        m.decoder[0].weight.add_(1.0)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        loss.backward()
+    # a write behind the version counter's back is what invalidate_caches() is for
+    idx0, _ = m.tokenize(x, count_usage=False)
+    m.quantizer.codebook.data.add_(0.25)
+    m.invalidate_caches()
+    idx1, _ = m.tokenize(x, count_usage=False)
+    ze = m.encode(x)
+    ref, _, _ = __import__("lipvq_vae_amd").ops.nearest(ze, m.quantizer.codebook.detach())
+    assert torch.equal(idx1, ref)

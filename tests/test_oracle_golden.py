@@ -17,7 +17,7 @@ from oracle import lipvq_oracle as O
 GOLD = Path(__file__).resolve().parent / "golden"
 TOL = 1e-5
 LLFQ = sorted(Path(p).stem for p in glob.glob(str(GOLD / "llfq_*.npz"))
-              if "nearest_edge" not in p and "nearties" not in p and not p.endswith("_big.npz"))
+              if "nearest_edge" not in p and "nearties" not in p and "_train_" not in p and not p.endswith("_big.npz"))
 NEARTIES = sorted(Path(p).stem for p in glob.glob(str(GOLD / "llfq_nearties_*.npz")))
 BIG = sorted(Path(p).stem for p in glob.glob(str(GOLD / "llfq_*_big.npz")))
 NEAR_TIE = 1e-6      # relative top-2 distance gap (in the reference's own fp32 distances) below which an index may differ
@@ -167,3 +167,35 @@ def test_adversarial_near_ties_exact(name, oracle):
     idx, _, _ = oracle.nearest(z, cb)
     assert np.array_equal(idx, g["indices"].astype(np.int64))
     assert len(NEARTIES) >= 3
+
+
+def test_icrt_training_steps_k1024_restatement_vs_reference(oracle):
+    """BASELINE config 5's tokenizer step at the real shape (A = 12, D = 208, K = 1024, N = 80): three zero_grad / forward /
+    backward / AdamW iterations by the torch restatement reproduce what the REFERENCE module produced (losses, indices,
+    first-step gradients, final parameters)."""
+    g = np.load(GOLD / "llfq_icrt_train_k1024.npz")
+    A, D, K, N, steps, seed = (int(g[k]) for k in ("A", "D", "K", "N", "steps", "seed"))
+    p = O.make_params(seed, A, D, K, regime="trained", oracle=oracle)
+    assert O.params_digest(p) == str(g["params_sha256"])
+    torch.set_num_threads(1)
+    tp = {k: v.requires_grad_(True) for k, v in O.to_torch(p).items()}
+    opt = torch.optim.AdamW(list(tp.values()), lr=1e-3, weight_decay=1e-4)
+    tol = 0 if _same_platform(g) else 1e-6
+    for st in range(steps):
+        x = torch.from_numpy(O.make_inputs(seed + st, N, A))
+        opt.zero_grad()
+        _, loss, ex = O.torch_llfq_forward(tp, x)
+        loss.backward()
+        assert abs(loss.item() - float(g[f"loss{st}"])) <= max(tol, 1e-7) * abs(float(g[f"loss{st}"]))
+        assert np.array_equal(ex["indices"].numpy(), g[f"indices{st}"].astype(np.int64))
+        if st == 0:
+            for k in O.LLFQ_KEYS:
+                ref = g["grad0/" + k]
+                got = tp[k].grad.numpy()
+                got = got[g["grad0_rows"]] if k == "quantizer.codebook" else got
+                assert np.abs(got - ref).max() <= tol * max(1.0, np.abs(ref).max()) + (0 if tol == 0 else 1e-9), k
+        opt.step()
+    for k in O.LLFQ_KEYS:
+        got = tp[k].detach().numpy()
+        got = got[g["post_rows"]] if k == "quantizer.codebook" else got
+        assert np.abs(got - g["post/" + k]).max() <= tol, k
