@@ -101,7 +101,11 @@ class GraphedTokenizerStep:
         self.model = vq_vae_model
         self._fb = forward_backward
         self.static_x = example_actions.detach().clone().contiguous()
+        # foreach AdamW, capturable (~8 launches).  torch's fused=True form is one launch (measured: 0.41 instead of 0.52 ms per
+        # replayed step at N = 80) but on this build its trajectory leaves the eager AdamW's after one step even without a graph
+        # (scripts/dev/debug_fused.py: loss 0.99112 vs 0.98865), so it is not used.
         self.vq_optimizer = torch.optim.AdamW(vq_vae_model.parameters(), lr=lr, weight_decay=weight_decay, capturable=True)
+        fused = False
         if optimizer_state is not None:
             import copy
             # continue an eager run: moments and step count carry over.  Deep copy: Optimizer.load_state_dict keeps the very
@@ -109,6 +113,9 @@ class GraphedTokenizerStep:
             self.vq_optimizer.load_state_dict(copy.deepcopy(optimizer_state))
             for grp in self.vq_optimizer.param_groups:
                 grp["capturable"] = True
+                grp["fused"] = True if fused else grp.get("fused")
+                if fused:
+                    grp["foreach"] = False
                 for prm in grp["params"]:                            # an eager AdamW keeps `step` on the host
                     st = self.vq_optimizer.state.get(prm)
                     if st and "step" in st:
