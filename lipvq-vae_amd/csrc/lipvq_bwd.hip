@@ -119,38 +119,50 @@ __global__ __launch_bounds__(64 * WGW_WAVES) void wgrad_wg_kernel(const float* _
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
     }
-    // staging map: wave w fetches rows 4w .. 4w+3 of the 32-row block, lanes along the columns (whole-row coalesced);
-    // the next block's loads are in flight (registers) while the current block is multiplied
-    float gq[4][CG], hq[4][CG];
-    auto fetch = [&](int64_t rb) {
+    // staging map: wave w fetches rows 4w .. 4w+3 of the 32-row block, lanes along the columns (whole-row coalesced).
+    // The loads of the next TWO blocks are in flight (registers) while the current block is multiplied: with one block of
+    // look-ahead (the first version) the loads had one MFMA phase -- ~0.5 us -- to come back from HBM, and SQ counters showed
+    // the waves parked in s_waitcnt / barriers 65 % of the time with the matrix pipe 27 % busy.
+    constexpr int DEPTH = 3;                       // register sets: the block being staged + two in flight
+    float gq[DEPTH][4][CG], hq[DEPTH][4][CG];
+    // Branch-free on purpose: every load has a valid (clamped) address and is masked by a select afterwards, every block runs
+    // its 16 k-steps (rows past the chunk were staged as zeros), and the block loop has no conditional between blocks -- at a
+    // control-flow join hipcc's wait-count pass falls back to vmcnt(0), which would drain the look-ahead at every block.
+    auto fetch = [&](int64_t rb, float (&gqs)[4][CG], float (&hqs)[4][CG]) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int64_t row = rb + 4 * wave + rr;
             const bool in = row < r1;
-            int64_t hr = row;
-            if (in && hidx) hr = hidx[row];
+            const int64_t rowc = in ? row : r1 - 1;
+            const int64_t hr = hidx ? hidx[rowc] : rowc;
 #pragma unroll
             for (int cg = 0; cg < CG; ++cg) {
                 const int c = lane + 64 * cg;
-                gq[rr][cg] = (in && c < J) ? G[(size_t)row * J + c] : 0.0f;
-                hq[rr][cg] = (in && c < Kd) ? H[(size_t)hr * Kd + c] : 0.0f;
+#ifdef LQ_WG_NOLOAD                /* timing-only ablation */
+                const float gv = (float)(rowc & 7) * 0.125f, hv = (float)(c & 3);
+#else
+                const float gv = G[(size_t)rowc * J + (c < J ? c : J - 1)];
+                const float hv = H[(size_t)hr * Kd + (c < Kd ? c : Kd - 1)];
+#endif
+                gqs[rr][cg] = (in && c < J) ? gv : 0.0f;
+                hqs[rr][cg] = (in && c < Kd) ? hv : 0.0f;
             }
         }
     };
-    fetch(r0);
-    for (int64_t rb = r0; rb < r1; rb += 32) {
-        __syncthreads();                                   // the previous block's operands have been consumed
+    auto block = [&](int64_t rb, float (&gqs)[4][CG], float (&hqs)[4][CG]) {
+        // stage the block held in (gqs, hqs), refill that register set with block rb + 32 DEPTH, multiply
+        lq_wg_barrier();                                   // the previous block's operands have been consumed (raw barrier:
+                                                           // the two blocks of loads in flight stay in flight)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
             for (int cg = 0; cg < CG; ++cg) {
                 const int c = lane + 64 * cg;
-                if (c < Jp) Gs[(4 * wave + rr) * Jp + c] = gq[rr][cg];
-                if (c < Kp) Hs[(4 * wave + rr) * Kp + c] = (c < Kd) ? lq_act_apply(hq[rr][cg], h_act) : 0.0f;
+                if (c < Jp) Gs[(4 * wave + rr) * Jp + c] = gqs[rr][cg];
+                if (c < Kp) Hs[(4 * wave + rr) * Kp + c] = (c < Kd) ? lq_act_apply(hqs[rr][cg], h_act) : 0.0f;
             }
-        __syncthreads();
-        if (rb + 32 < r1) fetch(rb + 32);
-        const int steps = (r1 - rb >= 32) ? 16 : (int)((r1 - rb + 1) >> 1);
+        lq_wg_barrier();
+        fetch(rb + 32 * DEPTH, gqs, hqs);                  // (past the chunk: clamped addresses, zeros)
 #pragma unroll
         for (int q = 0; q < TPW; ++q) {
             const int t = wave + q * WGW_WAVES;
@@ -158,10 +170,152 @@ __global__ __launch_bounds__(64 * WGW_WAVES) void wgrad_wg_kernel(const float* _
                 const int ti = t / TJ, tj = t - ti * TJ;
                 const float* ga = Gs + kh * Jp + 32 * ti + li;
                 const float* hb = Hs + kh * Kp + 32 * tj + li;
-                for (int s2 = 0; s2 < steps; ++s2) {
-                    const float av = ga[2 * s2 * Jp];
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, hb[2 * s2 * Kp], acc[q], 0, 0, 0);
-                    bsum[q] += av;
+                // all 32 LDS reads first, then the 16 MFMAs back to back (the rolled loop read two values, waited for the LDS
+                // round trip and issued one MFMA, sixteen times per block)
+                float av[16], bv[16];
+#pragma unroll
+                for (int s2 = 0; s2 < 16; ++s2) { av[s2] = ga[2 * s2 * Jp]; bv[s2] = hb[2 * s2 * Kp]; }
+#pragma unroll
+                for (int s2 = 0; s2 < 16; ++s2) {
+#ifdef LQ_WG_NOMFMA                /* timing-only ablation */
+                    acc[q][s2] += av[s2] * bv[s2];
+#else
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], bv[s2], acc[q], 0, 0, 0);
+#endif
+                    bsum[q] += av[s2];
+                }
+            }
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) fetch(r0 + 32 * d, gq[d], hq[d]);
+    const int ntrip = (int)((r1 - r0 + 32 * DEPTH - 1) / (32 * DEPTH));      // whole trips of DEPTH blocks; the surplus blocks multiply zeros
+    for (int trip = 0; trip < ntrip; ++trip) {
+        const int64_t rb = r0 + (int64_t)trip * 32 * DEPTH;
+        block(rb, gq[0], hq[0]);
+        block(rb + 32, gq[1], hq[1]);
+        block(rb + 64, gq[2], hq[2]);
+    }
+    float* pw = partW + (size_t)blockIdx.x * J * Kd;
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int t = wave + q * WGW_WAVES;
+        if (t >= T) continue;
+        const int ti = t / TJ, tj = t - ti * TJ;
+        const int fj = 32 * tj + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int oi = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (oi < J && fj < Kd) pw[(size_t)oi * Kd + fj] = acc[q][r];
+        }
+        if (tj == 0) {
+            const float tot = bsum[q] + __shfl_xor(bsum[q], 32, 64);
+            const int fi = 32 * ti + li;
+            if (kh == 0 && fi < J) partB[(size_t)blockIdx.x * J + fi] = tot;
+        }
+    }
+}
+
+// Vectorised workgroup-per-chunk variant (J and Kd multiples of 4, the tokenizer's own layer widths): what ablations of the
+// kernel above showed (N = 524 288, J = 128, Kd = 64: 271 us; 150 us with the global loads replaced by constants, 210 us with
+// the MFMAs removed) is that its 4-byte loads -- twelve 256-byte wave-instructions per wave and 32-row block -- move 1.9 TB/s
+// however far ahead they are issued, and that two barriers per 16 MFMAs per wave are a skeleton of their own.  Here a block is
+// 64 rows, fetched with 16-byte loads (the 512 threads sweep the block's float4s: J/32 + Kd/32 instructions per thread, each
+// wave-instruction 1 KiB of whole rows), staged with 16-byte LDS writes, one block of look-ahead in registers, raw barriers
+// (no vmcnt drain).  Same chunk-ordered, row-ordered accumulation per tile: the same bits as the kernels above.
+#define WG4_ROWS 64
+template <int TPW, int NG, int NH>      // tiles per wave; float4s per thread and block of G / of H
+__global__ __launch_bounds__(64 * WGW_WAVES) void wgrad_wg4_kernel(const float* __restrict__ G, const float* __restrict__ H,
+                                                                   const int64_t* __restrict__ hidx, int h_act,
+                                                                   float* __restrict__ partW, float* __restrict__ partB,
+                                                                   int64_t N, int J, int Kd, int TI, int TJ, int chunk_rows) {
+    extern __shared__ __attribute__((aligned(16))) float wg_lds[];
+    const int Jp = 32 * TI, Kp = 32 * TJ;
+    float* Gs = wg_lds;                        // [64][Jp]
+    float* Hs = Gs + WG4_ROWS * Jp;            // [64][Kp]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kh = lane >> 5;
+    const int T = TI * TJ;
+    const int J4 = J >> 2, K4 = Kd >> 2, Jp4 = Jp >> 2, Kp4 = Kp >> 2;
+    const int64_t r0 = (int64_t)blockIdx.x * chunk_rows;
+    int64_t r1 = r0 + chunk_rows;
+    if (r1 > N) r1 = N;
+    f32x16 acc[TPW];
+    float bsum[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        bsum[q] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+    }
+    // thread's float4 slots of a block: slot u of G is float4 (tid + 512 u) of the [64][Jp4] image (padding columns and rows
+    // past the chunk are staged as zeros), likewise H
+    int grow[NG], gcol[NG], hrow[NH], hcol[NH];
+#pragma unroll
+    for (int u = 0; u < NG; ++u) { const int i = tid + 512 * u; grow[u] = i / Jp4; gcol[u] = i - grow[u] * Jp4; }
+#pragma unroll
+    for (int u = 0; u < NH; ++u) { const int i = tid + 512 * u; hrow[u] = i / Kp4; hcol[u] = i - hrow[u] * Kp4; }
+    float4 gq[NG], hq[NH];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch = [&](int64_t rb) {             // branch-free: clamped addresses, masked by selects
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+            const int64_t row = rb + grow[u];
+            const bool in = grow[u] < WG4_ROWS && row < r1 && gcol[u] < J4;
+            const int64_t rc = row < r1 ? row : r1 - 1;
+            const float4 v = reinterpret_cast<const float4*>(G + (size_t)rc * J)[gcol[u] < J4 ? gcol[u] : J4 - 1];
+            gq[u] = in ? v : zero4;
+        }
+#pragma unroll
+        for (int u = 0; u < NH; ++u) {
+            const int64_t row = rb + hrow[u];
+            const bool in = hrow[u] < WG4_ROWS && row < r1 && hcol[u] < K4;
+            const int64_t rc = row < r1 ? row : r1 - 1;
+            const int64_t hr = hidx ? hidx[rc] : rc;
+            const float4 v = reinterpret_cast<const float4*>(H + (size_t)hr * Kd)[hcol[u] < K4 ? hcol[u] : K4 - 1];
+            hq[u] = in ? v : zero4;
+        }
+    };
+    fetch(r0);
+    const int nblk = (int)((r1 - r0 + WG4_ROWS - 1) / WG4_ROWS);
+    for (int b = 0; b < nblk; ++b) {
+        const int64_t rb = r0 + (int64_t)b * WG4_ROWS;
+        lq_wg_barrier();                                   // the previous block's operands have been consumed
+#pragma unroll
+        for (int u = 0; u < NG; ++u)
+            if (grow[u] < WG4_ROWS) reinterpret_cast<float4*>(Gs)[grow[u] * Jp4 + gcol[u]] = gq[u];
+#pragma unroll
+        for (int u = 0; u < NH; ++u)
+            if (hrow[u] < WG4_ROWS) {
+                float4 v = hq[u];
+                if (h_act != LIPVQ_ACT_NONE && hcol[u] < K4) {          // (padding columns stay zero: act(0) need not be 0)
+                    v.x = lq_act_apply(v.x, h_act); v.y = lq_act_apply(v.y, h_act);
+                    v.z = lq_act_apply(v.z, h_act); v.w = lq_act_apply(v.w, h_act);
+                }
+                // rows past the chunk must contribute nothing even if act(0) != 0
+                if (rb + hrow[u] >= r1) v = zero4;
+                reinterpret_cast<float4*>(Hs)[hrow[u] * Kp4 + hcol[u]] = v;
+            }
+        lq_wg_barrier();
+        fetch(rb + WG4_ROWS);                              // the next block (past the chunk: zeros), in flight under the MFMAs
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) {
+            const int t = wave + q * WGW_WAVES;
+            if (t < T) {                                   // wave-uniform
+                const int ti = t / TJ, tj = t - ti * TJ;
+                const float* ga = Gs + kh * Jp + 32 * ti + li;
+                const float* hb = Hs + kh * Kp + 32 * tj + li;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    float av[16], bv[16];
+#pragma unroll
+                    for (int s2 = 0; s2 < 16; ++s2) { av[s2] = ga[2 * (16 * half + s2) * Jp]; bv[s2] = hb[2 * (16 * half + s2) * Kp]; }
+#pragma unroll
+                    for (int s2 = 0; s2 < 16; ++s2) {
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], bv[s2], acc[q], 0, 0, 0);
+                        bsum[q] += av[s2];
+                    }
                 }
             }
         }
@@ -231,7 +385,20 @@ extern "C" int lipvq_wgrad_f32(const float* G, const float* H, const int64_t* hi
     const size_t lds = (size_t)32 * 32 * (TI + TJ) * sizeof(float);
     static int use_wg = -1;                     // LIPVQ_WGRAD_PER_TILE=1 forces the one-wave-per-tile kernel (measurement knob)
     if (use_wg < 0) use_wg = getenv("LIPVQ_WGRAD_PER_TILE") ? 0 : 1;
-    if (use_wg && TI * TJ <= WGW_WAVES * WGW_MAXT && TI <= 8 && TJ <= 8 && lds <= 64 * 1024) {
+    const size_t lds4 = (size_t)WG4_ROWS * 32 * (TI + TJ) * sizeof(float);
+    const int ng = (WG4_ROWS * 8 * TI + 511) / 512, nh = (WG4_ROWS * 8 * TJ + 511) / 512;      // float4s per thread and block
+    if (use_wg && (J & 3) == 0 && (Kd & 3) == 0 && TI * TJ <= WGW_WAVES * 2 && ng <= 4 && nh <= 4 && lds4 <= 64 * 1024 &&
+        (((uintptr_t)G | (uintptr_t)H) & 15) == 0) {
+        const int tpw = (TI * TJ + WGW_WAVES - 1) / WGW_WAVES;
+        typedef void (*wg_fn)(const float*, const float*, const int64_t*, int, float*, float*, int64_t, int, int, int, int, int);
+        wg_fn kfn = nullptr;
+#define LQ_W4(NG_, NH_) if (ng == NG_ && nh == NH_) kfn = tpw <= 1 ? (wg_fn)wgrad_wg4_kernel<1, NG_, NH_> : (wg_fn)wgrad_wg4_kernel<2, NG_, NH_>;
+        LQ_W4(1, 1) LQ_W4(1, 2) LQ_W4(2, 1) LQ_W4(2, 2) LQ_W4(1, 4) LQ_W4(4, 1) LQ_W4(2, 4) LQ_W4(4, 2) LQ_W4(4, 4)
+        LQ_W4(1, 3) LQ_W4(3, 1) LQ_W4(2, 3) LQ_W4(3, 2) LQ_W4(3, 3) LQ_W4(3, 4) LQ_W4(4, 3)
+#undef LQ_W4
+        hipLaunchKernelGGL(kfn, dim3(nch), dim3(64 * WGW_WAVES), lds4, st, G, H, hidx, h_act, partW, partB, N, J, Kd, TI, TJ,
+                           wgrad_chunk_rows(N));
+    } else if (use_wg && TI * TJ <= WGW_WAVES * WGW_MAXT && TI <= 8 && TJ <= 8 && lds <= 64 * 1024) {
         const int wide = 32 * (TI > TJ ? TI : TJ);
         const int tpw = (TI * TJ + WGW_WAVES - 1) / WGW_WAVES;
         typedef void (*wg_fn)(const float*, const float*, const int64_t*, int, float*, float*, int64_t, int, int, int, int, int);

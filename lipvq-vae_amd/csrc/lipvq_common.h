@@ -26,6 +26,18 @@ struct LqLdsReserve {
 int lipvq_reserve_lds(LqLdsReserve& r, const void* kernel, size_t bytes, const char* what);
 #endif
 
+#if defined(__HIPCC__)
+// Workgroup barrier that does NOT drain vector-memory operations: this wave's LDS accesses are done (lgkmcnt(0)), then
+// s_barrier.  __syncthreads() makes hipcc wait vmcnt(0) first, i.e. for every global load / LDS-DMA still in flight --
+// which defeats any prefetch that is meant to stay in flight across the barrier.  Global data is waited for where it is
+// consumed (hipcc's own counted vmcnt for ordinary loads; lq_wait_vmcnt for LDS-DMA).
+__device__ __forceinline__ void lq_wg_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+#endif
+
 // error plumbing (defined in lipvq_misc.hip)
 int lipvq_fail(int code, const char* fmt, ...);
 int lipvq_check_launch(const char* what);

@@ -159,12 +159,6 @@ __device__ __forceinline__ void lq_wait_vmcnt() {            // all but the N yo
     static_assert(N >= 0 && N < 64, "vmcnt immediate");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-__device__ __forceinline__ void lq_wg_barrier() {             // LDS accesses of this wave done, then the workgroup barrier (no vmcnt drain)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
 // LDS the ring needs: NB stage buffers + 1 KiB that absorbs the copies issued for stages past the end
 template <int S, int TC_, int NB>
 constexpr size_t lq_ring_bytes() { return (size_t)NB * ScreenCfg<S, TC_>::STAGE_BYTES + 1024; }
