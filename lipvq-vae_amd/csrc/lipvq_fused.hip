@@ -32,40 +32,50 @@
 #endif
 #define FUSED_THREADS (FUSED_WAVES * 64)
 // LDS budget: the D = 128 instance holds 105 KB of weights, so its codebook stages are one tile deep
+#ifndef FUSED_HIST_MAX
 #define FUSED_HIST_MAX 2048
+#endif
 // stage ring of the fused kernel (LDS left beside the encoder weights): S <= 4: four buffers of two/four tiles; S = 8: the
 // weights take 98 KB, three buffers of one tile
+#ifdef LQ_EXP_RING_TC             /* experiment builds: ring shape from the command line */
+constexpr int fused_ring_tc(int S) { return LQ_EXP_RING_TC; }
+constexpr int fused_ring_nb(int S) { return LQ_EXP_RING_NB; }
+#else
 constexpr int fused_ring_tc(int S) { return (S <= 2) ? 4 : (S <= 4) ? 2 : 1; }
 constexpr int fused_ring_nb(int S) { return (S <= 4) ? 4 : 3; }
+#endif
+#ifndef LQ_EXP_WGS_PER_CU
+#define LQ_EXP_WGS_PER_CU 1
+#endif
 
-// lq_gelu_poly for two elements, cut into four stages so that one stage can follow each MFMA of a 4-MFMA group
-// (same operations in the same order as lq_gelu_poly: bit-identical values)
+// lq_gelu_poly2 (two elements per instruction: v_pk_fma_f32), cut into four stages so that one stage can follow each MFMA of a
+// 4-MFMA group (same operations in the same order as lq_gelu_poly: bit-identical values)
 struct Gelu2 {
-    float x0, x1, t0, t1, u0, u1, s0, s1;
+    lq_v2f x, t, u, s;
     __device__ __forceinline__ void stage0(float a, float b) {
-        x0 = a; x1 = b;
-        t0 = a * a; t1 = b * b;
-        u0 = lq_fma(t0, 0.11111111111111111111f, -1.0f); u1 = lq_fma(t1, 0.11111111111111111111f, -1.0f);
-        s0 = lq_fma(0.00012666420661844313f, u0, -0.00043783686123788357f); s1 = lq_fma(0.00012666420661844313f, u1, -0.00043783686123788357f);
-        s0 = lq_fma(s0, u0, 0.0008924771682359278f); s1 = lq_fma(s1, u1, 0.0008924771682359278f);
+        x = (lq_v2f){a, b};
+        t = x * x;
+        u = lq_fma2(t, lq_bc2(0.11111111111111111111f), lq_bc2(-1.0f));
+        s = lq_fma2(lq_bc2(0.00012666420661844313f), u, lq_bc2(-0.00043783686123788357f));
+        s = lq_fma2(s, u, lq_bc2(0.0008924771682359278f));
     }
     __device__ __forceinline__ void stage1() {
-        s0 = lq_fma(s0, u0, -0.002175821689888835f); s1 = lq_fma(s1, u1, -0.002175821689888835f);
-        s0 = lq_fma(s0, u0, 0.005515238270163536f); s1 = lq_fma(s1, u1, 0.005515238270163536f);
-        s0 = lq_fma(s0, u0, -0.01217574905604124f); s1 = lq_fma(s1, u1, -0.01217574905604124f);
-        s0 = lq_fma(s0, u0, 0.02415713667869568f); s1 = lq_fma(s1, u1, 0.02415713667869568f);
+        s = lq_fma2(s, u, lq_bc2(-0.002175821689888835f));
+        s = lq_fma2(s, u, lq_bc2(0.005515238270163536f));
+        s = lq_fma2(s, u, lq_bc2(-0.01217574905604124f));
+        s = lq_fma2(s, u, lq_bc2(0.02415713667869568f));
     }
     __device__ __forceinline__ void stage2() {
-        s0 = lq_fma(s0, u0, -0.043842192739248276f); s1 = lq_fma(s1, u1, -0.043842192739248276f);
-        s0 = lq_fma(s0, u0, 0.07253222167491913f); s1 = lq_fma(s1, u1, 0.07253222167491913f);
-        s0 = lq_fma(s0, u0, -0.11009667813777924f); s1 = lq_fma(s1, u1, -0.11009667813777924f);
-        s0 = lq_fma(s0, u0, 0.15749694406986237f); s1 = lq_fma(s1, u1, 0.15749694406986237f);
+        s = lq_fma2(s, u, lq_bc2(-0.043842192739248276f));
+        s = lq_fma2(s, u, lq_bc2(0.07253222167491913f));
+        s = lq_fma2(s, u, lq_bc2(-0.11009667813777924f));
+        s = lq_fma2(s, u, lq_bc2(0.15749694406986237f));
     }
     __device__ __forceinline__ void stage3(float& o0, float& o1) {
-        s0 = lq_fma(s0, u0, -0.2287982553243637f); s1 = lq_fma(s1, u1, -0.2287982553243637f);
-        s0 = lq_fma(s0, u0, 0.4701318144798279f); s1 = lq_fma(s1, u1, 0.4701318144798279f);
-        o0 = lq_fma(t0 * 0.35355339059327376220f, s0, 0.5f * x0);
-        o1 = lq_fma(t1 * 0.35355339059327376220f, s1, 0.5f * x1);
+        s = lq_fma2(s, u, lq_bc2(-0.2287982553243637f));
+        s = lq_fma2(s, u, lq_bc2(0.4701318144798279f));
+        const lq_v2f o = lq_fma2(t * lq_bc2(0.35355339059327376220f), s, lq_bc2(0.5f) * x);
+        o0 = o.x; o1 = o.y;
     }
 };
 
@@ -186,6 +196,12 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
     const float fown = lq_pow2f(sz + (int)hdr[3]);
     const float tiny2 = (float)(16 * S) * lq_pow2f(-10 - 2 * sz);
     const int64_t nblk = (a.N + FUSED_WAVES * 32 - 1) / (FUSED_WAVES * 32);
+#ifdef LQ_EXP_STAGGER             /* experiment: the workgroup in the SIMDs' odd wave slots starts LQ_EXP_STAGGER cycles late */
+    if (__builtin_amdgcn_s_getreg(6148) & 1) {
+        const long long t0_ = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0_ < LQ_EXP_STAGGER) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
 
 #ifdef LQ_STAMPS
     // diagnostic build only (scripts/stamps.py): per-wave cycles per segment, accumulated over the row blocks and written to
@@ -238,12 +254,36 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
         float n2 = 0.0f;
         // sigmoid, centring, row statistics and the optional z_e store of one finished 32-feature tile
         auto finish_tile = [&](const int t, f32x16& acc) {
+#if !defined(LQ_ABL_NOSIGMOID) && !defined(LQ_SCALAR_SIGMOID)
+            if constexpr (!FAST) {
+                // the canonical sigmoid, two elements per instruction; a tile that holds a NaN or an infinity (wave-uniform test,
+                // practically never true) takes the one-element form, whose clamps propagate NaN
+                lq_v2f chk = lq_bc2(0.0f);
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) chk = lq_nonfinite_acc2((lq_v2f){acc[r], acc[r + 1]}, chk);
+                if (__builtin_amdgcn_ballot_w64(!(chk.x == 0.0f && chk.y == 0.0f)) != 0ull) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = lq_sigmoid(acc[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        if (2 * t + (r >> 3) >= S) continue;
+                        const lq_v2f z2 = lq_sigmoid2_finite((lq_v2f){acc[r], acc[r + 1]});
+                        acc[r] = z2.x; acc[r + 1] = z2.y;
+                    }
+                }
+            }
+#endif
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (2 * t + (r >> 3) >= S) continue;             // S odd: features past D in the last tile (zero weights) are not z_e
                 // fast mode: hardware exp2 / rcp (1 ulp each) instead of the canonical exp polynomial + IEEE division
+#if !defined(LQ_ABL_NOSIGMOID) && !defined(LQ_SCALAR_SIGMOID)
+                const float zv = FAST ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[r] * -1.44269504088896341f)) : acc[r];
+#else
                 const float zv = FAST ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[r] * -1.44269504088896341f))
                                       : FUSED_SIGMOID(acc[r]);
+#endif
                 acc[r] = zv;
                 const float v = zv - w_mu[32 * t + 2 * r + h];
                 n2 = lq_fma(v, v, n2);
@@ -368,9 +408,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
                 for (int t = 0; t < T0; ++t) {
                     const f32x16 pre = h0[t];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
+                    for (int r = 0; r < 16; r += 2) {
 #ifndef LQ_ABL_NOGELU
-                        h0[t][r] = lq_gelu_poly(pre[r]);
+                        const lq_v2f g2 = lq_gelu_poly2((lq_v2f){pre[r], pre[r + 1]});
+                        h0[t][r] = g2.x; h0[t][r + 1] = g2.y;
 #endif
                     }
 #ifndef LQ_ABL_NOGELU
@@ -587,19 +628,17 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
         lq_screen_core<S, FUSED_THREADS, TCF, NBF, PACKF>(ah, al, tiles, L.ntiles, stage0, tid, frow, m1, m2, k1);
         LQ_STAMP(4);
         int my_k;
-        bool certified = lq_screen_decide<PACKF>(m1, m2, k1, stage0 + (size_t)wave * LQ_DECIDE_BYTES, hdr, n2, fown, a.gamma, a.K,
-                                                       a.D, lane, my_k, PACKF ? lq_pow2f(lq_pack_bits(L.ntiles) - 23) : 0.0f,
-                                                       PACKF ? ~((1u << lq_pack_bits(L.ntiles)) - 1u) : 0xffffffffu);
-        certified = certified && (n2 >= tiny2);
-        if (h == 0 && row < a.N) {
-            if (certified) {
-                a.idx[row] = (int64_t)my_k;
-                if (use_hist) atomicAdd(&hist[my_k], 1u);              // LDS atomic
-            } else {
-                const int slot = atomicAdd(a.amb_count, 1);
-                a.amb_list[slot] = (int)row;
-                a.amb_list[lq_list_ints(a.N) + slot] = my_k;      // the screen's best candidate: bounds the exact scan
-            }
+        LqDecision dec;
+        const unsigned keep_mask = PACKF ? ~((1u << lq_pack_bits(L.ntiles)) - 1u) : 0xffffffffu;
+        unsigned char* scratch = stage0 + (size_t)wave * LQ_DECIDE_BYTES;
+        bool certified = lq_screen_decide<PACKF>(m1, m2, k1, scratch, hdr, n2, fown, a.gamma, a.K, a.D, lane, my_k, dec,
+                                                 PACKF ? lq_pow2f(lq_pack_bits(L.ntiles) - 23) : 0.0f, keep_mask);
+        const bool row_sane = n2 >= tiny2;                        // (see fz above; such a row's screen values bound nothing)
+        certified = certified && row_sane;
+        lq_screen_emit<PACKF>(dec, certified, row_sane, my_k, row, row < a.N, a.amb_count, a.amb_list, a.N, a.K, lane, keep_mask, scratch);
+        if (h == 0 && row < a.N && certified) {
+            a.idx[row] = (int64_t)my_k;
+            if (use_hist) atomicAdd(&hist[my_k], 1u);              // LDS atomic
         }
         if (a.usage && !use_hist) lq_usage_add(a.usage, my_k, h == 0 && row < a.N && certified);
         LQ_STAMP(5);
@@ -646,7 +685,7 @@ static int launch_tokenize(const TokArgs& a, hipStream_t st) {
     static LqLdsReserve reserved;               // per instantiation: per-device, thread-safe (lipvq_common.h)
     if (int rc = lipvq_reserve_lds(reserved, (const void*)kfn, lds, "tokenize")) return rc;
     int64_t nblk = (a.N + FUSED_WAVES * 32 - 1) / (FUSED_WAVES * 32);
-    int64_t blocks = nblk < 256 ? nblk : 256;            // one persistent workgroup per CU
+    int64_t blocks = nblk < 256 * LQ_EXP_WGS_PER_CU ? nblk : 256 * LQ_EXP_WGS_PER_CU;            // one persistent workgroup per CU
     hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(FUSED_THREADS), lds, st, a);
     return check_launch("tokenize");
 }
@@ -713,8 +752,8 @@ __global__ void w2q_pack_kernel(const float* __restrict__ P2, float* __restrict_
 
 extern "C" size_t lipvq_tokenize_workspace_bytes(int64_t N, int D) {
     if (N <= 0 || D <= 0) return 0;
-    // uncertified-row counter, row list, candidate list, then (D = 208) the streamed layer-2 weights
-    return 64 + 2 * sizeof(int) * lq_list_ints(N) + sizeof(float) * w2q_floats(D);
+    // uncertified-row counter, row list, best-candidate list, short lists, then (D = 208) the streamed layer-2 weights
+    return 64 + lq_lists_bytes(N) + sizeof(float) * w2q_floats(D);
 }
 
 // Fused encode + quantize (reference v5:71-74).  packed: lipvq_mlp3_pack_f32 of the encoder stack
@@ -749,7 +788,7 @@ static int tokenize_impl(const float* x, const float* packed, const void* packed
     if (w2q_floats(D)) {
         // the streamed instance: re-lay out layer 2's packed weights into the workspace (one small launch; the weights may have
         // changed since the last call and the library keeps no state)
-        w2q = reinterpret_cast<float*>(ws + 64 + 2 * sizeof(int) * lq_list_ints(N));
+        w2q = reinterpret_cast<float*>(ws + 64 + lq_lists_bytes(N));
         const PackedLayout PL = packed_layout(A, J0, J1, D);
         const size_t n = w2q_floats(D);
         hipLaunchKernelGGL(w2q_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, packed + PL.oP2, w2q, PL.T2, PL.S2);

@@ -171,6 +171,77 @@ LQ_HD float lq_sigmoid(float x) {
     return 1.0f / (1.0f + e);
 }
 
+#if defined(__HIPCC__) || defined(__HIP__)
+/* ---- two elements per instruction (device code only) ------------------------------------------------------------
+ * gfx950 issues v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 -- the same IEEE operation on both halves of a 64-bit
+ * register pair -- at the rate of their one-element forms (scripts/probe/probe_pk.hip: 16 of either take 78 cycles),
+ * so the polynomials below cost half the issue slots of lq_gelu_poly / lq_sigmoid and return the same bits per
+ * element.  They matter where nothing can hide vector instructions: beside fp32 MFMAs (which run on the same ALUs). */
+typedef float lq_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ lq_v2f lq_fma2(lq_v2f a, lq_v2f b, lq_v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ lq_v2f lq_bc2(float c) { return (lq_v2f){c, c}; }
+
+/* lq_gelu_poly on a pair (valid for x*x < 18 per element; the caller fixes the others up with lq_gelu_tail) */
+__device__ __forceinline__ lq_v2f lq_gelu_poly2(lq_v2f x) {
+    const lq_v2f t = x * x;
+    const lq_v2f u = lq_fma2(t, lq_bc2(0.11111111111111111111f), lq_bc2(-1.0f));
+    lq_v2f s = lq_bc2(0.00012666420661844313f);
+    s = lq_fma2(s, u, lq_bc2(-0.00043783686123788357f));
+    s = lq_fma2(s, u, lq_bc2(0.0008924771682359278f));
+    s = lq_fma2(s, u, lq_bc2(-0.002175821689888835f));
+    s = lq_fma2(s, u, lq_bc2(0.005515238270163536f));
+    s = lq_fma2(s, u, lq_bc2(-0.01217574905604124f));
+    s = lq_fma2(s, u, lq_bc2(0.02415713667869568f));
+    s = lq_fma2(s, u, lq_bc2(-0.043842192739248276f));
+    s = lq_fma2(s, u, lq_bc2(0.07253222167491913f));
+    s = lq_fma2(s, u, lq_bc2(-0.11009667813777924f));
+    s = lq_fma2(s, u, lq_bc2(0.15749694406986237f));
+    s = lq_fma2(s, u, lq_bc2(-0.2287982553243637f));
+    s = lq_fma2(s, u, lq_bc2(0.4701318144798279f));
+    return lq_fma2(t * lq_bc2(0.35355339059327376220f), s, lq_bc2(0.5f) * x);
+}
+
+/* 1 / d for d in [1, 2^126): hipcc's IEEE division sequence (v_div_scale, v_rcp, four refinement fmas, v_div_fmas,
+ * v_div_fixup) with the range handling removed -- for such d and numerator 1 the scaling is the identity and the fix-up
+ * passes the value through, so what remains is v_rcp + six fmas, the same bits as 1.0f / d (probe_pk.hip: all 2^23
+ * mantissas at exponents 0, 1, 2, 13, 73, 123, 125).  NaN propagates. */
+__device__ __forceinline__ lq_v2f lq_rcp2_ge1(lq_v2f d) {
+    lq_v2f r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    const lq_v2f nd = -d, one = lq_bc2(1.0f);
+    const lq_v2f e = lq_fma2(nd, r, one);
+    r = lq_fma2(e, r, r);
+    lq_v2f err = lq_fma2(nd, r, one);
+    const lq_v2f q = lq_fma2(err, r, r);
+    err = lq_fma2(nd, q, one);
+    return lq_fma2(err, r, q);
+}
+
+/* lq_sigmoid on a pair of FINITE elements (the clamp is a v_med3, which would turn a NaN into a number: callers route
+ * tiles that hold a NaN or an infinity to lq_sigmoid -- see lq_nonfinite_acc2) */
+__device__ __forceinline__ lq_v2f lq_sigmoid2_finite(lq_v2f x) {
+    const lq_v2f t = {__builtin_amdgcn_fmed3f(-x.x, -87.0f, 87.0f), __builtin_amdgcn_fmed3f(-x.y, -87.0f, 87.0f)};
+    const lq_v2f magic = lq_bc2(12582912.0f);
+    const lq_v2f nf = lq_fma2(t, lq_bc2(1.44269504088896341f), magic);
+    /* (bits(nf) - 0x4B400000 + 127) << 23 = (bits(nf) << 23) + 0x3F800000: the low nine bits of 0x4B400000 are zero */
+    const lq_v2f sc = {lq_u2f((lq_f2u(nf.x) << 23) + 0x3F800000u), lq_u2f((lq_f2u(nf.y) << 23) + 0x3F800000u)};
+    const lq_v2f n = nf - magic;
+    lq_v2f r = lq_fma2(n, lq_bc2(-0.693145751953125f), t);
+    r = lq_fma2(n, lq_bc2(-1.42860682030941723e-6f), r);
+    lq_v2f q = lq_bc2(0.00019907570094801486f);
+    q = lq_fma2(q, r, lq_bc2(0.0013933652080595493f));
+    q = lq_fma2(q, r, lq_bc2(0.00833328627049923f));
+    q = lq_fma2(q, r, lq_bc2(0.04166646674275398f));
+    q = lq_fma2(q, r, lq_bc2(0.1666666716337204f));
+    q = lq_fma2(q, r, lq_bc2(0.5f));
+    const lq_v2f p = lq_fma2(r * r, q, r) + lq_bc2(1.0f);
+    const lq_v2f e = p * sc;
+    return lq_rcp2_ge1(lq_bc2(1.0f) + e);
+}
+/* running check for lq_sigmoid2_finite: chk stays 0 (or -0) while every element seen is finite, and turns NaN for good
+ * once one is NaN or +-inf (0 * inf = NaN) */
+__device__ __forceinline__ lq_v2f lq_nonfinite_acc2(lq_v2f x, lq_v2f chk) { return lq_fma2(x, lq_bc2(0.0f), chk); }
+#endif
+
 /* log(u) for finite u >= 1 (only use: softplus). */
 LQ_HD float lq_logf_ge1(float u) {
     uint32_t b = lq_f2u(u);

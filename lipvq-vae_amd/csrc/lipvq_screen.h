@@ -352,11 +352,21 @@ __device__ __forceinline__ void lq_row_factors(float fown, int lane, float (&fro
 // 32-row tile instead of ~720 for a 5-step shuffle butterfly over 16 registers x 3 values (ablation: the
 // butterfly + its LDS hand-off cost 46 us of a 350 us launch), and no workgroup barrier.
 // Returns certified (valid in every lane, duplicated across the halves); my_k = the row's code.
+// What lq_screen_decide leaves behind for lq_screen_emit: the 16 per-lane minima of this lane's part of the row (lane l of the
+// half-wave held the codes = l mod 32; part h of row i sees lanes 16h .. 16h+15), the smallest per-lane SECOND minimum of the
+// part, the row's best value and the two coefficients of the margin  thr(v) = t0 + p (|best| + |v|).
+struct LqDecision {
+    float vv[16];
+    float m2min, best, t0, p;
+    bool screen_ok;              // the screen's numbers mean something (finite codebook bound, best code in range)
+};
+
 template <bool PACK = false>
 __device__ __forceinline__ bool lq_screen_decide(const float (&m1)[16], const float (&m2)[16], const int (&k1)[16],
                                                  unsigned char* wave_lds /* LQ_DECIDE_BYTES, this wave only */,
                                                  const unsigned* hdr, float n2, float fown, float gamma, int K, int D,
-                                                 int lane, int& my_k, float pack_eps = 0.0f, unsigned keep_mask = 0xffffffffu) {
+                                                 int lane, int& my_k, LqDecision& dec, float pack_eps = 0.0f,
+                                                 unsigned keep_mask = 0xffffffffu) {
     constexpr int TS = LQ_DECIDE_STRIDE;
     const int ln = lane & 31, h = lane >> 5;
     float* tv = reinterpret_cast<float*>(wave_lds);           // [32 rows][TS], reused by the passes
@@ -375,6 +385,7 @@ __device__ __forceinline__ bool lq_screen_decide(const float (&m1)[16], const fl
             const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+                dec.vv[4 * q + e] = vv[e];
                 const bool take = vv[e] < best;       // equal minima need no tie-break: second == best then, the
                 second = __builtin_amdgcn_fmed3f(vv[e], best, second);   // row is not certified and the exact
                 pos = take ? 4 * q + e : pos;                             // kernel decides it
@@ -383,32 +394,34 @@ __device__ __forceinline__ bool lq_screen_decide(const float (&m1)[16], const fl
         }
     }
     __builtin_amdgcn_wave_barrier();                          // pass-1 reads are issued before the next pass overwrites
+    // ---- pass 2: m2 -----------------------------------------------------------------------------------------
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tv[((r & 3) + 8 * (r >> 2) + 4 * h) * TS + ln] = m2[r];
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    float m2min = INFINITY;
+    {
+        const float4* pv = reinterpret_cast<const float4*>(tv + ln * TS + 16 * h);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v4 = pv[q];
+            m2min = fminf(m2min, fminf(fminf(v4.x, v4.y), fminf(v4.z, v4.w)));
+        }
+    }
+    second = fminf(second, m2min);
+    __builtin_amdgcn_wave_barrier();
     int bk;
     if constexpr (PACK) {
         // the smallest value carries its tile index; its lane (= code mod 32) is the column it was read from
         bk = (int)(__float_as_uint(best) & ~keep_mask) * 32 + 16 * h + pos;
     } else {
-        // ---- pass 2: k1 -> the code at that position --------------------------------------------------------
+        // ---- pass 3: k1 -> the code at that position; the image STAYS in the scratch for lq_screen_emit ----------
         int* tk = reinterpret_cast<int*>(wave_lds);
 #pragma unroll
         for (int r = 0; r < 16; ++r) tk[((r & 3) + 8 * (r >> 2) + 4 * h) * TS + ln] = k1[r];
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
         bk = tk[ln * TS + 16 * h + pos];
-        __builtin_amdgcn_wave_barrier();
-    }
-    // ---- pass 3: m2 -----------------------------------------------------------------------------------------
-#pragma unroll
-    for (int r = 0; r < 16; ++r) tv[((r & 3) + 8 * (r >> 2) + 4 * h) * TS + ln] = m2[r];
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();
-    {
-        const float4* pv = reinterpret_cast<const float4*>(tv + ln * TS + 16 * h);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 v4 = pv[q];
-            second = fminf(second, fminf(fminf(v4.x, v4.y), fminf(v4.z, v4.w)));
-        }
     }
     // ---- join the two 16-lane parts of the row ---------------------------------------------------------------
     {
@@ -445,13 +458,79 @@ __device__ __forceinline__ bool lq_screen_decide(const float (&m1)[16], const fl
     const float s1 = fmaxf(0.0f, best + n2s) + eps_s + (float)(Dpad16 + 2) * u24 * n2s;
     //  (3) PACK bookkeeping (lq_track_one): best and second carry the tile index in their low bits, a perturbation below
     //      pack_eps = 2^(TB-23) of each value's own magnitude, and so does every other code's value that `second` bounds.
-    const float thr = 2.0f * eps_s + 2.125f * (float)(Dpad16 / 8 + 12) * u24 * s1 + 2.125f * pack_eps * (lq_abs(best) + lq_abs(second));
+    //  The same inequality, applied to ANY code's value v instead of `second`, says that code loses strictly to k1 in the
+    //  reference's arithmetic: thr(v) = t0 + p (|best| + |v|)  (lq_screen_emit lists the codes it does not exclude).
+    dec.t0 = 2.0f * eps_s + 2.125f * (float)(Dpad16 / 8 + 12) * u24 * s1;
+    dec.p = 2.125f * pack_eps;
+    dec.best = best;
+    dec.m2min = m2min;
+    dec.screen_ok = (twoemax < INFINITY) && (bk >= 0) && (bk < K);
+    const float thr = dec.t0 + dec.p * (lq_abs(best) + lq_abs(second));
     // non-finite inputs make the comparison false
-    bool certified = (twoemax < INFINITY) && (second - best > thr) && (bk >= 0) && (bk < K);
+    bool certified = dec.screen_ok && (second - best > thr);
 #ifdef LQ_ABL_CERT_ALL
     certified = true; my_k = (my_k >= 0 && my_k < K) ? my_k : (lane * 7) % K;
 #endif
     return certified;
+}
+
+// Rows the screen could not certify (plus rows whose screen is meaningless: fp16 overflow of the codebook, `lists_ok` false):
+// one slot of the workspace lists each -- the row, the screen's best candidate (bounds a full exact scan) and, new in round 2,
+// WHICH codes can still win.  By (1)-(3) above every code whose screened value v exceeds best + thr(v) loses strictly to k1
+// in the reference's own arithmetic, so the reference's argmin is the first exact minimum among the others.  Per lane of the
+// half-wave (= codes congruent to that lane mod 32) the screen kept the smallest value (its code known) and the second
+// smallest (code unknown).  Per part h of the row (lanes 16h .. 16h+15), at [8h] of the slot's 16 ints: {n, mask, c0 .. c5}
+//   n >= 0 : the part's candidates are exactly the n listed codes (the lanes' minima within the margin); a typical
+//            uncertified row is a near-tie of two codes: two candidates instead of K;
+//   n = -2 : some lane's SECOND minimum may be within the margin too (or more than LQ_CAND_MAX lanes are): every code of the
+//            lanes in `mask` (bit l = lane 16h + l) has to be scored -- |mask| K/32 codes.  The mask holds every lane whose
+//            minimum is <= vmax, the largest value the margin admits: v - best <= t0 + p (|best| + |v|) implies
+//            v <= (best + t0 + p |best|) / (1 - p), and a lane with ANY admissible code has its minimum below that;
+//   n = -1 : no information (scan all K codes).
+// `mask` is always valid unless n = -1; the exact kernels use the lane masks of both parts as soon as one part says -2.
+#define LQ_CAND_MAX 6
+__host__ __device__ static inline size_t lq_list_ints(int64_t N);
+__host__ __device__ static inline size_t lq_cand_cap(int64_t N) { return (size_t)(N / 8) + 64; }   // slots that get a list; later slots: full scan
+
+template <bool PACK>
+__device__ __forceinline__ void lq_screen_emit(const LqDecision& dec, bool certified, bool lists_ok, int my_k, int64_t row,
+                                               bool row_valid, int* __restrict__ amb_count, int* __restrict__ amb_list, int64_t N,
+                                               int K, int lane, unsigned keep_mask, const unsigned char* wave_lds) {
+    const bool need = row_valid && !certified;                          // the same in both halves of the row
+    if (__builtin_amdgcn_ballot_w64(need) == 0ull) return;              // wave-uniform: most waves have nothing to list
+    const int ln = lane & 31, h = lane >> 5;
+    int slot = 0;
+    if (h == 0 && need) {
+        slot = atomicAdd(amb_count, 1);
+        amb_list[slot] = (int)row;
+        amb_list[lq_list_ints(N) + slot] = my_k;                        // the screen's best candidate: bounds the exact scan
+    }
+    slot = __shfl(slot, ln, 64);                                        // the row's other half learns the slot
+    if (!need || (size_t)slot >= lq_cand_cap(N)) return;
+    int* out = amb_list + 2 * lq_list_ints(N) + (size_t)slot * 16 + 8 * h;
+    const float ab = lq_abs(dec.best);
+    // vmax, rounded up generously (the two roundings of the quotient are far below the 2^-20 slack)
+    const float vmax0 = (dec.best + dec.t0 + dec.p * ab) / (1.0f - dec.p);
+    const float vmax = vmax0 + lq_abs(vmax0) * 9.5367431640625e-07f + 1.1754944e-38f;
+    int n = 0;
+    unsigned mask = 0u;
+    bool nothing = !lists_ok || !dec.screen_ok || !(vmax == vmax);
+    const bool second_in = !(dec.m2min - dec.best > dec.t0 + dec.p * (ab + lq_abs(dec.m2min)));
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const float v = dec.vv[e];
+        if (!(v > vmax)) mask |= 1u << e;                               // (a NaN stays in)
+        if (!(v - dec.best > dec.t0 + dec.p * (ab + lq_abs(v)))) {      // not excluded (a NaN excludes nothing)
+            int code;
+            if constexpr (PACK) code = (int)(__float_as_uint(v) & ~keep_mask) * 32 + 16 * h + e;
+            else code = reinterpret_cast<const int*>(wave_lds)[ln * LQ_DECIDE_STRIDE + 16 * h + e];
+            nothing = nothing || code < 0 || code >= K;
+            if (n < LQ_CAND_MAX) out[2 + n] = code;
+            ++n;
+        }
+    }
+    out[1] = (int)mask;
+    out[0] = nothing ? -1 : ((second_in || n > LQ_CAND_MAX) ? -2 : n);
 }
 
 // usage[k] += 1 for every lane with `active`, with duplicates inside the wave combined first: when many rows map
@@ -550,8 +629,10 @@ __device__ __forceinline__ void lq_screen_gather(const float* __restrict__ cb, f
     }
 }
 
-// workspace of the screened routes: [64 B: counter] [row list: lq_list_ints(N) ints] [candidate list: the same]
+// workspace of the screened routes: [64 B: counter] [row list: lq_list_ints(N) ints] [best-candidate list: the same]
+// [short lists: 16 ints x lq_cand_cap(N)]
 __host__ __device__ static inline size_t lq_list_ints(int64_t N) { return ((size_t)N + 15) & ~(size_t)15; }
+__host__ __device__ static inline size_t lq_lists_bytes(int64_t N) { return sizeof(int) * (2 * lq_list_ints(N) + 16 * lq_cand_cap(N)); }
 
 // exact decision for listed rows (lipvq_screen.hip); z_by_slot: z is a compact [count][D] buffer
 int lipvq_launch_rows(const float* z, int z_by_slot, const float* cb, int64_t* idx, float* zq, int64_t* usage,

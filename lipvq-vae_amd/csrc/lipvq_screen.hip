@@ -23,6 +23,8 @@
 // operand magnitudes from 1e-6 to 1e6 (scripts/measure_bound.py, measure_bound_scales.py): 2^-22.  gamma
 // (LIPVQ_SCREEN_GAMMA) is 2^-18: 5x the analytic split bound, 16x the largest error observed;
 // tests/test_gpu_screen.py (test_error_bound_holds, test_any_magnitude) assert a >= 4x margin on every run.
+#include <stdlib.h>
+
 #include "lipvq_screen.h"
 
 extern "C" size_t lipvq_nearest_prep_bytes(int K, int D) {
@@ -212,21 +214,19 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
     }
     int my_k;
     const float pack_eps = (SC::PACK && !DBG) ? lq_pow2f(lq_pack_bits(L.ntiles) - 23) : 0.0f;
+    const unsigned keep_mask = (SC::PACK && !DBG) ? ~((1u << lq_pack_bits(L.ntiles)) - 1u) : 0xffffffffu;
+    unsigned char* scratch = lds + (size_t)wave * LQ_DECIDE_BYTES;
+    LqDecision dec;
     bool certified;
-    if (SC::PACK && !DBG)
-        certified = lq_screen_decide<true>(m1, m2, k1, lds + (size_t)wave * LQ_DECIDE_BYTES, hdr, n2, fown, gamma, K, D, lane, my_k, pack_eps,
-                                           ~((1u << lq_pack_bits(L.ntiles)) - 1u));
-    else
-        certified = lq_screen_decide<false>(m1, m2, k1, lds + (size_t)wave * LQ_DECIDE_BYTES, hdr, n2, fown, gamma, K, D, lane, my_k, 0.0f);
-    if (h == 0 && row < N) {
-        if (certified) {
-            idx[row] = (int64_t)my_k;
-        } else {
-            const int slot = atomicAdd(amb_count, 1);
-            amb_list[slot] = (int)row;
-            amb_list[lq_list_ints(N) + slot] = my_k;             // the screen's best candidate: bounds the exact scan
-        }
+    // (the debug hook runs with the caller's gamma, which need not bound anything: its uncertified rows get no short list)
+    if (SC::PACK && !DBG) {
+        certified = lq_screen_decide<true>(m1, m2, k1, scratch, hdr, n2, fown, gamma, K, D, lane, my_k, dec, pack_eps, keep_mask);
+        lq_screen_emit<true>(dec, certified, true, my_k, row, row < N, amb_count, amb_list, N, K, lane, keep_mask, scratch);
+    } else {
+        certified = lq_screen_decide<false>(m1, m2, k1, scratch, hdr, n2, fown, gamma, K, D, lane, my_k, dec, 0.0f);
+        lq_screen_emit<false>(dec, certified, !DBG, my_k, row, row < N, amb_count, amb_list, N, K, lane, keep_mask, scratch);
     }
+    if (h == 0 && row < N && certified) idx[row] = (int64_t)my_k;
     if (usage) lq_usage_add(usage, my_k, h == 0 && row < N && certified);
     if (zq) lq_screen_gather(cb, zq, my_k, certified, row0, N, D, lane);
 }
@@ -311,6 +311,102 @@ __device__ __forceinline__ float lq_seed_bound(const float (&zr)[DCH * 8], const
     return (b == b) ? b : INFINITY;                                            // a NaN square prunes nothing
 }
 
+// One thread's share of a listed row's exact decision (thread = (row r of the workgroup, slice sl of SL)), by what
+// lq_screen_emit (lipvq_screen.h) wrote for the row:
+//  * short lists: slice j scores candidate j exactly -- typically two codes instead of K;
+//  * lane masks: the codes congruent to a flagged lane mod 32, tiles of 32 codes dealt to the slices;
+//  * nothing: codes [sl per, (sl+1) per) are scanned; the screen's best candidate, when there is one, bounds both kinds of scan.
+// Returns the slice's (root, code); the caller takes the smallest root, the LOWER CODE among equal roots (torch.argmin's
+// first-minimum rule, v5:46).
+template <int DCH, int SL>
+__device__ __forceinline__ void lq_rows_search(const float (&zr)[DCH * 8], const float* __restrict__ cb, int K, int sl, int cslot,
+                                               const int* __restrict__ seed_list, const int* __restrict__ cand_list,
+                                               size_t cand_cap, float& best_v, int& best_k) {
+    constexpr int D = DCH * 8;
+    const int per = (K + SL - 1) / SL;
+    const int kb = sl * per, ke = (kb + per < K) ? kb + per : K;
+    float best_s = INFINITY;
+    best_v = INFINITY;
+    best_k = kb < K ? kb : K - 1;            // always a valid code, even if every distance is NaN (torch.argmin
+                                             // of an all-NaN row is unspecified; an out-of-range index is not an option)
+    int n0 = -1, n1 = -1;
+    const int* cl = nullptr;
+    if (cand_list && (size_t)cslot < cand_cap) {
+        cl = cand_list + (size_t)cslot * 16;
+        n0 = cl[0]; n1 = cl[8];
+    }
+    if (n0 >= 0 && n1 >= 0 && n0 + n1 >= 1 && n0 <= LQ_CAND_MAX && n1 <= LQ_CAND_MAX) {
+        const int j = sl < n0 + n1 ? sl : 0;                      // idle slices repeat candidate 0
+        const int code = j < n0 ? cl[2 + j] : cl[10 + (j - n0)];
+        if (code >= 0 && code < K) {                              // (lq_screen_emit lists valid codes only)
+            const float4* c4 = reinterpret_cast<const float4*>(cb + (size_t)code * D);
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+#pragma unroll
+            for (int i = 0; i < DCH; ++i) {
+                const float4 lo = c4[2 * i], hi = c4[2 * i + 1];
+                const float d0 = zr[8 * i + 0] - lo.x, d1 = zr[8 * i + 1] - lo.y;
+                const float d2 = zr[8 * i + 2] - lo.z, d3 = zr[8 * i + 3] - lo.w;
+                const float d4 = zr[8 * i + 4] - hi.x, d5 = zr[8 * i + 5] - hi.y;
+                const float d6 = zr[8 * i + 6] - hi.z, d7 = zr[8 * i + 7] - hi.w;
+                a0 = lq_fma(d0, d0, a0); a1 = lq_fma(d1, d1, a1);
+                a2 = lq_fma(d2, d2, a2); a3 = lq_fma(d3, d3, a3);
+                a4 = lq_fma(d4, d4, a4); a5 = lq_fma(d5, d5, a5);
+                a6 = lq_fma(d6, d6, a6); a7 = lq_fma(d7, d7, a7);
+            }
+            const float v = lq_sqrt(((((((a0 + a1) + a2) + a3) + a4) + a5) + a6) + a7);
+            best_k = code;
+            best_v = (v == v) ? v : INFINITY;                     // a NaN root never wins; the code stays valid
+            return;
+        }
+    }
+    float prune = INFINITY;
+    if (seed_list) {                         // rows listed by the screen come with its best candidate
+        int seed = seed_list[cslot];
+        seed = (seed >= 0 && seed < K) ? seed : 0;
+        prune = lq_seed_bound<DCH>(zr, cb, seed);
+    }
+    if (n0 != -1 && n1 != -1 && cl) {
+        // lane masks (at least one part said -2; a part with a short list contributes the lanes of its mask all the same)
+        const unsigned lanes = ((unsigned)cl[1] & 0xffffu) | (((unsigned)cl[9] & 0xffffu) << 16);
+        const int ntile = (K + 31) / 32;
+        for (int t = sl; t < ntile; t += SL) {                    // ascending codes within a slice: first minimum kept
+            unsigned m = lanes;
+            while (m) {
+                const int l = __builtin_ctz(m);
+                m &= m - 1;
+                const int k = 32 * t + l;
+                if (k < K) lq_exact_scan<DCH, true>(zr, cb, k, k + 1, best_v, best_s, best_k, prune);
+            }
+        }
+        return;
+    }
+    if (seed_list) lq_exact_scan<DCH, true>(zr, cb, kb, ke, best_v, best_s, best_k, prune);
+    else lq_exact_scan<DCH>(zr, cb, kb, ke, best_v, best_s, best_k);
+}
+
+// (root, code) of a row over its SL slices: smallest root, among equal roots the lower code (first-minimum rule).  Thread
+// layout tid = sl * 4 + r: the 16 slices a wave holds for row r sit in lanes r, r+4, ..: four xor-shuffles, then the four
+// waves' results through LDS.  (The first version let one thread walk all 64 slices: 17 k cycles of dependent LDS reads,
+// a third of the workgroup's critical path once the search had shrunk to two candidates.)
+__device__ __forceinline__ void lq_rows_reduce(float& bv, int& bk, float (*s_v)[64], int (*s_k)[64], int r, int tid) {
+#pragma unroll
+    for (int off = 4; off < 64; off <<= 1) {
+        const float ov = __shfl_xor(bv, off, 64);
+        const int ok = __shfl_xor(bk, off, 64);
+        if (ov < bv || (ov == bv && ok < bk)) { bv = ov; bk = ok; }
+    }
+    if ((tid & 63) < 4) { s_v[r][tid >> 6] = bv; s_k[r][tid >> 6] = bk; }
+    __syncthreads();
+    if (tid < 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float ov = s_v[r][q];
+            const int ok = s_k[r][q];
+            if (q == 0 || ov < bv || (ov == bv && ok < bk)) { bv = ov; bk = ok; }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // exact decision for the listed rows: 4 rows x 64 code slices per workgroup
 // ------------------------------------------------------------------------------------------
@@ -318,7 +414,7 @@ template <int DCH>
 __global__ __launch_bounds__(256) void nearest_rows_kernel(
     const float* __restrict__ z, const float* __restrict__ cb, int64_t* __restrict__ idx, float* __restrict__ zq,
     unsigned long long* __restrict__ usage, const int* __restrict__ row_list, const int* __restrict__ row_count,
-    int K, int z_by_slot, int count_direct, const int* __restrict__ seed_list) {
+    int K, int z_by_slot, int count_direct, const int* __restrict__ seed_list, const int* __restrict__ cand_list, size_t cand_cap) {
     constexpr int D = DCH * 8;
     constexpr int RB = 4, SL = 64;               // rows per workgroup, code slices per row
     __shared__ float s_v[RB][SL];
@@ -339,28 +435,13 @@ __global__ __launch_bounds__(256) void nearest_rows_kernel(
             zr[4 * i + 0] = v.x; zr[4 * i + 1] = v.y; zr[4 * i + 2] = v.z; zr[4 * i + 3] = v.w;
         }
     }
-    const int per = (K + SL - 1) / SL;
-    const int kb = sl * per, ke = (kb + per < K) ? kb + per : K;
-    float best_v = INFINITY, best_s = INFINITY;
-    int best_k = kb < K ? kb : 0;            // always a valid code, even if every distance is NaN (torch.argmin
-                                             // of an all-NaN row is unspecified; an out-of-range index is not an option)
-    if (seed_list) {                         // wave-uniform: rows listed by the screen come with its best candidate
-        int seed = seed_list[cslot];
-        seed = (seed >= 0 && seed < K) ? seed : 0;
-        lq_exact_scan<DCH, true>(zr, cb, kb, ke, best_v, best_s, best_k, lq_seed_bound<DCH>(zr, cb, seed));
-    } else {
-        lq_exact_scan<DCH>(zr, cb, kb, ke, best_v, best_s, best_k);
-    }
-    s_v[r][sl] = best_v; s_k[r][sl] = best_k;
-    __syncthreads();
-    if (sl == 0 && valid) {
-        // slices hold increasing code ranges: the first slice reaching the minimum root wins
-        float bv = s_v[r][0];
-        int bk = s_k[r][0];
-        for (int q = 1; q < SL; ++q)
-            if (s_v[r][q] < bv) { bv = s_v[r][q]; bk = s_k[r][q]; }
-        idx[row] = (int64_t)bk;
-        s_k[r][0] = bk;
+    float best_v;
+    int best_k;
+    lq_rows_search<DCH, SL>(zr, cb, K, sl, cslot, seed_list, cand_list, cand_cap, best_v, best_k);
+    lq_rows_reduce(best_v, best_k, s_v, s_k, r, threadIdx.x);
+    if (sl == 0) {
+        if (valid) idx[row] = (int64_t)best_k;
+        s_k[r][0] = best_k;
     }
     if (usage && threadIdx.x < 64) lq_usage_add(usage, (sl == 0 && valid) ? s_k[r][0] : 0, sl == 0 && valid);
     __syncthreads();
@@ -387,25 +468,54 @@ template <int DCH>
 __global__ __launch_bounds__(256) void nearest_rows_encode_kernel(
     const float* __restrict__ x, RawEncoder w, int A, const float* __restrict__ cb, int64_t* __restrict__ idx,
     float* __restrict__ zq, unsigned long long* __restrict__ usage, const int* __restrict__ row_list,
-    const int* __restrict__ row_count, int K, const int* __restrict__ seed_list) {
+    const int* __restrict__ row_count, int K, const int* __restrict__ seed_list, const int* __restrict__ cand_list, size_t cand_cap) {
     constexpr int D = DCH * 8;
     constexpr int RB = 4, SL = 64;
     __shared__ float s_x[RB][64];
-    __shared__ float s_h0[RB][64];
-    __shared__ float s_h1[RB][128];
+    __shared__ __attribute__((aligned(16))) float s_h0[RB][64];
+    __shared__ __attribute__((aligned(16))) float s_h1[RB][128];
     __shared__ __attribute__((aligned(16))) float s_z[RB][D];
     __shared__ float s_v[RB][SL];
     __shared__ int s_k[RB][SL];
     const int count = *row_count;
     const int tid = threadIdx.x;
+#ifdef LQ_ROWS_STAMPS        /* diagnostic build: one workgroup prints its cycle stamps */
+    long long rst_prev = __builtin_amdgcn_s_memtime(), rst_t[8];
+    int rst_n = 0;
+#define LQ_RSTAMP(name) do { const long long t_ = __builtin_amdgcn_s_memtime(); if (rst_n < 8) rst_t[rst_n++] = t_ - rst_prev; rst_prev = t_; \
+        if (rst_n == 7 && blockIdx.x == 7 && tid == 0) printf("x %lld | L0 %lld | L1 %lld | L2 %lld | search %lld | reduce %lld | zq %lld\n", rst_t[0], rst_t[1], rst_t[2], rst_t[3], rst_t[4], rst_t[5], rst_t[6]); } while (0)
+#else
+#define LQ_RSTAMP(name) do { } while (0)
+#endif
   for (int base = blockIdx.x * RB; base < count; base += gridDim.x * RB) {
     // ---- encoder for the 4 rows -------------------------------------------------------------------------------
+    // thread j owns output j of layers 1 and 2 for all four rows; its weight rows are fetched whole (16-byte loads) and FIRST:
+    // they do not depend on x, so their L2 round trip overlaps the row-list -> x chain.  (The first version walked each row with
+    // dependent 4-byte loads, 2 (r, j) pairs per thread: ~30 us of round trips that were the whole launch once the search
+    // shrank to two candidates per row.)
+    const bool al16 = ((((uintptr_t)w.W1) | ((uintptr_t)w.W2)) & 15) == 0;          // uniform
+    auto load4 = [&](const float* p) {
+        if (al16) return *reinterpret_cast<const float4*>(p);
+        return make_float4(p[0], p[1], p[2], p[3]);
+    };
+    float4 wv[16], wa[16], wb[16];                 // W1 row (64), the two halves of the W2 row (128)
+    if (tid < 128) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wv[i] = load4(w.W1 + (size_t)tid * 64 + 4 * i);
+    }
+    if (tid < D) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wa[i] = load4(w.W2 + (size_t)tid * 128 + 4 * i);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wb[i] = load4(w.W2 + (size_t)tid * 128 + 64 + 4 * i);
+    }
     for (int o = tid; o < RB * A; o += 256) {
         const int r = o / A, k = o - r * A;
         const int sl_ = base + r < count ? base + r : count - 1;
         s_x[r][k] = x[(size_t)row_list[sl_] * A + k];
     }
     __syncthreads();
+    LQ_RSTAMP("x staged");
     {
         const int r = tid >> 6, j = tid & 63;
         float acc = w.b0[j];
@@ -414,22 +524,59 @@ __global__ __launch_bounds__(256) void nearest_rows_encode_kernel(
         s_h0[r][j] = lq_gelu(acc);
     }
     __syncthreads();
-    for (int o = tid; o < RB * 128; o += 256) {
-        const int r = o >> 7, j = o & 127;
-        float acc = w.b1[j];
-        const float* wr = w.W1 + (size_t)j * 64;
-        for (int k = 0; k < 64; ++k) acc = lq_fma(s_h0[r][k], wr[k], acc);
-        s_h1[r][j] = lq_gelu(acc);
+    LQ_RSTAMP("layer0");
+    if (tid < 128) {
+        const int j = tid;
+        float acc[RB];
+        const float bj = w.b1[j];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = bj;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const float4 hv = *reinterpret_cast<const float4*>(&s_h0[r][4 * i]);       // (broadcast read)
+                acc[r] = lq_fma(hv.x, wv[i].x, acc[r]);
+                acc[r] = lq_fma(hv.y, wv[i].y, acc[r]);
+                acc[r] = lq_fma(hv.z, wv[i].z, acc[r]);
+                acc[r] = lq_fma(hv.w, wv[i].w, acc[r]);
+            }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) s_h1[r][j] = lq_gelu(acc[r]);
     }
     __syncthreads();
-    for (int o = tid; o < RB * D; o += 256) {
-        const int r = o / D, j = o - r * D;
-        float acc = w.b2[j];
-        const float* wr = w.W2 + (size_t)j * 128;
-        for (int k = 0; k < 128; ++k) acc = lq_fma(s_h1[r][k], wr[k], acc);
-        s_z[r][j] = lq_sigmoid(acc);
+    LQ_RSTAMP("layer1");
+    if (tid < D) {
+        const int j = tid;
+        float acc[RB];
+        const float bj = w.b2[j];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = bj;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const float4 hv = *reinterpret_cast<const float4*>(&s_h1[r][4 * i]);
+                acc[r] = lq_fma(hv.x, wa[i].x, acc[r]);
+                acc[r] = lq_fma(hv.y, wa[i].y, acc[r]);
+                acc[r] = lq_fma(hv.z, wa[i].z, acc[r]);
+                acc[r] = lq_fma(hv.w, wa[i].w, acc[r]);
+            }
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const float4 hv = *reinterpret_cast<const float4*>(&s_h1[r][64 + 4 * i]);
+                acc[r] = lq_fma(hv.x, wb[i].x, acc[r]);
+                acc[r] = lq_fma(hv.y, wb[i].y, acc[r]);
+                acc[r] = lq_fma(hv.z, wb[i].z, acc[r]);
+                acc[r] = lq_fma(hv.w, wb[i].w, acc[r]);
+            }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) s_z[r][j] = lq_sigmoid(acc[r]);
     }
     __syncthreads();
+    LQ_RSTAMP("layer2");
     // ---- exact search (same as nearest_rows_kernel, z from LDS) ---------------------------------------------------
     const int r = tid & (RB - 1), sl = tid / RB;
     const int slot = base + r;
@@ -441,27 +588,18 @@ __global__ __launch_bounds__(256) void nearest_rows_encode_kernel(
         const float4 v = reinterpret_cast<const float4*>(&s_z[r][0])[i];
         zr[4 * i + 0] = v.x; zr[4 * i + 1] = v.y; zr[4 * i + 2] = v.z; zr[4 * i + 3] = v.w;
     }
-    const int per = (K + SL - 1) / SL;
-    const int kb = sl * per, ke = (kb + per < K) ? kb + per : K;
-    float best_v = INFINITY, best_s = INFINITY;
-    int best_k = kb < K ? kb : 0;
-    {
-        int seed = seed_list[valid ? slot : count - 1];
-        seed = (seed >= 0 && seed < K) ? seed : 0;
-        lq_exact_scan<DCH, true>(zr, cb, kb, ke, best_v, best_s, best_k, lq_seed_bound<DCH>(zr, cb, seed));
-    }
-    s_v[r][sl] = best_v; s_k[r][sl] = best_k;
-    __syncthreads();
-    if (sl == 0 && valid) {
-        float bv = s_v[r][0];
-        int bk = s_k[r][0];
-        for (int q = 1; q < SL; ++q)
-            if (s_v[r][q] < bv) { bv = s_v[r][q]; bk = s_k[r][q]; }
-        idx[row] = (int64_t)bk;
-        s_k[r][0] = bk;
+    float best_v;
+    int best_k;
+    lq_rows_search<DCH, SL>(zr, cb, K, sl, valid ? slot : count - 1, seed_list, cand_list, cand_cap, best_v, best_k);
+    LQ_RSTAMP("search");
+    lq_rows_reduce(best_v, best_k, s_v, s_k, r, tid);
+    if (sl == 0) {
+        if (valid) idx[row] = (int64_t)best_k;
+        s_k[r][0] = best_k;
     }
     if (usage && tid < 64) lq_usage_add(usage, (sl == 0 && valid) ? s_k[r][0] : 0, sl == 0 && valid);
     __syncthreads();
+    LQ_RSTAMP("reduce+idx");
     if (zq && valid) {
         const int bk = s_k[r][0];
         const float4* src = reinterpret_cast<const float4*>(cb + (size_t)bk * D);
@@ -469,6 +607,7 @@ __global__ __launch_bounds__(256) void nearest_rows_encode_kernel(
         for (int v = sl; v < D / 4; v += SL) dst[v] = src[v];
     }
     __syncthreads();
+    LQ_RSTAMP("zq");
   }
 }
 
@@ -478,10 +617,12 @@ int lipvq_launch_rows_encode(const float* x, const float* const* raw6, int A, co
     const int* amb_seed = amb_list + lq_list_ints(N);
     RawEncoder w{raw6[0], raw6[1], raw6[2], raw6[3], raw6[4], raw6[5]};
     int64_t blocks = (N + 3) / 4;
-    if (blocks > 4096) blocks = 4096;
+    static int grid_cap = -1;                   // LIPVQ_ROWS_GRID: measurement knob
+    if (grid_cap < 0) { const char* e = getenv("LIPVQ_ROWS_GRID"); grid_cap = e ? atoi(e) : 1024; }      // (the count lives on the device; the grid strides)
+    if (blocks > grid_cap) blocks = grid_cap;
     auto go = [&](auto kfn) {
         hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(256), 0, st, x, w, A, cb, idx, zq,
-                           (unsigned long long*)usage, amb_list, amb_count, K, amb_seed);
+                           (unsigned long long*)usage, amb_list, amb_count, K, amb_seed, amb_list + 2 * lq_list_ints(N), lq_cand_cap(N));
     };
     switch (D) {
         case 32: go(nearest_rows_encode_kernel<4>); break;
@@ -498,7 +639,7 @@ int lipvq_launch_rows_encode(const float* x, const float* const* raw6, int A, co
 // ------------------------------------------------------------------------------------------
 extern "C" size_t lipvq_nearest_workspace_bytes(int64_t N) {
     if (N <= 0) return 0;
-    return 64 + 2 * sizeof(int) * lq_list_ints(N);    // [0] uncertified-row counter, then the row list and the candidate list
+    return 64 + lq_lists_bytes(N);    // [0] uncertified-row counter, then the row list, the best-candidate list and the short lists
 }
 
 template <int S>
@@ -527,7 +668,8 @@ static int launch_rows_t(const float* z, int z_by_slot, const float* cb, int64_t
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL((nearest_rows_kernel<DCH>), dim3((unsigned)blocks), dim3(256), 0, st, z, cb, idx, zq,
                        (unsigned long long*)usage, amb_list, amb_count, K, z_by_slot, amb_list ? 0 : (int)N,
-                       amb_list ? amb_list + lq_list_ints(N) : nullptr);
+                       amb_list ? amb_list + lq_list_ints(N) : nullptr, amb_list ? amb_list + 2 * lq_list_ints(N) : nullptr,
+                       amb_list ? lq_cand_cap(N) : (size_t)0);
     return check_launch("nearest_rows");
 }
 
