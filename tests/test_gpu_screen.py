@@ -202,3 +202,54 @@ def test_nearest_rows_all_rows_equals_oracle(oracle, N, K, D):
     assert np.array_equal(idx.cpu().numpy(), idx_ref)
     assert np.array_equal(zq.cpu().numpy(), zq_ref)
     assert np.array_equal(usage.cpu().numpy(), usage_ref)
+
+
+def _list_modes(ws, N):
+    """How lq_screen_emit listed the uncertified rows (csrc/lipvq_screen.h): counts of short lists / lane masks / full scans."""
+    w = ws.cpu().numpy()
+    cnt, L, cap = int(w[0]), (N + 15) & ~15, N // 8 + 64
+    cl = w[16 + 2 * L: 16 + 2 * L + 16 * cap].reshape(cap, 16)[:min(cnt, cap)]
+    n0, n1 = cl[:, 0], cl[:, 8]
+    full = (n0 == -1) | (n1 == -1)
+    lanes = ~full & ((n0 == -2) | (n1 == -2))
+    return int((~full & ~lanes).sum()), int(lanes.sum()), int(full.sum()), max(0, cnt - cap)
+
+
+@pytest.mark.parametrize("K,D", [(1024, 64), (8192, 128), (1024, 208), (256, 32)])
+def test_uncertified_rows_by_list_kind(ops, oracle, K, D):
+    """The three ways an uncertified row reaches the exact kernel -- a short list of codes, lane masks (two near-equidistant
+    codes that share a lane of the screen, i.e. congruent mod 32; or more than six candidate lanes), and slots past the list
+    capacity -- all return the oracle's first-minimum index."""
+    rng = np.random.default_rng(K + D)
+    N = 640
+    cb = rng.uniform(0, 1, (K, D)).astype(np.float32)
+    z = np.empty((N, D), np.float32)
+    for n in range(N):
+        kind = n % 4
+        t = np.float32(0.5 + (n % 5 - 2) * 1e-8)
+        if kind == 0:                       # bisector of two codes in different lanes
+            a = int(rng.integers(K)); b = (a + 1 + int(rng.integers(30))) % K
+            if (a - b) % 32 == 0:
+                b = (b + 1) % K
+        elif kind == 1:                     # bisector of two codes in the SAME lane
+            a = int(rng.integers(K)); b = (a + 32 * (1 + int(rng.integers(K // 32 - 1)))) % K
+        else:
+            a = b = int(rng.integers(K))
+        z[n] = cb[a] * t + cb[b] * (np.float32(1) - t)
+        if kind == 2:                       # exactly one code, nothing near
+            z[n] = cb[a]
+    # rows of kind 3 sit on a code that exists nine times (nine lanes): more candidates than a short list holds
+    dup = rng.choice(K, 9, replace=False)
+    dup = dup[np.argsort(dup % 32)]
+    if len(set(int(v) % 32 for v in dup)) == 9:
+        cb[dup[1:]] = cb[dup[0]]
+        z[3::4] = cb[dup[0]] + (1e-7 * rng.standard_normal((len(z[3::4]), D))).astype(np.float32)
+    idx_ref, zq_ref, _ = oracle.nearest(z, cb)
+    cbd = dev(cb)
+    idx, zq, ws = ops.nearest_screened(dev(z), cbd, ops.nearest_prepare(cbd), return_workspace=True)
+    assert np.array_equal(idx.cpu().numpy(), idx_ref)
+    assert np.array_equal(zq.cpu().numpy(), zq_ref)
+    short, lanes, full, past = _list_modes(ws, N)
+    assert short >= 32 and lanes >= 32, (short, lanes, full, past)
+    assert full == 0, "a finite codebook needs no full scans"
+    assert past > 0, "list capacity (N/8 + 64 slots) was meant to be exceeded here"
