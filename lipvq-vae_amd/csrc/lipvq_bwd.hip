@@ -340,6 +340,177 @@ __global__ __launch_bounds__(64 * WGW_WAVES) void wgrad_wg4_kernel(const float* 
     }
 }
 
+// Double-buffered variant (TI, TJ in {1, 2, 4}: every layer of the tokenizer at D <= 128).  The ISA of wgrad_wg4_kernel showed
+// why it never left ~250 us at N = 524 288: its look-ahead registers live in arrays captured by a lambda, hipcc keeps them in
+// SCRATCH (scratch_store right behind every global load, scratch_load + vmcnt(0) in front of every LDS write), and the runtime
+// activation switch inlines the whole erf/exp tail into the staging code.  Here everything is straight-line over compile-time
+// shapes: a block of 64 rows is 512 TI + 512 TJ float4s, exactly TI + TJ per thread (no remainder tests); two LDS buffers, so one
+// barrier per block: compute block b from buffer b & 1, then write block b+1 (already in registers) into the other buffer and
+// issue the loads of block b+2 -- a whole block of MFMAs to land.  The GELU is the straight-line polynomial with the rare
+// |x| >= sqrt(18) elements fixed up behind a branch.  Same chunk-ordered, row-ordered accumulation: the same bits.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 wg5_act(f32x4 v, int act) {
+    if (act == LIPVQ_ACT_GELU) {
+        f32x4 o;
+        o.x = lq_gelu_poly(v.x); o.y = lq_gelu_poly(v.y); o.z = lq_gelu_poly(v.z); o.w = lq_gelu_poly(v.w);
+        const float m = fmaxf(fmaxf(v.x * v.x, v.y * v.y), fmaxf(v.z * v.z, v.w * v.w));
+        if (!(m < 18.0f)) {                                            // rare (also taken for NaN: lq_gelu propagates it)
+            o.x = lq_gelu(v.x); o.y = lq_gelu(v.y); o.z = lq_gelu(v.z); o.w = lq_gelu(v.w);
+        }
+        return o;
+    }
+    if (act == LIPVQ_ACT_RELU) return (f32x4){v.x > 0.f ? v.x : 0.f, v.y > 0.f ? v.y : 0.f, v.z > 0.f ? v.z : 0.f, v.w > 0.f ? v.w : 0.f};
+    if (act == LIPVQ_ACT_SIGMOID) return (f32x4){lq_sigmoid(v.x), lq_sigmoid(v.y), lq_sigmoid(v.z), lq_sigmoid(v.w)};
+    return v;
+}
+
+__device__ __forceinline__ f32x4 wg5_sel(bool keep, f32x4 v) {        // (a ?: on HIP's float4 STRUCT goes through scratch memory)
+    return (f32x4){keep ? v.x : 0.f, keep ? v.y : 0.f, keep ? v.z : 0.f, keep ? v.w : 0.f};
+}
+
+template <int TI, int TJ>
+__global__ __launch_bounds__(64 * WGW_WAVES) void wgrad_wg5_kernel(const float* __restrict__ G, const float* __restrict__ H,
+                                                                   const int64_t* __restrict__ hidx, int h_act,
+                                                                   float* __restrict__ partW, float* __restrict__ partB,
+                                                                   int64_t N, int J, int Kd, int chunk_rows) {
+    extern __shared__ __attribute__((aligned(16))) float wg_lds[];
+    constexpr int Jp = 32 * TI, Kp = 32 * TJ, Jp4 = Jp / 4, Kp4 = Kp / 4;
+    constexpr int T = TI * TJ, TPW = (T + WGW_WAVES - 1) / WGW_WAVES;
+    constexpr int BUF = WG4_ROWS * (Jp + Kp);                 // floats per LDS buffer: [64][Jp] of G, then [64][Kp] of act(H)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kh = lane >> 5;
+    const int J4 = J >> 2, K4 = Kd >> 2;
+    // whole-float4 rows (16-byte aligned bases: host check).  Only a one-tile operand may have odd rows (fan-in 7: element loads);
+    // for the wide instantiations the test is a compile-time constant -- as a runtime flag it cost the hot shape 45 us
+    const bool vecG = TI > 1 || (J & 3) == 0, vecH = TJ > 1 || (Kd & 3) == 0;
+    const int64_t r0 = (int64_t)blockIdx.x * chunk_rows;
+    int64_t r1 = r0 + chunk_rows;
+    if (r1 > N) r1 = N;
+    const int nblk = (int)((r1 - r0 + WG4_ROWS - 1) / WG4_ROWS);
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+    float bsum0 = 0.0f, bsum1 = 0.0f;
+
+    // this thread's f32x4 slots of a block (slot u: f32x4 tid + 512 u of the [64][Jp4] / [64][Kp4] image)
+    f32x4 g0, g1, g2, g3, h0, h1, h2, h3;
+    const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    g0 = g1 = g2 = g3 = h0 = h1 = h2 = h3 = z4;
+#define WG5_SLOT(u, P4, row_, col_) const int row_ = (tid + 512 * (u)) / (P4), col_ = (tid + 512 * (u)) % (P4)
+    auto fetchG = [&](int64_t rb, int u) -> f32x4 {                   // clamped address, masked value: no branch
+        WG5_SLOT(u, Jp4, row, col);
+        const int64_t rr = rb + row;
+        const int64_t rc = rr < r1 ? rr : r1 - 1;
+        if (vecG) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(G + (size_t)rc * J)[col < J4 ? col : J4 - 1];
+            return wg5_sel(rr < r1 && col < J4, v);
+        }
+        f32x4 v;                                                       // rows that are not whole float4s (fan-in 7): element loads
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * col + e;
+            const float t = G[(size_t)rc * J + (c < J ? c : J - 1)];
+            v[e] = (rr < r1 && c < J) ? t : 0.0f;
+        }
+        return v;
+    };
+    auto fetchH = [&](int64_t rb, int u) -> f32x4 {
+        WG5_SLOT(u, Kp4, row, col);
+        const int64_t rr = rb + row;
+        const int64_t rc = rr < r1 ? rr : r1 - 1;
+        const int64_t hr = hidx ? hidx[rc] : rc;
+        if (vecH) return reinterpret_cast<const f32x4*>(H + (size_t)hr * Kd)[col < K4 ? col : K4 - 1];
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * col + e;
+            v[e] = H[(size_t)hr * Kd + (c < Kd ? c : Kd - 1)];
+        }
+        return v;
+    };
+    auto storeG = [&](float* buf, int u, f32x4 v) {
+        WG5_SLOT(u, Jp4, row, col);
+        reinterpret_cast<f32x4*>(buf)[row * Jp4 + col] = v;
+    };
+    auto storeH = [&](float* buf, int64_t rb, int u, f32x4 v) {          // activation, then the masks (act(0) need not be 0)
+        WG5_SLOT(u, Kp4, row, col);
+        v = wg5_act(v, h_act);
+        const bool in = rb + row < r1;
+        reinterpret_cast<f32x4*>(buf + WG4_ROWS * Jp)[row * Kp4 + col] =
+            (f32x4){(in && 4 * col + 0 < Kd) ? v.x : 0.f, (in && 4 * col + 1 < Kd) ? v.y : 0.f, (in && 4 * col + 2 < Kd) ? v.z : 0.f,
+                    (in && 4 * col + 3 < Kd) ? v.w : 0.f};
+    };
+#define WG5_FETCH(rb) do { \
+        g0 = fetchG(rb, 0); if (TI > 1) g1 = fetchG(rb, 1); if (TI > 2) { g2 = fetchG(rb, 2); g3 = fetchG(rb, 3); } \
+        h0 = fetchH(rb, 0); if (TJ > 1) h1 = fetchH(rb, 1); if (TJ > 2) { h2 = fetchH(rb, 2); h3 = fetchH(rb, 3); } } while (0)
+#define WG5_STAGE(buf, rb) do { \
+        storeG(buf, 0, g0); if (TI > 1) storeG(buf, 1, g1); if (TI > 2) { storeG(buf, 2, g2); storeG(buf, 3, g3); } \
+        storeH(buf, rb, 0, h0); if (TJ > 1) storeH(buf, rb, 1, h1); if (TJ > 2) { storeH(buf, rb, 2, h2); storeH(buf, rb, 3, h3); } } while (0)
+
+    WG5_FETCH(r0);
+    WG5_STAGE(wg_lds, r0);
+    WG5_FETCH(r0 + WG4_ROWS);                                  // (past the chunk: clamped addresses, staged as zeros)
+    lq_wg_barrier();
+    for (int b = 0; b < nblk; ++b) {
+        const float* cur = wg_lds + (b & 1) * BUF;
+        float* nxt = wg_lds + ((b + 1) & 1) * BUF;
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) {
+            const int t = wave + q * WGW_WAVES;
+            if (t < T) {                                       // wave-uniform
+                const int ti = t / TJ, tj = t % TJ;
+                const float* ga = cur + kh * Jp + 32 * ti + li;
+                const float* hb = cur + WG4_ROWS * Jp + kh * Kp + 32 * tj + li;
+                f32x16 acc = q == 0 ? acc0 : acc1;
+                float bs = q == 0 ? bsum0 : bsum1;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    float av[16], bv[16];
+#pragma unroll
+                    for (int s2 = 0; s2 < 16; ++s2) { av[s2] = ga[2 * (16 * half + s2) * Jp]; bv[s2] = hb[2 * (16 * half + s2) * Kp]; }
+#pragma unroll
+                    for (int s2 = 0; s2 < 16; ++s2) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], bv[s2], acc, 0, 0, 0);
+                        bs += av[s2];
+                    }
+                }
+                if (q == 0) { acc0 = acc; bsum0 = bs; } else { acc1 = acc; bsum1 = bs; }
+            }
+        }
+        // block b+1 (in registers since the previous iteration) -> the other buffer, whose last readers passed the barrier
+        // that ended iteration b-1; then the loads of block b+2
+        const int64_t rb1 = r0 + (int64_t)(b + 1) * WG4_ROWS;
+        WG5_STAGE(nxt, rb1);
+        WG5_FETCH(rb1 + WG4_ROWS);
+        lq_wg_barrier();
+    }
+#undef WG5_FETCH
+#undef WG5_STAGE
+#undef WG5_SLOT
+    float* pw = partW + (size_t)blockIdx.x * J * Kd;
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int t = wave + q * WGW_WAVES;
+        if (t >= T) continue;
+        const int ti = t / TJ, tj = t % TJ;
+        const int fj = 32 * tj + li;
+        const f32x16 acc = q == 0 ? acc0 : acc1;
+        const float bs = q == 0 ? bsum0 : bsum1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int oi = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (oi < J && fj < Kd) pw[(size_t)oi * Kd + fj] = acc[r];
+        }
+        if (tj == 0) {
+            const float tot = bs + __shfl_xor(bs, 32, 64);
+            const int fi = 32 * ti + li;
+            if (kh == 0 && fi < J) partB[(size_t)blockIdx.x * J + fi] = tot;
+        }
+    }
+}
+
 // gW / gb = sum over chunks of the partial slabs (one launch for both): 32 elements x 8 chunk groups per block (group g sums chunks g, g+8, ... in
 // double), the 8 group sums are combined in a fixed order: deterministic.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partW, const float* __restrict__ partB,
@@ -387,7 +558,23 @@ extern "C" int lipvq_wgrad_f32(const float* G, const float* H, const int64_t* hi
     if (use_wg < 0) use_wg = getenv("LIPVQ_WGRAD_PER_TILE") ? 0 : 1;
     const size_t lds4 = (size_t)WG4_ROWS * 32 * (TI + TJ) * sizeof(float);
     const int ng = (WG4_ROWS * 8 * TI + 511) / 512, nh = (WG4_ROWS * 8 * TJ + 511) / 512;      // float4s per thread and block
-    if (use_wg && (J & 3) == 0 && (Kd & 3) == 0 && TI * TJ <= WGW_WAVES * 2 && ng <= 4 && nh <= 4 && lds4 <= 64 * 1024 &&
+    static int use_wg5 = -1;                    // LIPVQ_WGRAD_NO_WG5=1: the single-buffered kernels (measurement knob)
+    if (use_wg5 < 0) use_wg5 = getenv("LIPVQ_WGRAD_NO_WG5") ? 0 : 1;
+    const bool pow2 = (TI == 1 || TI == 2 || TI == 4) && (TJ == 1 || TJ == 2 || TJ == 4);
+    if (use_wg && use_wg5 && pow2 && ((J & 3) == 0 || TI == 1) && ((Kd & 3) == 0 || TJ == 1) && (((uintptr_t)G | (uintptr_t)H) & 15) == 0) {
+        typedef void (*wg5_fn)(const float*, const float*, const int64_t*, int, float*, float*, int64_t, int, int, int);
+        wg5_fn kfn = nullptr;
+#define LQ_W5(TI_, TJ_) if (TI == TI_ && TJ == TJ_) kfn = (wg5_fn)wgrad_wg5_kernel<TI_, TJ_>;
+        LQ_W5(1, 1) LQ_W5(1, 2) LQ_W5(1, 4) LQ_W5(2, 1) LQ_W5(2, 2) LQ_W5(2, 4) LQ_W5(4, 1) LQ_W5(4, 2) LQ_W5(4, 4)
+#undef LQ_W5
+        const size_t lds5 = (size_t)2 * WG4_ROWS * 32 * (TI + TJ) * sizeof(float);
+        static LqLdsReserve reserved5[9];           // per instantiation: per-device, thread-safe (lipvq_common.h)
+        const int inst = (TI == 1 ? 0 : TI == 2 ? 1 : 2) * 3 + (TJ == 1 ? 0 : TJ == 2 ? 1 : 2);
+        if (lds5 > 64 * 1024)
+            if (int rc = lipvq_reserve_lds(reserved5[inst], (const void*)kfn, lds5, "wgrad")) return rc;
+        hipLaunchKernelGGL(kfn, dim3(nch), dim3(64 * WGW_WAVES), lds5, st, G, H, hidx, h_act, partW, partB, N, J, Kd,
+                           wgrad_chunk_rows(N));
+    } else if (use_wg && (J & 3) == 0 && (Kd & 3) == 0 && TI * TJ <= WGW_WAVES * 2 && ng <= 4 && nh <= 4 && lds4 <= 64 * 1024 &&
         (((uintptr_t)G | (uintptr_t)H) & 15) == 0) {
         const int tpw = (TI * TJ + WGW_WAVES - 1) / WGW_WAVES;
         typedef void (*wg_fn)(const float*, const float*, const int64_t*, int, float*, float*, int64_t, int, int, int, int, int);
