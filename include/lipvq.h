@@ -254,6 +254,40 @@ int lipvq_bin_hidden_f32(const int64_t* bins, const float* P, const float* b1, f
 /* out = g * act'(pre), elementwise over n floats (backward of the GELUs of bin:28,30). */
 int lipvq_act_bwd_f32(const float* g, const float* pre, float* out, int64_t n, int act, void* stream);
 
+/* ---- the DEFAULT action branch (obs_nets.py:1244-1260, the `else` of the tokenizer switch; ob = robomimic/models/obs_nets.py):
+ *      nn.Sequential(spectral_norm(Linear(A,64)), GELU, spectral_norm(Linear(64,128)), GELU, spectral_norm(Linear(128,D)),
+ *                    nn.TransformerEncoder(TransformerEncoderLayer(d_model=D, nhead=8, dim_feedforward=256, activation="gelu"), 4),
+ *                    Linear(D,D))
+ *      called on the 2-D [B*T][A] action tensor (ob:1344), i.e. the encoder sees ONE unbatched sequence of S = B*T actions.
+ *      Linears: lipvq_linear_act_f32 / lipvq_wgrad_f32 above.  lipvq-vae_amd/csrc/lipvq_xf.hip, lipvq-vae_amd/default_branch.py ---- */
+
+/* ob:1253-1257 torch.nn.utils.spectral_norm (torch/nn/utils/spectral_norm.py compute_weight), W [J][K] = weight_orig,
+ * u [J] = weight_u, v [K] = weight_v.  do_power_iteration (module.training): v = normalize(W^T u), u = normalize(W v)
+ * (x / max(|x|, eps), one iteration) written back in place.  Always: sigma[0] = u . (W v), Wsn = W / sigma.  J, K <= 256. */
+int lipvq_spectral_norm_f32(const float* W, float* u, float* v, float* Wsn, float* sigma, int J, int K,
+                            int do_power_iteration, float eps, void* stream);
+/* Backward of W -> Wsn with u, v held constant (as torch does):  gW = (gWsn - <gWsn, Wsn> u v^T) / sigma. */
+int lipvq_spectral_norm_bwd_f32(const float* gWsn, const float* Wsn, const float* u, const float* v, const float* sigma,
+                                float* gW, int J, int K, void* stream);
+
+/* ob:1245-1258 nn.MultiheadAttention inside TransformerEncoderLayer on an unbatched sequence: qkv [S][3D] = in_proj(x)
+ * (q | k | v column blocks; head h owns columns [h D/H, (h+1) D/H) of each), out [S][D] = concat_h softmax(Q_h K_h^T /
+ * sqrt(D/H)) V_h, lse [H][S] = log-sum-exp of the scaled scores (for the backward).  keep [H][S][S] bytes (may be NULL):
+ * the attention-probability dropout mask of training mode, kept entries scaled by 1 / keep_prob.  D/H <= 32. */
+int lipvq_attention_f32(const float* qkv, float* out, float* lse, const unsigned char* keep, float keep_prob, int64_t S,
+                        int D, int H, void* stream);
+/* Its backward: gqkv [S][3D] from gout [S][D]; delta [H][S] is scratch. */
+int lipvq_attention_bwd_f32(const float* qkv, const float* out, const float* gout, const float* lse, float* gqkv,
+                            float* delta, const unsigned char* keep, float keep_prob, int64_t S, int D, int H, void* stream);
+
+/* ob:1245 post-norm residual of TransformerEncoderLayer (norm_first = False): y = LayerNorm(a + b) * w + bias, rows of
+ * E <= 256 floats; b may be NULL.  xhat [N][E] and rstd [N] (either may be NULL) are saved for the backward. */
+int lipvq_add_layernorm_f32(const float* a, const float* b, const float* w, const float* bias, float eps, float* y,
+                            float* xhat, float* rstd, int64_t N, int E, void* stream);
+/* gx [N][E] (the gradient of BOTH a and b), and gw [E], gb [E] ACCUMULATED (caller zero-fills). */
+int lipvq_layernorm_bwd_f32(const float* gy, const float* xhat, const float* rstd, const float* w, float* gx, float* gw,
+                            float* gb, int64_t N, int E, void* stream);
+
 /* ---- opt-in extension: EMA codebook update (not in the reference; named by BASELINE.json's north star) ----
  * cluster_size [K] and embed_sum [K][D] are the running statistics (updated in place), counts [K] int64 = this batch's
  * code usage (lipvq_nearest_f32 / lipvq_tokenize_f32 `usage`, summed over ranks), dw [K][D] = sum of the z_e rows mapped

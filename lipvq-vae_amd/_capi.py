@@ -72,6 +72,12 @@ SIGNATURES = {
     "lipvq_bin_boundaries_f32": (_i, [_vp] * 3 + [_i, _i, _vp]),
     "lipvq_bin_hidden_f32": (_i, [_vp] * 5 + [_i64, _i, _i, _i, _vp]),
     "lipvq_act_bwd_f32": (_i, [_vp] * 3 + [_i64, _i, _vp]),
+    "lipvq_spectral_norm_f32": (_i, [_vp] * 5 + [_i, _i, _i, C.c_float, _vp]),
+    "lipvq_spectral_norm_bwd_f32": (_i, [_vp] * 6 + [_i, _i, _vp]),
+    "lipvq_attention_f32": (_i, [_vp] * 4 + [C.c_float, _i64, _i, _i, _vp]),
+    "lipvq_attention_bwd_f32": (_i, [_vp] * 7 + [C.c_float, _i64, _i, _i, _vp]),
+    "lipvq_add_layernorm_f32": (_i, [_vp] * 4 + [C.c_float] + [_vp] * 3 + [_i64, _i, _vp]),
+    "lipvq_layernorm_bwd_f32": (_i, [_vp] * 7 + [_i64, _i, _vp]),
     "lipvq_ema_update_f32": (_i, [_vp] * 5 + [C.c_float, C.c_float, _i, _i, _vp, _vp]),
     "lipvq_comm_unique_id": (_i, [_vp]),
     "lipvq_comm_init": (_i, [C.POINTER(_vp), _vp, _i, _i]),

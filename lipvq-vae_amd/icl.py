@@ -2,7 +2,8 @@
 
 * ``ICLActionBranch``      -- the action branch of ``ICLObservationGroupEncoder`` when ``vq_vae_enabled``
                              (robomimic/models/obs_nets.py:1219-1227 construction, :1335-1337 call) or
-                             ``bin_enabled`` (:1214-1217, :1343-1344): owns ``action_network``, stashes ``_vq_vae_loss``.
+                             ``bin_enabled`` (:1214-1217, :1343-1344) or neither (:1244-1260, the default branch):
+                             owns ``action_network``, stashes ``_vq_vae_loss``.
 * ``time_distributed``     -- the [B, T, ...] <-> [B*T, ...] reshape of
                              ``TensorUtils.icl_time_distributed`` (robomimic/utils/tensor_utils.py:1045-1090)
                              for the action leaf.
@@ -19,6 +20,7 @@ import torch.nn as nn
 
 from . import sharded
 from .binning import AdaptiveBinActionEmbedding
+from .default_branch import DefaultActionNetwork
 from .tokenizer import LLFQVAE_V4, VQVAE
 
 
@@ -30,8 +32,8 @@ class ICLActionBranch(nn.Module):
         self.vq_vae_enabled = bool(vq_vae_enabled) and not self.bin_enabled      # the reference's elif order
         if self.bin_enabled:             # obs_nets.py:1214-1217: the binning tokenizer of the paper's ablation
             self.action_network = AdaptiveBinActionEmbedding(action_dim=action_input_shape, output_dim=action_output_shape)
-        elif not vq_vae_enabled:
-            raise NotImplementedError("only the vq_vae_enabled and bin_enabled branches of the group encoder are on this path")
+        elif not vq_vae_enabled:         # obs_nets.py:1244-1260: spectral-norm MLP + TransformerEncoder + Linear
+            self.action_network = DefaultActionNetwork(action_input_shape, action_output_shape)
         elif variant == "lipvq":         # obs_nets.py:1225: the paper's tokenizer
             self.action_network = LLFQVAE_V4(feature_dim=action_input_shape, latent_dim=action_output_shape)
         elif variant == "vqvae":         # obs_nets.py:1220-1222 (commented-out alternative)
@@ -41,7 +43,7 @@ class ICLActionBranch(nn.Module):
         self._vq_vae_loss = None
 
     def forward(self, prompt_actions: torch.Tensor) -> torch.Tensor:
-        if self.bin_enabled:
+        if self.bin_enabled or not self.vq_vae_enabled:
             return self.action_network(prompt_actions)                    # obs_nets.py:1343-1344 (no tokenizer loss)
         context_actions, loss = self.action_network(prompt_actions)      # obs_nets.py:1336
         self._vq_vae_loss = loss                                          # obs_nets.py:1337

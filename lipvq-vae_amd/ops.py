@@ -546,3 +546,93 @@ def ema_update(cluster_size, embed_sum, counts, dw, codebook, decay, eps):
     with _on(codebook.device):
         check(lib.lipvq_ema_update_f32(_ptr(cluster_size), _ptr(embed_sum), _ptr(counts), _ptr(dw), _ptr(codebook),
                                        float(decay), float(eps), K, D, _ptr(ws), _stream()), "lipvq_ema_update_f32")
+
+
+# ---------------------------------------------------------------------------------------------------
+# the default action branch (obs_nets.py:1244-1260; csrc/lipvq_xf.hip)
+# ---------------------------------------------------------------------------------------------------
+
+def spectral_norm(W, u, v, do_power_iteration: bool, eps: float = 1e-12):
+    """(W / sigma, sigma [1]) of torch.nn.utils.spectral_norm; with do_power_iteration u and v are UPDATED IN PLACE."""
+    W, u, v = _chk(W, "W"), _chk(u, "u"), _chk(v, "v")
+    if W.dim() != 2 or u.shape != (W.shape[0],) or v.shape != (W.shape[1],):
+        raise ValueError(f"spectral_norm: W {tuple(W.shape)}, u {tuple(u.shape)}, v {tuple(v.shape)}")
+    Wsn = torch.empty_like(W)
+    sigma = torch.empty(1, device=W.device, dtype=torch.float32)
+    with _on(W.device):
+        check(lib.lipvq_spectral_norm_f32(_ptr(W), _ptr(u), _ptr(v), _ptr(Wsn), _ptr(sigma), W.shape[0], W.shape[1],
+                                          int(bool(do_power_iteration)), float(eps), _stream()), "lipvq_spectral_norm_f32")
+    return Wsn, sigma
+
+
+def spectral_norm_bwd(gWsn, Wsn, u, v, sigma):
+    gWsn, Wsn = _chk(gWsn, "gWsn"), _chk(Wsn, "Wsn")
+    gW = torch.empty_like(Wsn)
+    with _on(Wsn.device):
+        check(lib.lipvq_spectral_norm_bwd_f32(_ptr(gWsn), _ptr(Wsn), _ptr(_chk(u, "u")), _ptr(_chk(v, "v")), _ptr(_chk(sigma, "sigma")),
+                                              _ptr(gW), Wsn.shape[0], Wsn.shape[1], _stream()), "lipvq_spectral_norm_bwd_f32")
+    return gW
+
+
+def _chk_keep(keep, H, S, dev):
+    if keep is None:
+        return None
+    if keep.dtype != torch.uint8 or keep.shape != (H, S, S) or not keep.is_contiguous() or keep.device != dev:
+        raise ValueError("attention: keep must be a contiguous uint8 [H, S, S] tensor on the input's device")
+    return keep
+
+
+def attention(qkv, nhead: int, keep=None, keep_prob: float = 1.0):
+    """(out [S, D], lse [H, S]) of multi-head self-attention over the unbatched sequence qkv [S, 3D] (q | k | v)."""
+    qkv = _chk(qkv, "qkv")
+    if qkv.dim() != 2 or qkv.shape[1] % 3 != 0:
+        raise ValueError(f"attention: qkv {tuple(qkv.shape)}")
+    S, D = qkv.shape[0], qkv.shape[1] // 3
+    keep = _chk_keep(keep, nhead, S, qkv.device)
+    out = torch.empty((S, D), device=qkv.device, dtype=torch.float32)
+    lse = torch.empty((nhead, S), device=qkv.device, dtype=torch.float32)
+    with _on(qkv.device):
+        check(lib.lipvq_attention_f32(_ptr(qkv), _ptr(out), _ptr(lse), _ptr(keep), float(keep_prob), S, D, int(nhead), _stream()),
+              "lipvq_attention_f32")
+    return out, lse
+
+
+def attention_bwd(qkv, out, gout, lse, nhead: int, keep=None, keep_prob: float = 1.0):
+    qkv, out, gout, lse = _chk(qkv, "qkv"), _chk(out, "out"), _chk(gout, "gout"), _chk(lse, "lse")
+    S, D = out.shape
+    keep = _chk_keep(keep, nhead, S, qkv.device)
+    gqkv = torch.empty_like(qkv)
+    delta = torch.empty_like(lse)
+    with _on(qkv.device):
+        check(lib.lipvq_attention_bwd_f32(_ptr(qkv), _ptr(out), _ptr(gout), _ptr(lse), _ptr(gqkv), _ptr(delta), _ptr(keep),
+                                          float(keep_prob), S, D, int(nhead), _stream()), "lipvq_attention_bwd_f32")
+    return gqkv
+
+
+def add_layernorm(a, b, w, bias, eps: float, save: bool = False):
+    """LayerNorm(a + b) * w + bias over the last dimension (b may be None); save=True also returns (xhat, rstd)."""
+    a = _chk(a, "a")
+    if b is not None:
+        b = _chk(b, "b")
+        if b.shape != a.shape:
+            raise ValueError("add_layernorm: shapes differ")
+    N, E = a.shape
+    y = torch.empty_like(a)
+    xhat = torch.empty_like(a) if save else None
+    rstd = torch.empty(N, device=a.device, dtype=torch.float32) if save else None
+    with _on(a.device):
+        check(lib.lipvq_add_layernorm_f32(_ptr(a), _ptr(b), _ptr(_chk(w, "w")), _ptr(_chk(bias, "bias")), float(eps), _ptr(y),
+                                          _ptr(xhat), _ptr(rstd), N, E, _stream()), "lipvq_add_layernorm_f32")
+    return (y, xhat, rstd) if save else y
+
+
+def layernorm_bwd(gy, xhat, rstd, w):
+    gy, xhat = _chk(gy, "gy"), _chk(xhat, "xhat")
+    N, E = gy.shape
+    gx = torch.empty_like(gy)
+    gw = torch.zeros(E, device=gy.device, dtype=torch.float32)
+    gb = torch.zeros(E, device=gy.device, dtype=torch.float32)
+    with _on(gy.device):
+        check(lib.lipvq_layernorm_bwd_f32(_ptr(gy), _ptr(xhat), _ptr(_chk(rstd, "rstd")), _ptr(_chk(w, "w")), _ptr(gx), _ptr(gw),
+                                          _ptr(gb), N, E, _stream()), "lipvq_layernorm_bwd_f32")
+    return gx, gw, gb

@@ -367,6 +367,77 @@ def run_embed(name, seed, B, T, Din, E, K, mode):
     print(f"{name}: B={B} T={T} Din={Din} E={E} mode={mode}")
 
 
+def _zero_dropout(net):
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, torch.nn.MultiheadAttention):
+            m.dropout = 0.0
+
+
+def run_default_branch(name, seed, A, D, N):
+    """Fixture of the DEFAULT action branch (obs_nets.py:1244-1260).  ICLObservationGroupEncoder cannot be imported here (its
+    module needs torchvision/robosuite/...), so the fixture is produced by the same stock torch MODULES its
+    constructor builds, in its order (oracle.build_default_branch_modules restates those sixteen lines), called as the
+    reference calls them (obs_nets.py:1343-1344: the 2-D [B*T, A] tensor).  Kept: the eval-mode output `y`; from ONE
+    training-mode call with every dropout probability set to 0 (the only way to make a training-mode call reproducible):
+    its output `y_train`, the spectral-norm vectors it leaves behind, and a digest (sum, norm, 16 entries) of every parameter
+    gradient of L = sum(y_train * r).  (Gradients are taken in training mode on purpose: that is where the reference takes
+    them, and torch's EVAL-mode fp32 backward through this stack is off by 3-28 % against float64 on the first encoder
+    layer and everything before it, while its training-mode backward agrees to 5e-7.)  Parameters are re-drawn from the
+    seed by the tests (sha256 stored)."""
+    import hashlib
+    p = O.make_default_branch_params(seed, A, D)
+    rng = np.random.Generator(np.random.PCG64(seed + 7))
+    x = rng.uniform(-1, 1, (N, A)).astype(np.float32)
+    r = rng.standard_normal((N, D)).astype(np.float32)
+    net = O.build_default_branch_modules(A, D)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
+    net.eval()
+    with torch.no_grad():
+        y = net(torch.from_numpy(x))
+    out = {"seed": seed, "A": A, "D": D, "N": N, "x": x, "r": r, "y": y.numpy()}
+    # how far fp32 rounding alone moves this output: the same modules in float64 (the ICRT-width case is sharp: ~2e-4)
+    net64 = O.build_default_branch_modules(A, D).double()
+    net64.load_state_dict({k: torch.from_numpy(v).double() for k, v in p.items()})
+    net64.eval()
+    with torch.no_grad():
+        y64 = net64(torch.from_numpy(x).double())
+    out["fp32_noise"] = np.float64(float((y.double() - y64).abs().max()) / float(y64.abs().max()))
+    y2, _, _ = O.torch_default_branch(p, x)
+    assert float((y2.detach() - y).abs().max()) <= 2e-6 * float(y.abs().max()), "oracle restatement drifted (eval forward)"
+    net2 = O.build_default_branch_modules(A, D)
+    net2.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
+    net2.train()
+    _zero_dropout(net2)
+    yt = net2(torch.from_numpy(x))
+    (yt * torch.from_numpy(r)).sum().backward()
+    out["y_train"] = yt.detach().numpy()
+    y3, uv, P3 = O.torch_default_branch(p, x, training=True)
+    (y3 * torch.from_numpy(r)).sum().backward()
+    assert float((y3.detach() - yt.detach()).abs().max()) <= 2e-6 * float(yt.detach().abs().max()), "oracle restatement drifted (train forward)"
+    for k, t in net2.named_parameters():
+        ga, gb = t.grad.numpy(), P3[k].grad.numpy()
+        assert np.abs(ga - gb).max() <= 1e-5 * max(1e-6, np.abs(ga).max()), (k, np.abs(ga - gb).max(), np.abs(ga).max())
+        out["gdig/" + k] = O.grad_digest(ga)
+    for i in (0, 2, 4):
+        out[f"train_u/{i}"] = getattr(net2[i], "weight_u").detach().numpy().copy()
+        out[f"train_v/{i}"] = getattr(net2[i], "weight_v").detach().numpy().copy()
+        assert np.allclose(out[f"train_u/{i}"], uv[i][0], rtol=0, atol=1e-6) and np.allclose(out[f"train_v/{i}"], uv[i][1], rtol=0, atol=1e-6)
+    h = hashlib.sha256()
+    for k in sorted(p):
+        h.update(np.ascontiguousarray(p[k]).tobytes())
+    out["params_sha256"] = np.array(h.hexdigest())
+    out["meta"] = meta_of(kind="default_branch")
+    np.savez_compressed(GOLD / f"{name}.npz", **out)
+    print(f"{name}: y scale {float(np.abs(out['y']).max()):.3f}, {len(p)} state tensors")
+
+
+def run_default_all():
+    run_default_branch("default_icrt", 801, 12, 208, 80)       # the ICRT step shape (obs_nets.py:2411)
+    run_default_branch("default_a7_d64", 802, 7, 64, 203)      # BASELINE's action width, ragged N, head width 8
+
+
 def run_embed_all():
     run_embed("embed_parameter", 301, 3, 10, 64, 512, 1024, "parameter")      # the reference defaults (icl_config.py:133-160)
     run_embed("embed_embedding", 302, 2, 7, 32, 256, 256, "embedding")
@@ -418,6 +489,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--only-init", action="store_true")
+    ap.add_argument("--only-default", action="store_true", help="only the default action branch fixtures")
     ap.add_argument("--only-edge", action="store_true")
     ap.add_argument("--only-embed", action="store_true")
     ap.add_argument("--only-bin", action="store_true")
@@ -427,6 +499,10 @@ def main():
         GOLD.mkdir(parents=True, exist_ok=True)
         return run_embed_all()
     ref_root = Path(args.ref)
+    if args.only_default:
+        GOLD.mkdir(parents=True, exist_ok=True)
+        torch.set_num_threads(1)
+        return run_default_all()
     if args.only_bin:
         GOLD.mkdir(parents=True, exist_ok=True)
         return run_bin_all(ref_root)
@@ -464,6 +540,7 @@ def main():
     run_nearest_edge(v5, "llfq_nearest_edge")
     run_init(v5, vq)
     run_embed_all()
+    run_default_all()
     run_bin_all(ref_root)
     run_big_all(v5, orc)
 

@@ -649,3 +649,100 @@ def params_digest(p):
 def to_torch(p):
     import torch
     return {k: torch.from_numpy(np.ascontiguousarray(v).copy()) for k, v in p.items()}
+
+
+# ---------------------------------------------------------------------------------------------------
+# The DEFAULT action branch (reference robomimic/models/obs_nets.py:1244-1260): spectral-norm MLP + 4 post-norm
+# nn.TransformerEncoder layers over the unbatched [B*T, D] sequence + Linear.  Test infrastructure only.
+#   make_default_branch_params   seeded parameters (the stock constructors' draws, perturbed so that the four cloned
+#                                layers differ and biases / LayerNorm affine terms are not the trivial 0 / 1)
+#   torch_default_branch         restatement in explicit torch-CPU ops -- power iteration as torch/nn/utils/
+#                                spectral_norm.py writes it, F.linear, per-head softmax attention, F.layer_norm -- with NO
+#                                nn.TransformerEncoder / spectral_norm hook involved (those produce the fixtures:
+#                                oracle/gen_golden.py::run_default_branch)
+# ---------------------------------------------------------------------------------------------------
+DEFAULT_NHEAD, DEFAULT_FF, DEFAULT_LAYERS = 8, 256, 4
+
+
+def build_default_branch_modules(A, D):
+    """The reference's constructor text (obs_nets.py:1245-1260) with stock torch modules."""
+    import warnings
+    import torch  # noqa: F401
+    import torch.nn as nn
+    from torch.nn.utils import spectral_norm
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        layer = nn.TransformerEncoderLayer(d_model=D, nhead=DEFAULT_NHEAD, dim_feedforward=DEFAULT_FF, activation="gelu")
+        return nn.Sequential(
+            spectral_norm(nn.Linear(A, 64)), nn.GELU(),
+            spectral_norm(nn.Linear(64, 128)), nn.GELU(),
+            spectral_norm(nn.Linear(128, D)),
+            nn.TransformerEncoder(layer, num_layers=DEFAULT_LAYERS),
+            nn.Linear(D, D))
+
+
+def make_default_branch_params(seed, A, D):
+    """state_dict (numpy) of the default branch: constructor draws under torch.manual_seed(seed), then every float tensor
+    except the spectral-norm vectors is perturbed by 0.05 * N(0, 1) from a seeded numpy generator."""
+    import torch
+    torch.manual_seed(seed)
+    net = build_default_branch_modules(A, D)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = {}
+    for k, v in net.state_dict().items():
+        a = v.detach().numpy().astype(np.float32).copy()
+        if not (k.endswith("weight_u") or k.endswith("weight_v")):
+            a = (a + 0.05 * rng.standard_normal(a.shape)).astype(np.float32)
+        out[k] = a
+    return out
+
+
+def torch_default_branch(params, x, training=False, eps_sn=1e-12):
+    """(y [N, D] tensor with grad_fn, dict of updated (u, v) per spectral layer, leaf parameter tensors).
+    params: state_dict as numpy; x: numpy [N, A].  Dropout is NOT applied (eval semantics for every dropout; `training`
+    only switches the spectral-norm power iteration, as module.training does in torch's hook)."""
+    import torch
+    import torch.nn.functional as F
+    P = {k: torch.from_numpy(np.ascontiguousarray(v)).clone().requires_grad_(not (k.endswith("_u") or k.endswith("_v")))
+         for k, v in params.items()}
+    uv = {}
+
+    def sn(i):
+        W, u, v = P[f"{i}.weight_orig"], P[f"{i}.weight_u"].detach().clone(), P[f"{i}.weight_v"].detach().clone()
+        if training:                               # spectral_norm.py compute_weight, n_power_iterations = 1
+            with torch.no_grad():
+                v = F.normalize(torch.mv(W.t(), u), dim=0, eps=eps_sn)
+                u = F.normalize(torch.mv(W, v), dim=0, eps=eps_sn)
+        uv[i] = (u.numpy().copy(), v.numpy().copy())
+        sigma = torch.dot(u, torch.mv(W, v))
+        return W / sigma
+
+    h = torch.from_numpy(np.ascontiguousarray(x))
+    h = F.gelu(F.linear(h, sn(0), P["0.bias"]))
+    h = F.gelu(F.linear(h, sn(2), P["2.bias"]))
+    h = F.linear(h, sn(4), P["4.bias"])
+    S, D = h.shape
+    H, dh = DEFAULT_NHEAD, D // DEFAULT_NHEAD
+    for li in range(DEFAULT_LAYERS):
+        pre = f"5.layers.{li}."
+        qkv = F.linear(h, P[pre + "self_attn.in_proj_weight"], P[pre + "self_attn.in_proj_bias"])
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        heads = []
+        for hh in range(H):
+            sl = slice(hh * dh, (hh + 1) * dh)
+            sc = (q[:, sl] / float(np.sqrt(dh))) @ k[:, sl].t()
+            heads.append(torch.softmax(sc, dim=-1) @ v[:, sl])
+        a = F.linear(torch.cat(heads, dim=1), P[pre + "self_attn.out_proj.weight"], P[pre + "self_attn.out_proj.bias"])
+        h = F.layer_norm(h + a, (D,), P[pre + "norm1.weight"], P[pre + "norm1.bias"], 1e-5)
+        f = F.linear(F.gelu(F.linear(h, P[pre + "linear1.weight"], P[pre + "linear1.bias"])), P[pre + "linear2.weight"],
+                     P[pre + "linear2.bias"])
+        h = F.layer_norm(h + f, (D,), P[pre + "norm2.weight"], P[pre + "norm2.bias"], 1e-5)
+    y = F.linear(h, P["6.weight"], P["6.bias"])
+    return y, uv, P
+
+
+def grad_digest(g):
+    """What a fixture keeps of a (possibly large) gradient: sum, L2 norm and 16 entries at fixed strided positions."""
+    a = np.asarray(g, dtype=np.float64).ravel()
+    pos = (np.arange(16) * max(1, a.size // 16)) % a.size
+    return np.concatenate([[a.sum(), np.sqrt((a * a).sum())], a[pos]]).astype(np.float64)
