@@ -123,5 +123,6 @@ def test_action_branch_switches():
     assert isinstance(ICLActionBranch(7, 32, variant="vqvae").action_network, VQVAE)
     b = ICLActionBranch(7, 32, bin_enabled=True)
     assert isinstance(b.action_network, AdaptiveBinActionEmbedding) and not b.vq_vae_enabled     # the reference's elif order
-    with pytest.raises(NotImplementedError):
-        ICLActionBranch(7, 32, vq_vae_enabled=False)
+    from lipvq_vae_amd.default_branch import DefaultActionNetwork
+    d = ICLActionBranch(7, 32, vq_vae_enabled=False)                     # obs_nets.py:1244: the default branch
+    assert isinstance(d.action_network, DefaultActionNetwork) and not d.vq_vae_enabled and not d.bin_enabled
