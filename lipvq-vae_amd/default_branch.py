@@ -154,3 +154,35 @@ class DefaultActionNetwork(nn.Sequential):
             f = F.dropout(f, layer.dropout2.p, self.training)
             h = _AddLayerNormFn.apply(h, f, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
         return _LinearActFn.apply(h, self[6].weight, self[6].bias, ACT_NONE)
+
+
+class GraphedDefaultBranch:
+    """Eval-mode forward of a DefaultActionNetwork captured in ONE HIP graph for a fixed [N, A] shape.
+
+    The branch is ~40 small launches (at the ICRT step shape N = 80 every one of them is microseconds of GPU work), so an
+    eager call is bound by Python + ctypes issue (~1.5 ms); a graph replay costs the GPU time alone.  Rollouts call the
+    action branch once per environment step with the same prompt shape (obs_nets.py:1343-1344 under algo.py:736 set_eval()),
+    which is what this serves.  Parameters are read at replay time through their storage, so in-place updates
+    (optimizer steps, load_state_dict) are seen; re-capture after anything that REPLACES a parameter tensor (.to(), .cuda())."""
+
+    def __init__(self, net: DefaultActionNetwork, example_actions: torch.Tensor):
+        if net.training:
+            raise RuntimeError("GraphedDefaultBranch captures the eval-mode forward: call net.eval() first")
+        self.net = net
+        self._x = example_actions.detach().contiguous().float().clone()
+        side = torch.cuda.Stream(device=self._x.device)
+        side.wait_stream(torch.cuda.current_stream(self._x.device))
+        with torch.no_grad(), torch.cuda.stream(side):            # first-use work (LDS reservations, lazy module state) stays out of the capture
+            for _ in range(3):
+                net(self._x)
+        torch.cuda.current_stream(self._x.device).wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self._graph):
+            self._y = net(self._x)
+
+    def __call__(self, prompt_actions: torch.Tensor) -> torch.Tensor:
+        if prompt_actions.shape != self._x.shape:
+            raise ValueError(f"captured for {tuple(self._x.shape)}, got {tuple(prompt_actions.shape)}")
+        self._x.copy_(prompt_actions)
+        self._graph.replay()
+        return self._y

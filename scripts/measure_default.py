@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 from torch.nn.utils import spectral_norm
 import lipvq_vae_amd  # noqa: F401
-from lipvq_vae_amd.default_branch import DefaultActionNetwork
+from lipvq_vae_amd.default_branch import DefaultActionNetwork, GraphedDefaultBranch
 
 
 def stock(A, D):
@@ -37,10 +37,13 @@ for N, A, D in ((80, 12, 208), (500, 12, 208), (2048, 7, 64)):
     with torch.no_grad():
         d = (ours(x) - ref(x)).abs().max().item() / ref(x).abs().max().item()
         t_o, t_r = timed(lambda: ours(x)), timed(lambda: ref(x))
+        gr = GraphedDefaultBranch(ours, x)
+        dg = (gr(x) - ours(x)).abs().max().item()
+        t_g = timed(lambda: gr(x))
     ours.train(); ref.train()
     def step(m):
         for p in m.parameters(): p.grad = None
         m(x).square().mean().backward()
     s_o, s_r = timed(lambda: step(ours), 20), timed(lambda: step(ref), 20)
-    print(f"N={N} A={A} D={D}: eval forward {t_o:.3f} ms (stock torch {t_r:.3f} ms, max rel diff {d:.1e}); "
+    print(f"N={N} A={A} D={D}: eval forward {t_o:.3f} ms, HIP-graph replay {t_g:.3f} ms (== eager: {dg == 0.0}) (stock torch {t_r:.3f} ms, max rel diff {d:.1e}); "
           f"train forward+backward {s_o:.3f} ms (stock torch {s_r:.3f} ms)")

@@ -163,3 +163,23 @@ def test_training_mode_dropout_and_branch_shim(golden_dir):
         br = ICLActionBranch(7, 64, vq_vae_enabled=False).cuda().eval()
     out = time_distributed(torch.randn(3, 10, 7, device="cuda"), br)
     assert out.shape == (3, 10, 64) and br._vq_vae_loss is None
+
+
+def test_graphed_eval_forward_equals_eager(golden_dir):
+    from lipvq_vae_amd.default_branch import GraphedDefaultBranch
+    g, m = _module(golden_dir, "default_icrt")
+    x = torch.from_numpy(g["x"]).cuda()
+    m.eval()
+    with torch.no_grad():
+        want = m(x).clone()
+    gr = GraphedDefaultBranch(m, x)
+    assert torch.equal(gr(x), want)
+    x2 = x.flip(0).contiguous()
+    with torch.no_grad():
+        want2 = m(x2).clone()
+    assert torch.equal(gr(x2), want2)                       # new inputs through the same graph
+    with torch.no_grad():
+        m[6].bias.add_(1.0)                                 # an in-place parameter update is seen by the next replay
+    assert torch.allclose(gr(x2), want2 + 1.0, rtol=0, atol=1e-5)
+    with pytest.raises(ValueError):
+        gr(x[:10])
