@@ -288,6 +288,16 @@ int lipvq_add_layernorm_f32(const float* a, const float* b, const float* w, cons
 int lipvq_layernorm_bwd_f32(const float* gy, const float* xhat, const float* rstd, const float* w, float* gx, float* gw,
                             float* gb, int64_t N, int E, void* stream);
 
+/* icl.py:885-889, :970  optim.AdamW(vq_vae_model.parameters(), lr=1e-3, weight_decay=1e-4).step() for a LIST of tensors in
+ * two launches (torch's foreach form is 8-10): params / grads / exp_avg / exp_avg_sq / steps are HOST arrays of `count`
+ * DEVICE pointers (count <= 32), numels their element counts; steps[i] is a float32 device scalar (torch's capturable layout),
+ * incremented here.  Standard AdamW (amsgrad off); the hyper-parameters are doubles (derived constants such as 1 - beta2 are
+ * formed in double and rounded to fp32 once, as torch forms them).  workspace: lipvq_adamw_workspace_bytes() device bytes. */
+size_t lipvq_adamw_workspace_bytes(void);
+int lipvq_adamw_f32(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                    float* const* steps, const int64_t* numels, int count, double lr, double beta1, double beta2, double eps,
+                    double weight_decay, void* workspace, void* stream);
+
 /* ---- opt-in extension: EMA codebook update (not in the reference; named by BASELINE.json's north star) ----
  * cluster_size [K] and embed_sum [K][D] are the running statistics (updated in place), counts [K] int64 = this batch's
  * code usage (lipvq_nearest_f32 / lipvq_tokenize_f32 `usage`, summed over ranks), dw [K][D] = sum of the z_e rows mapped

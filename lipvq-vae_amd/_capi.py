@@ -78,6 +78,8 @@ SIGNATURES = {
     "lipvq_attention_bwd_f32": (_i, [_vp] * 7 + [C.c_float, _i64, _i, _i, _vp]),
     "lipvq_add_layernorm_f32": (_i, [_vp] * 4 + [C.c_float] + [_vp] * 3 + [_i64, _i, _vp]),
     "lipvq_layernorm_bwd_f32": (_i, [_vp] * 7 + [_i64, _i, _vp]),
+    "lipvq_adamw_workspace_bytes": (_sz, []),
+    "lipvq_adamw_f32": (_i, [_vp] * 6 + [_i] + [C.c_double] * 5 + [_vp, _vp]),
     "lipvq_ema_update_f32": (_i, [_vp] * 5 + [C.c_float, C.c_float, _i, _i, _vp, _vp]),
     "lipvq_comm_unique_id": (_i, [_vp]),
     "lipvq_comm_init": (_i, [C.POINTER(_vp), _vp, _i, _i]),

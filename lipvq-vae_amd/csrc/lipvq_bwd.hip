@@ -662,37 +662,57 @@ extern "C" int lipvq_scatter_add_f32(const float* g, const int64_t* idx, float* 
     return check_launch("scatter_add");
 }
 
-// Backward of  Wn = W * sc,  sc = min(1, softplus(ci)/sum|W|)   (v5:6-12).  One thread per row.
-__global__ void lipschitz_bwd_kernel(const float* __restrict__ W, const float* __restrict__ ci,
-                                     const float* __restrict__ gWn, float* __restrict__ gW,
-                                     float* __restrict__ gci, int D, int H) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= D) return;
-    const float* w = W + (size_t)i * H;
-    const float* g = gWn + (size_t)i * H;
-    double s = 0.0, gsc = 0.0;
-    float s32 = 0.0f;
-    for (int j = 0; j < H; ++j) {
-        s += fabs((double)w[j]);
-        s32 = s32 + lq_abs(w[j]);
-        gsc += (double)g[j] * (double)w[j];
+// Backward of  Wn = W * sc,  sc = min(1, softplus(ci)/sum|W|)   (v5:6-12).  16 rows per workgroup, staged in LDS (coalesced
+// loads and stores; 16 threads run the per-row sums -- the fp32 one in index order, because it must reproduce the forward
+// kernel's `active` test bit for bit).  One thread per row from global memory took 33 us at D = 208.
+#define LIPB_ROWS 16
+#define LIPB_HMAX 256
+__global__ __launch_bounds__(256) void lipschitz_bwd_kernel(const float* __restrict__ W, const float* __restrict__ ci,
+                                                            const float* __restrict__ gWn, float* __restrict__ gW,
+                                                            float* __restrict__ gci, int D, int H) {
+    __shared__ float ws[LIPB_ROWS][LIPB_HMAX + 1], gs[LIPB_ROWS][LIPB_HMAX + 1];
+    __shared__ double s_sc[LIPB_ROWS], s_k[LIPB_ROWS];
+    const int tid = threadIdx.x, r0 = blockIdx.x * LIPB_ROWS;
+    for (int i = tid; i < LIPB_ROWS * H; i += 256) {
+        const int r = i / H, j = i - r * H;
+        const bool in = r0 + r < D;
+        ws[r][j] = in ? W[(size_t)(r0 + r) * H + j] : 0.0f;
+        gs[r][j] = in ? gWn[(size_t)(r0 + r) * H + j] : 0.0f;
     }
-    const float spf = lq_softplus(ci[i]);
-    const bool active = (spf / s32) < 1.0f;        // the same test the forward kernel makes
-    const double sp = (double)spf;
-    const double sc = active ? sp / s : 1.0;
-    const double k = active ? gsc * (-sp / (s * s)) : 0.0;
-    for (int j = 0; j < H; ++j) {
-        const double wj = (double)w[j];
-        gW[(size_t)i * H + j] = (float)((double)g[j] * sc + k * ((wj > 0) - (wj < 0)));
+    __syncthreads();
+    if (tid < LIPB_ROWS && r0 + tid < D) {
+        double s = 0.0, gsc = 0.0;
+        float s32 = 0.0f;
+        for (int j = 0; j < H; ++j) {
+            const float w = ws[tid][j];
+            s += fabs((double)w);
+            s32 = s32 + lq_abs(w);
+            gsc += (double)gs[tid][j] * (double)w;
+        }
+        const float cv = ci[r0 + tid];
+        const float spf = lq_softplus(cv);
+        const bool active = (spf / s32) < 1.0f;        // the same test the forward kernel makes
+        const double sp = (double)spf;
+        s_sc[tid] = active ? sp / s : 1.0;
+        s_k[tid] = active ? gsc * (-sp / (s * s)) : 0.0;
+        gci[r0 + tid] = active ? (float)(gsc * (double)lq_sigmoid(cv) / s) : 0.0f;
     }
-    gci[i] = active ? (float)(gsc * (double)lq_sigmoid(ci[i]) / s) : 0.0f;
+    __syncthreads();
+    for (int i = tid; i < LIPB_ROWS * H; i += 256) {
+        const int r = i / H, j = i - r * H;
+        if (r0 + r < D) {
+            const double wj = (double)ws[r][j];
+            gW[(size_t)(r0 + r) * H + j] = (float)((double)gs[r][j] * s_sc[r] + s_k[r] * ((wj > 0) - (wj < 0)));
+        }
+    }
 }
 
 extern "C" int lipvq_lipschitz_bwd_f32(const float* W, const float* ci, const float* gWn, float* gW, float* gci,
                                        int D, int H, void* stream) {
     if (!W || !ci || !gWn || !gW || !gci || D <= 0 || H <= 0) return fail(LIPVQ_EINVAL, "lipschitz_bwd: bad argument");
-    hipLaunchKernelGGL(lipschitz_bwd_kernel, dim3((D + 63) / 64), dim3(64), 0, (hipStream_t)stream, W, ci, gWn, gW, gci, D, H);
+    if (H > LIPB_HMAX) return fail(LIPVQ_EUNSUPPORTED, "lipschitz_bwd: H=%d > %d", H, LIPB_HMAX);
+    hipLaunchKernelGGL(lipschitz_bwd_kernel, dim3((D + LIPB_ROWS - 1) / LIPB_ROWS), dim3(256), 0, (hipStream_t)stream, W, ci, gWn, gW,
+                       gci, D, H);
     return check_launch("lipschitz_bwd");
 }
 
@@ -777,4 +797,88 @@ extern "C" int lipvq_ema_update_f32(float* cluster_size, float* embed_sum, const
     hipLaunchKernelGGL(ema_codebook_kernel, dim3((unsigned)g), dim3(256), 0, st, cluster_size, embed_sum, dw, codebook, decay,
                        eps, K, D, (const double*)workspace);
     return check_launch("ema_codebook_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// AdamW for the tokenizer's parameter list in TWO launches (reference robomimic/algo/icl.py:885-889 builds
+// optim.AdamW(vq_vae_model.parameters(), lr=1e-3, weight_decay=1e-4); :970 vq_optimizer.step()).  torch's foreach AdamW
+// is 8-10 launches over the 14 tensors (~80 us of GPU time at the ICRT step shape, as much as the encoder's forward and
+// backward launches together, plus their Python issue cost); one launch per tensor LIST is what a launch-bound step wants.
+// Same update as torch.optim.AdamW (amsgrad = False, maximize = False):
+//     step += 1;  p *= 1 - lr wd;  m += (g - m)(1 - b1);  v = b2 v + (1 - b2) g g;
+//     p -= (lr / (1 - b1^step)) m / (sqrt(v) / sqrt(1 - b2^step) + eps)
+// `step` is a float32 device scalar PER TENSOR (torch's capturable layout: the optimizer state_dict stays interchangeable),
+// so the whole step is capturable in a HIP graph.
+// ---------------------------------------------------------------------------------------------------
+#define LIPVQ_ADAMW_MAX 32
+struct AdamwArgs {
+    float* p[LIPVQ_ADAMW_MAX];
+    const float* g[LIPVQ_ADAMW_MAX];
+    float* m[LIPVQ_ADAMW_MAX];
+    float* v[LIPVQ_ADAMW_MAX];
+    float* step[LIPVQ_ADAMW_MAX];
+    long long n[LIPVQ_ADAMW_MAX];
+    int count;
+};
+
+__global__ void adamw_steps_kernel(AdamwArgs a, double beta1, double beta2, float* __restrict__ bc) {
+    const int t = threadIdx.x;
+    if (t >= a.count) return;
+    const float s = a.step[t][0] + 1.0f;
+    a.step[t][0] = s;
+    // 1 - beta^step in double (torch computes the power in the step tensor's precision on the capturable path; the difference
+    // is far below the 1e-5 the fixtures are held to)
+    bc[2 * t] = (float)(1.0 - pow(beta1, (double)s));
+    bc[2 * t + 1] = (float)sqrt(1.0 - pow(beta2, (double)s));
+}
+
+// the scalar constants are formed in double on the host, as torch forms them in Python, and rounded to fp32 once
+// (1 - 0.999f is not 0.001f: the second moment drifted by 1.3e-5 relative)
+__global__ __launch_bounds__(256) void adamw_kernel(AdamwArgs a, float lr, float decay, float omb1, float beta2, float omb2, float eps,
+                                                    const float* __restrict__ bc) {
+    const int t = blockIdx.y;
+    float* __restrict__ p = a.p[t];
+    const float* __restrict__ g = a.g[t];
+    float* __restrict__ m = a.m[t];
+    float* __restrict__ v = a.v[t];
+    const long long n = a.n[t];
+    const float step_size = lr / bc[2 * t], bc2s = bc[2 * t + 1];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float gi = g[i];
+        float pi = p[i] * decay;
+        const float mi = m[i] + (gi - m[i]) * omb1;
+        const float vi = v[i] * beta2 + omb2 * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        pi = pi - step_size * (mi / (lq_sqrt(vi) / bc2s + eps));
+        p[i] = pi;
+    }
+}
+
+extern "C" size_t lipvq_adamw_workspace_bytes(void) { return 2 * LIPVQ_ADAMW_MAX * sizeof(float); }
+
+extern "C" int lipvq_adamw_f32(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                               float* const* steps, const int64_t* numels, int count, double lr, double beta1, double beta2, double eps,
+                               double weight_decay, void* workspace, void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !steps || !numels || !workspace)
+        return fail(LIPVQ_EINVAL, "adamw: null pointer");
+    if (count <= 0 || count > LIPVQ_ADAMW_MAX) return fail(LIPVQ_EINVAL, "adamw: %d tensors (1..%d per call)", count, LIPVQ_ADAMW_MAX);
+    AdamwArgs a;
+    long long nmax = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i] || !steps[i] || numels[i] <= 0)
+            return fail(LIPVQ_EINVAL, "adamw: tensor %d has a null pointer or no elements", i);
+        a.p[i] = params[i]; a.g[i] = grads[i]; a.m[i] = exp_avg[i]; a.v[i] = exp_avg_sq[i]; a.step[i] = steps[i];
+        a.n[i] = numels[i];
+        if (numels[i] > nmax) nmax = numels[i];
+    }
+    a.count = count;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(adamw_steps_kernel, dim3(1), dim3(64), 0, st, a, beta1, beta2, (float*)workspace);
+    long long gx = (nmax + 1023) / 1024;
+    if (gx > 256) gx = 256;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)gx, count), dim3(256), 0, st, a, (float)lr, (float)(1.0 - lr * weight_decay),
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (const float*)workspace);
+    return check_launch("adamw");
 }

@@ -455,6 +455,53 @@ __global__ __launch_bounds__(256) void nearest_rows_kernel(
   }
 }
 
+// One row per workgroup, 256 code slices: the training-step route (every row of a batch of a few hundred rows is decided
+// exactly, lipvq_nearest_rows_f32).  With 4 rows x 64 slices a thread walked K/64 codes one after the other -- 16 dependent
+// row fetches at K = 1024: 45 us for 80 rows, as long as both MLP launches of the step together; here it walks K/256.
+template <int DCH>
+__global__ __launch_bounds__(256) void nearest_rows1_kernel(const float* __restrict__ z, const float* __restrict__ cb,
+                                                            int64_t* __restrict__ idx, float* __restrict__ zq,
+                                                            unsigned long long* __restrict__ usage, int count, int K) {
+    constexpr int D = DCH * 8;
+    constexpr int SL = 256;
+    __shared__ float s_v[4];
+    __shared__ int s_k[4];
+    const int tid = threadIdx.x;
+    for (int row = blockIdx.x; row < count; row += gridDim.x) {
+        float zr[D];
+        const float4* z4 = reinterpret_cast<const float4*>(z + (size_t)row * D);
+#pragma unroll
+        for (int i = 0; i < D / 4; ++i) {
+            const float4 v = z4[i];
+            zr[4 * i + 0] = v.x; zr[4 * i + 1] = v.y; zr[4 * i + 2] = v.z; zr[4 * i + 3] = v.w;
+        }
+        const int per = (K + SL - 1) / SL;
+        const int kb = tid * per, ke = (kb + per < K) ? kb + per : K;
+        float bv = INFINITY, bs = INFINITY;
+        int bk = kb < K ? kb : K - 1;
+        lq_exact_scan<DCH>(zr, cb, kb, ke, bv, bs, bk);
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float ov = __shfl_xor(bv, off, 64);
+            const int ok = __shfl_xor(bk, off, 64);
+            if (ov < bv || (ov == bv && ok < bk)) { bv = ov; bk = ok; }
+        }
+        if ((tid & 63) == 0) { s_v[tid >> 6] = bv; s_k[tid >> 6] = bk; }
+        __syncthreads();
+        bv = s_v[0]; bk = s_k[0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+            if (s_v[q] < bv || (s_v[q] == bv && s_k[q] < bk)) { bv = s_v[q]; bk = s_k[q]; }
+        if (tid == 0) {
+            idx[row] = (int64_t)bk;
+            if (usage) atomicAdd(&usage[bk], 1ull);
+        }
+        if (zq && tid < D / 4)
+            reinterpret_cast<float4*>(zq + (size_t)row * D)[tid] = reinterpret_cast<const float4*>(cb + (size_t)bk * D)[tid];
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // exact decision for listed rows WITHOUT a stored z_e: the workgroup first recomputes z_e of its 4 rows from x
 // (encoder + Lipschitz layer as plain fp32 fmaf chains in natural k order, bias first, odd fan-in padded with one
@@ -663,6 +710,11 @@ static int launch_screen(const float* z, const unsigned char* prep, const float*
 template <int DCH>
 static int launch_rows_t(const float* z, int z_by_slot, const float* cb, int64_t* idx, float* zq, int64_t* usage,
                          const int* amb_list, const int* amb_count, int64_t N, int K, hipStream_t st) {
+    if (!amb_list && N <= 4096 && K >= 512) {                // every row of a small batch: one row per workgroup
+        hipLaunchKernelGGL((nearest_rows1_kernel<DCH>), dim3((unsigned)N), dim3(256), 0, st, z, cb, idx, zq,
+                           (unsigned long long*)usage, (int)N, K);
+        return check_launch("nearest_rows1");
+    }
     // the count lives on the device: a bounded grid strides over however many rows were listed
     int64_t blocks = (N + 3) / 4;
     if (blocks > 4096) blocks = 4096;

@@ -18,7 +18,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from . import sharded
+from . import optim, sharded
 from .binning import AdaptiveBinActionEmbedding
 from .default_branch import DefaultActionNetwork
 from .tokenizer import LLFQVAE_V4, VQVAE
@@ -60,7 +60,8 @@ def time_distributed(actions: torch.Tensor, op) -> torch.Tensor:
 class VQTokenizerTrainer:
     def __init__(self, vq_vae_model: nn.Module, lr: float = 1e-3, weight_decay: float = 1e-4, group=None):
         self.model = vq_vae_model
-        self.vq_optimizer = torch.optim.AdamW(vq_vae_model.parameters(), lr=lr, weight_decay=weight_decay)
+        # icl.py:885-889; the same AdamW in two launches for the whole parameter list (optim.py) instead of torch's foreach form
+        self.vq_optimizer = optim.AdamW(vq_vae_model.parameters(), lr=lr, weight_decay=weight_decay)
         self.group = group
 
     def train_on_actions(self, prompt_actions: torch.Tensor, n_global: int | None = None):
@@ -103,11 +104,11 @@ class GraphedTokenizerStep:
         self.model = vq_vae_model
         self._fb = forward_backward
         self.static_x = example_actions.detach().clone().contiguous()
-        # foreach AdamW, capturable (~8 launches).  torch's fused=True form is one launch (measured: 0.41 instead of 0.52 ms per
-        # replayed step at N = 80) but on this build its trajectory leaves the eager AdamW's after one step even without a graph
-        # (scripts/dev/debug_fused.py: loss 0.99112 vs 0.98865), so it is not used.
-        self.vq_optimizer = torch.optim.AdamW(vq_vae_model.parameters(), lr=lr, weight_decay=weight_decay, capturable=True)
-        fused = False
+        # AdamW in two launches for the whole parameter list (optim.py: lipvq_adamw_f32; its step counters live on the device,
+        # so it is capturable).  torch's foreach capturable AdamW is ~8 launches (~80 us of the 550 us step), its fused=True form
+        # one launch but on this build its trajectory leaves the eager AdamW's after one step even without a graph
+        # (scripts/dev/debug_fused.py: loss 0.99112 vs 0.98865).
+        self.vq_optimizer = optim.AdamW(vq_vae_model.parameters(), lr=lr, weight_decay=weight_decay)
         if optimizer_state is not None:
             import copy
             # continue an eager run: moments and step count carry over.  Deep copy: Optimizer.load_state_dict keeps the very
@@ -115,10 +116,7 @@ class GraphedTokenizerStep:
             self.vq_optimizer.load_state_dict(copy.deepcopy(optimizer_state))
             for grp in self.vq_optimizer.param_groups:
                 grp["capturable"] = True
-                grp["fused"] = True if fused else grp.get("fused")
-                if fused:
-                    grp["foreach"] = False
-                for prm in grp["params"]:                            # an eager AdamW keeps `step` on the host
+                for prm in grp["params"]:                            # a stock eager AdamW keeps `step` on the host
                     st = self.vq_optimizer.state.get(prm)
                     if st and "step" in st:
                         st["step"] = torch.as_tensor(float(st["step"]), dtype=torch.float32, device=prm.device)

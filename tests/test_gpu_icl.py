@@ -203,3 +203,37 @@ def test_backward_refuses_parameters_changed_since_forward(oracle):
     ze = m.encode(x)
     ref, _, _ = __import__("lipvq_vae_amd").ops.nearest(ze, m.quantizer.codebook.detach())
     assert torch.equal(idx1, ref)
+
+
+def test_fused_adamw_tracks_torch_adamw():
+    """lipvq_vae_amd.optim.AdamW (two launches for the whole list) against torch.optim.AdamW on identical parameters and
+    gradients over 5 steps, and its state_dict loads into the stock optimizer (and back)."""
+    import lipvq_vae_amd  # noqa: F401
+    from lipvq_vae_amd.optim import AdamW
+    g = torch.Generator().manual_seed(5)
+    shapes = [(64, 12), (64,), (208, 128), (1024, 208), (7,), (1,)]
+    pa = [torch.randn(s, generator=g).cuda().requires_grad_(True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    oa = AdamW(pa, lr=1e-3, weight_decay=1e-4)
+    ob = torch.optim.AdamW(pb, lr=1e-3, weight_decay=1e-4)
+    for step in range(5):
+        for a, b in zip(pa, pb):
+            gr = torch.randn(a.shape, generator=g).cuda() * (10.0 ** (step - 2))
+            a.grad, b.grad = gr.clone(), gr.clone()
+        if step == 3:
+            pa[2].grad = None; pb[2].grad = None             # a parameter without a gradient is skipped, its step does not advance
+        oa.step(); ob.step()
+        for a, b in zip(pa, pb):
+            assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max())), step
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert sa["state"].keys() == sb["state"].keys()
+    for k in sa["state"]:
+        assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"])
+        assert torch.allclose(sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"], rtol=1e-5, atol=1e-12)
+    ob.load_state_dict(sa)                                    # interchangeable layouts
+    oa.load_state_dict(ob.state_dict())
+    for a in pa:
+        a.grad = torch.ones_like(a)
+    oa.step()
+    with pytest.raises(ValueError):
+        AdamW(pa, amsgrad=True)
