@@ -20,6 +20,7 @@ static inline int wgrad_chunk_rows(int64_t N) {
         forced = e ? atoi(e) : 0;
     }
     if (forced > 0) return forced;
+    if (N <= 128) return 128;                    // ONE chunk: lipvq_wgrad_f32 then writes the result directly (no reduce launch)
     return N >= 262144 ? 1024 : (N >= 16384 ? 256 : 64);
 }
 
@@ -216,130 +217,7 @@ __global__ __launch_bounds__(64 * WGW_WAVES) void wgrad_wg_kernel(const float* _
     }
 }
 
-// Vectorised workgroup-per-chunk variant (J and Kd multiples of 4, the tokenizer's own layer widths): what ablations of the
-// kernel above showed (N = 524 288, J = 128, Kd = 64: 271 us; 150 us with the global loads replaced by constants, 210 us with
-// the MFMAs removed) is that its 4-byte loads -- twelve 256-byte wave-instructions per wave and 32-row block -- move 1.9 TB/s
-// however far ahead they are issued, and that two barriers per 16 MFMAs per wave are a skeleton of their own.  Here a block is
-// 64 rows, fetched with 16-byte loads (the 512 threads sweep the block's float4s: J/32 + Kd/32 instructions per thread, each
-// wave-instruction 1 KiB of whole rows), staged with 16-byte LDS writes, one block of look-ahead in registers, raw barriers
-// (no vmcnt drain).  Same chunk-ordered, row-ordered accumulation per tile: the same bits as the kernels above.
 #define WG4_ROWS 64
-template <int TPW, int NG, int NH>      // tiles per wave; float4s per thread and block of G / of H
-__global__ __launch_bounds__(64 * WGW_WAVES) void wgrad_wg4_kernel(const float* __restrict__ G, const float* __restrict__ H,
-                                                                   const int64_t* __restrict__ hidx, int h_act,
-                                                                   float* __restrict__ partW, float* __restrict__ partB,
-                                                                   int64_t N, int J, int Kd, int TI, int TJ, int chunk_rows) {
-    extern __shared__ __attribute__((aligned(16))) float wg_lds[];
-    const int Jp = 32 * TI, Kp = 32 * TJ;
-    float* Gs = wg_lds;                        // [64][Jp]
-    float* Hs = Gs + WG4_ROWS * Jp;            // [64][Kp]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, kh = lane >> 5;
-    const int T = TI * TJ;
-    const int J4 = J >> 2, K4 = Kd >> 2, Jp4 = Jp >> 2, Kp4 = Kp >> 2;
-    const int64_t r0 = (int64_t)blockIdx.x * chunk_rows;
-    int64_t r1 = r0 + chunk_rows;
-    if (r1 > N) r1 = N;
-    f32x16 acc[TPW];
-    float bsum[TPW];
-#pragma unroll
-    for (int q = 0; q < TPW; ++q) {
-        bsum[q] = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
-    }
-    // thread's float4 slots of a block: slot u of G is float4 (tid + 512 u) of the [64][Jp4] image (padding columns and rows
-    // past the chunk are staged as zeros), likewise H
-    int grow[NG], gcol[NG], hrow[NH], hcol[NH];
-#pragma unroll
-    for (int u = 0; u < NG; ++u) { const int i = tid + 512 * u; grow[u] = i / Jp4; gcol[u] = i - grow[u] * Jp4; }
-#pragma unroll
-    for (int u = 0; u < NH; ++u) { const int i = tid + 512 * u; hrow[u] = i / Kp4; hcol[u] = i - hrow[u] * Kp4; }
-    float4 gq[NG], hq[NH];
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto fetch = [&](int64_t rb) {             // branch-free: clamped addresses, masked by selects
-#pragma unroll
-        for (int u = 0; u < NG; ++u) {
-            const int64_t row = rb + grow[u];
-            const bool in = grow[u] < WG4_ROWS && row < r1 && gcol[u] < J4;
-            const int64_t rc = row < r1 ? row : r1 - 1;
-            const float4 v = reinterpret_cast<const float4*>(G + (size_t)rc * J)[gcol[u] < J4 ? gcol[u] : J4 - 1];
-            gq[u] = in ? v : zero4;
-        }
-#pragma unroll
-        for (int u = 0; u < NH; ++u) {
-            const int64_t row = rb + hrow[u];
-            const bool in = hrow[u] < WG4_ROWS && row < r1 && hcol[u] < K4;
-            const int64_t rc = row < r1 ? row : r1 - 1;
-            const int64_t hr = hidx ? hidx[rc] : rc;
-            const float4 v = reinterpret_cast<const float4*>(H + (size_t)hr * Kd)[hcol[u] < K4 ? hcol[u] : K4 - 1];
-            hq[u] = in ? v : zero4;
-        }
-    };
-    fetch(r0);
-    const int nblk = (int)((r1 - r0 + WG4_ROWS - 1) / WG4_ROWS);
-    for (int b = 0; b < nblk; ++b) {
-        const int64_t rb = r0 + (int64_t)b * WG4_ROWS;
-        lq_wg_barrier();                                   // the previous block's operands have been consumed
-#pragma unroll
-        for (int u = 0; u < NG; ++u)
-            if (grow[u] < WG4_ROWS) reinterpret_cast<float4*>(Gs)[grow[u] * Jp4 + gcol[u]] = gq[u];
-#pragma unroll
-        for (int u = 0; u < NH; ++u)
-            if (hrow[u] < WG4_ROWS) {
-                float4 v = hq[u];
-                if (h_act != LIPVQ_ACT_NONE && hcol[u] < K4) {          // (padding columns stay zero: act(0) need not be 0)
-                    v.x = lq_act_apply(v.x, h_act); v.y = lq_act_apply(v.y, h_act);
-                    v.z = lq_act_apply(v.z, h_act); v.w = lq_act_apply(v.w, h_act);
-                }
-                // rows past the chunk must contribute nothing even if act(0) != 0
-                if (rb + hrow[u] >= r1) v = zero4;
-                reinterpret_cast<float4*>(Hs)[hrow[u] * Kp4 + hcol[u]] = v;
-            }
-        lq_wg_barrier();
-        fetch(rb + WG4_ROWS);                              // the next block (past the chunk: zeros), in flight under the MFMAs
-#pragma unroll
-        for (int q = 0; q < TPW; ++q) {
-            const int t = wave + q * WGW_WAVES;
-            if (t < T) {                                   // wave-uniform
-                const int ti = t / TJ, tj = t - ti * TJ;
-                const float* ga = Gs + kh * Jp + 32 * ti + li;
-                const float* hb = Hs + kh * Kp + 32 * tj + li;
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    float av[16], bv[16];
-#pragma unroll
-                    for (int s2 = 0; s2 < 16; ++s2) { av[s2] = ga[2 * (16 * half + s2) * Jp]; bv[s2] = hb[2 * (16 * half + s2) * Kp]; }
-#pragma unroll
-                    for (int s2 = 0; s2 < 16; ++s2) {
-                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], bv[s2], acc[q], 0, 0, 0);
-                        bsum[q] += av[s2];
-                    }
-                }
-            }
-        }
-    }
-    float* pw = partW + (size_t)blockIdx.x * J * Kd;
-#pragma unroll
-    for (int q = 0; q < TPW; ++q) {
-        const int t = wave + q * WGW_WAVES;
-        if (t >= T) continue;
-        const int ti = t / TJ, tj = t - ti * TJ;
-        const int fj = 32 * tj + li;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int oi = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (oi < J && fj < Kd) pw[(size_t)oi * Kd + fj] = acc[q][r];
-        }
-        if (tj == 0) {
-            const float tot = bsum[q] + __shfl_xor(bsum[q], 32, 64);
-            const int fi = 32 * ti + li;
-            if (kh == 0 && fi < J) partB[(size_t)blockIdx.x * J + fi] = tot;
-        }
-    }
-}
-
 // Double-buffered variant (TI, TJ in {1, 2, 4}: every layer of the tokenizer at D <= 128).  The ISA of wgrad_wg4_kernel showed
 // why it never left ~250 us at N = 524 288: its look-ahead registers live in arrays captured by a lambda, hipcc keeps them in
 // SCRATCH (scratch_store right behind every global load, scratch_load + vmcnt(0) in front of every LDS write), and the runtime
@@ -368,7 +246,7 @@ __device__ __forceinline__ f32x4 wg5_sel(bool keep, f32x4 v) {        // (a ?: o
     return (f32x4){keep ? v.x : 0.f, keep ? v.y : 0.f, keep ? v.z : 0.f, keep ? v.w : 0.f};
 }
 
-template <int TI, int TJ>
+template <int TI, int TJ, int ROWS>
 __global__ __launch_bounds__(64 * WGW_WAVES) void wgrad_wg5_kernel(const float* __restrict__ G, const float* __restrict__ H,
                                                                    const int64_t* __restrict__ hidx, int h_act,
                                                                    float* __restrict__ partW, float* __restrict__ partB,
@@ -376,7 +254,9 @@ __global__ __launch_bounds__(64 * WGW_WAVES) void wgrad_wg5_kernel(const float* 
     extern __shared__ __attribute__((aligned(16))) float wg_lds[];
     constexpr int Jp = 32 * TI, Kp = 32 * TJ, Jp4 = Jp / 4, Kp4 = Kp / 4;
     constexpr int T = TI * TJ, TPW = (T + WGW_WAVES - 1) / WGW_WAVES;
-    constexpr int BUF = WG4_ROWS * (Jp + Kp);                 // floats per LDS buffer: [64][Jp] of G, then [64][Kp] of act(H)
+    constexpr int BUF = ROWS * (Jp + Kp);                     // floats per LDS buffer: [ROWS][Jp] of G, then [ROWS][Kp] of act(H)
+    constexpr int NG = (ROWS * Jp4 + 511) / 512, NH = (ROWS * Kp4 + 511) / 512;      // float4 slots per thread and block
+    constexpr bool GFULL = (ROWS * Jp4) % 512 == 0, HFULL = (ROWS * Kp4) % 512 == 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, kh = lane >> 5;
@@ -387,20 +267,21 @@ __global__ __launch_bounds__(64 * WGW_WAVES) void wgrad_wg5_kernel(const float* 
     const int64_t r0 = (int64_t)blockIdx.x * chunk_rows;
     int64_t r1 = r0 + chunk_rows;
     if (r1 > N) r1 = N;
-    const int nblk = (int)((r1 - r0 + WG4_ROWS - 1) / WG4_ROWS);
+    const int nblk = (int)((r1 - r0 + ROWS - 1) / ROWS);
 
-    f32x16 acc0, acc1;
+    f32x16 acc[TPW];
+    float bsum[TPW];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
-    float bsum0 = 0.0f, bsum1 = 0.0f;
-
-    // this thread's f32x4 slots of a block (slot u: f32x4 tid + 512 u of the [64][Jp4] / [64][Kp4] image)
-    f32x4 g0, g1, g2, g3, h0, h1, h2, h3;
-    const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    g0 = g1 = g2 = g3 = h0 = h1 = h2 = h3 = z4;
-#define WG5_SLOT(u, P4, row_, col_) const int row_ = (tid + 512 * (u)) / (P4), col_ = (tid + 512 * (u)) % (P4)
-    auto fetchG = [&](int64_t rb, int u) -> f32x4 {                   // clamped address, masked value: no branch
-        WG5_SLOT(u, Jp4, row, col);
+    for (int q = 0; q < TPW; ++q) {
+        bsum[q] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+    }
+    // this thread's float4 slots of a block (slot u: float4 tid + 512 u of the [ROWS][Jp4] / [ROWS][Kp4] image)
+    f32x4 gq[NG], hq[NH];
+    auto fetchG = [&](int64_t rb, int u) -> f32x4 {                    // clamped address, masked value: no branch
+        const int i = tid + 512 * u;
+        const int row = (i / Jp4) < ROWS ? (i / Jp4) : ROWS - 1, col = i % Jp4;
         const int64_t rr = rb + row;
         const int64_t rc = rr < r1 ? rr : r1 - 1;
         if (vecG) {
@@ -417,7 +298,8 @@ __global__ __launch_bounds__(64 * WGW_WAVES) void wgrad_wg5_kernel(const float* 
         return v;
     };
     auto fetchH = [&](int64_t rb, int u) -> f32x4 {
-        WG5_SLOT(u, Kp4, row, col);
+        const int i = tid + 512 * u;
+        const int row = (i / Kp4) < ROWS ? (i / Kp4) : ROWS - 1, col = i % Kp4;
         const int64_t rr = rb + row;
         const int64_t rc = rr < r1 ? rr : r1 - 1;
         const int64_t hr = hidx ? hidx[rc] : rc;
@@ -430,28 +312,35 @@ __global__ __launch_bounds__(64 * WGW_WAVES) void wgrad_wg5_kernel(const float* 
         }
         return v;
     };
-    auto storeG = [&](float* buf, int u, f32x4 v) {
-        WG5_SLOT(u, Jp4, row, col);
-        reinterpret_cast<f32x4*>(buf)[row * Jp4 + col] = v;
+    auto fetch = [&](int64_t rb) {
+#pragma unroll
+        for (int u = 0; u < NG; ++u) gq[u] = fetchG(rb, u);
+#pragma unroll
+        for (int u = 0; u < NH; ++u) hq[u] = fetchH(rb, u);
     };
-    auto storeH = [&](float* buf, int64_t rb, int u, f32x4 v) {          // activation, then the masks (act(0) need not be 0)
-        WG5_SLOT(u, Kp4, row, col);
-        v = wg5_act(v, h_act);
-        const bool in = rb + row < r1;
-        reinterpret_cast<f32x4*>(buf + WG4_ROWS * Jp)[row * Kp4 + col] =
-            (f32x4){(in && 4 * col + 0 < Kd) ? v.x : 0.f, (in && 4 * col + 1 < Kd) ? v.y : 0.f, (in && 4 * col + 2 < Kd) ? v.z : 0.f,
-                    (in && 4 * col + 3 < Kd) ? v.w : 0.f};
+    auto stage = [&](float* buf, int64_t rb) {
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+            const int i = tid + 512 * u;
+            if (GFULL || i < ROWS * Jp4) reinterpret_cast<f32x4*>(buf)[i] = gq[u];          // (i = row * Jp4 + col)
+        }
+#pragma unroll
+        for (int u = 0; u < NH; ++u) {
+            const int i = tid + 512 * u;
+            if (HFULL || i < ROWS * Kp4) {
+                const int row = i / Kp4, col = i % Kp4;
+                const f32x4 v = wg5_act(hq[u], h_act);                 // activation, then the masks (act(0) need not be 0)
+                const bool in = rb + row < r1;
+                reinterpret_cast<f32x4*>(buf + ROWS * Jp)[i] =
+                    (f32x4){(in && 4 * col + 0 < Kd) ? v.x : 0.f, (in && 4 * col + 1 < Kd) ? v.y : 0.f,
+                            (in && 4 * col + 2 < Kd) ? v.z : 0.f, (in && 4 * col + 3 < Kd) ? v.w : 0.f};
+            }
+        }
     };
-#define WG5_FETCH(rb) do { \
-        g0 = fetchG(rb, 0); if (TI > 1) g1 = fetchG(rb, 1); if (TI > 2) { g2 = fetchG(rb, 2); g3 = fetchG(rb, 3); } \
-        h0 = fetchH(rb, 0); if (TJ > 1) h1 = fetchH(rb, 1); if (TJ > 2) { h2 = fetchH(rb, 2); h3 = fetchH(rb, 3); } } while (0)
-#define WG5_STAGE(buf, rb) do { \
-        storeG(buf, 0, g0); if (TI > 1) storeG(buf, 1, g1); if (TI > 2) { storeG(buf, 2, g2); storeG(buf, 3, g3); } \
-        storeH(buf, rb, 0, h0); if (TJ > 1) storeH(buf, rb, 1, h1); if (TJ > 2) { storeH(buf, rb, 2, h2); storeH(buf, rb, 3, h3); } } while (0)
 
-    WG5_FETCH(r0);
-    WG5_STAGE(wg_lds, r0);
-    WG5_FETCH(r0 + WG4_ROWS);                                  // (past the chunk: clamped addresses, staged as zeros)
+    fetch(r0);
+    stage(wg_lds, r0);
+    fetch(r0 + ROWS);                                          // (past the chunk: clamped addresses, staged as zeros)
     lq_wg_barrier();
     for (int b = 0; b < nblk; ++b) {
         const float* cur = wg_lds + (b & 1) * BUF;
@@ -462,33 +351,27 @@ __global__ __launch_bounds__(64 * WGW_WAVES) void wgrad_wg5_kernel(const float* 
             if (t < T) {                                       // wave-uniform
                 const int ti = t / TJ, tj = t % TJ;
                 const float* ga = cur + kh * Jp + 32 * ti + li;
-                const float* hb = cur + WG4_ROWS * Jp + kh * Kp + 32 * tj + li;
-                f32x16 acc = q == 0 ? acc0 : acc1;
-                float bs = q == 0 ? bsum0 : bsum1;
+                const float* hb = cur + ROWS * Jp + kh * Kp + 32 * tj + li;
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
+                for (int part = 0; part < ROWS / 32; ++part) {
                     float av[16], bv[16];
 #pragma unroll
-                    for (int s2 = 0; s2 < 16; ++s2) { av[s2] = ga[2 * (16 * half + s2) * Jp]; bv[s2] = hb[2 * (16 * half + s2) * Kp]; }
+                    for (int s2 = 0; s2 < 16; ++s2) { av[s2] = ga[2 * (16 * part + s2) * Jp]; bv[s2] = hb[2 * (16 * part + s2) * Kp]; }
 #pragma unroll
                     for (int s2 = 0; s2 < 16; ++s2) {
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], bv[s2], acc, 0, 0, 0);
-                        bs += av[s2];
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], bv[s2], acc[q], 0, 0, 0);
+                        bsum[q] += av[s2];
                     }
                 }
-                if (q == 0) { acc0 = acc; bsum0 = bs; } else { acc1 = acc; bsum1 = bs; }
             }
         }
         // block b+1 (in registers since the previous iteration) -> the other buffer, whose last readers passed the barrier
         // that ended iteration b-1; then the loads of block b+2
-        const int64_t rb1 = r0 + (int64_t)(b + 1) * WG4_ROWS;
-        WG5_STAGE(nxt, rb1);
-        WG5_FETCH(rb1 + WG4_ROWS);
+        const int64_t rb1 = r0 + (int64_t)(b + 1) * ROWS;
+        stage(nxt, rb1);
+        fetch(rb1 + ROWS);
         lq_wg_barrier();
     }
-#undef WG5_FETCH
-#undef WG5_STAGE
-#undef WG5_SLOT
     float* pw = partW + (size_t)blockIdx.x * J * Kd;
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
@@ -496,15 +379,13 @@ __global__ __launch_bounds__(64 * WGW_WAVES) void wgrad_wg5_kernel(const float* 
         if (t >= T) continue;
         const int ti = t / TJ, tj = t % TJ;
         const int fj = 32 * tj + li;
-        const f32x16 acc = q == 0 ? acc0 : acc1;
-        const float bs = q == 0 ? bsum0 : bsum1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int oi = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (oi < J && fj < Kd) pw[(size_t)oi * Kd + fj] = acc[r];
+            if (oi < J && fj < Kd) pw[(size_t)oi * Kd + fj] = acc[q][r];
         }
         if (tj == 0) {
-            const float tot = bs + __shfl_xor(bs, 32, 64);
+            const float tot = bsum[q] + __shfl_xor(bsum[q], 32, 64);
             const int fi = 32 * ti + li;
             if (kh == 0 && fi < J) partB[(size_t)blockIdx.x * J + fi] = tot;
         }
@@ -556,34 +437,28 @@ extern "C" int lipvq_wgrad_f32(const float* G, const float* H, const int64_t* hi
     const size_t lds = (size_t)32 * 32 * (TI + TJ) * sizeof(float);
     static int use_wg = -1;                     // LIPVQ_WGRAD_PER_TILE=1 forces the one-wave-per-tile kernel (measurement knob)
     if (use_wg < 0) use_wg = getenv("LIPVQ_WGRAD_PER_TILE") ? 0 : 1;
-    const size_t lds4 = (size_t)WG4_ROWS * 32 * (TI + TJ) * sizeof(float);
-    const int ng = (WG4_ROWS * 8 * TI + 511) / 512, nh = (WG4_ROWS * 8 * TJ + 511) / 512;      // float4s per thread and block
     static int use_wg5 = -1;                    // LIPVQ_WGRAD_NO_WG5=1: the single-buffered kernels (measurement knob)
     if (use_wg5 < 0) use_wg5 = getenv("LIPVQ_WGRAD_NO_WG5") ? 0 : 1;
-    const bool pow2 = (TI == 1 || TI == 2 || TI == 4) && (TJ == 1 || TJ == 2 || TJ == 4);
-    if (use_wg && use_wg5 && pow2 && ((J & 3) == 0 || TI == 1) && ((Kd & 3) == 0 || TJ == 1) && (((uintptr_t)G | (uintptr_t)H) & 15) == 0) {
+    // one chunk (training-step batches of <= 128 rows): the kernel's slab IS the result, no reduce launch
+    const bool direct = nch == 1;
+    if (direct) { partW = gW; if (gb) partB = gb; }
+    auto tcode = [](int t) { return t == 1 ? 0 : t == 2 ? 1 : t == 4 ? 2 : t == 7 ? 3 : -1; };     // tile counts with an instance: 32, 64, 128, 208+ wide
+    const int ci = tcode(TI), cj = tcode(TJ);
+    if (use_wg && use_wg5 && ci >= 0 && cj >= 0 && ((J & 3) == 0 || TI == 1) && ((Kd & 3) == 0 || TJ == 1) &&
+        (((uintptr_t)G | (uintptr_t)H) & 15) == 0) {
         typedef void (*wg5_fn)(const float*, const float*, const int64_t*, int, float*, float*, int64_t, int, int, int);
         wg5_fn kfn = nullptr;
-#define LQ_W5(TI_, TJ_) if (TI == TI_ && TJ == TJ_) kfn = (wg5_fn)wgrad_wg5_kernel<TI_, TJ_>;
-        LQ_W5(1, 1) LQ_W5(1, 2) LQ_W5(1, 4) LQ_W5(2, 1) LQ_W5(2, 2) LQ_W5(2, 4) LQ_W5(4, 1) LQ_W5(4, 2) LQ_W5(4, 4)
+        // 64-row blocks while two buffers fit LDS (TI + TJ <= 10), 32-row blocks for the 208-wide pairs
+#define LQ_W5(TI_, TJ_) if (TI == TI_ && TJ == TJ_) kfn = (wg5_fn)wgrad_wg5_kernel<TI_, TJ_, (TI_ + TJ_ <= 10 ? 64 : 32)>;
+        LQ_W5(1, 1) LQ_W5(1, 2) LQ_W5(1, 4) LQ_W5(1, 7) LQ_W5(2, 1) LQ_W5(2, 2) LQ_W5(2, 4) LQ_W5(2, 7)
+        LQ_W5(4, 1) LQ_W5(4, 2) LQ_W5(4, 4) LQ_W5(4, 7) LQ_W5(7, 1) LQ_W5(7, 2) LQ_W5(7, 4) LQ_W5(7, 7)
 #undef LQ_W5
-        const size_t lds5 = (size_t)2 * WG4_ROWS * 32 * (TI + TJ) * sizeof(float);
-        static LqLdsReserve reserved5[9];           // per instantiation: per-device, thread-safe (lipvq_common.h)
-        const int inst = (TI == 1 ? 0 : TI == 2 ? 1 : 2) * 3 + (TJ == 1 ? 0 : TJ == 2 ? 1 : 2);
+        const int rows5 = TI + TJ <= 10 ? 64 : 32;
+        const size_t lds5 = (size_t)2 * rows5 * 32 * (TI + TJ) * sizeof(float);
+        static LqLdsReserve reserved5[16];          // per instantiation: per-device, thread-safe (lipvq_common.h)
         if (lds5 > 64 * 1024)
-            if (int rc = lipvq_reserve_lds(reserved5[inst], (const void*)kfn, lds5, "wgrad")) return rc;
+            if (int rc = lipvq_reserve_lds(reserved5[ci * 4 + cj], (const void*)kfn, lds5, "wgrad")) return rc;
         hipLaunchKernelGGL(kfn, dim3(nch), dim3(64 * WGW_WAVES), lds5, st, G, H, hidx, h_act, partW, partB, N, J, Kd,
-                           wgrad_chunk_rows(N));
-    } else if (use_wg && (J & 3) == 0 && (Kd & 3) == 0 && TI * TJ <= WGW_WAVES * 2 && ng <= 4 && nh <= 4 && lds4 <= 64 * 1024 &&
-        (((uintptr_t)G | (uintptr_t)H) & 15) == 0) {
-        const int tpw = (TI * TJ + WGW_WAVES - 1) / WGW_WAVES;
-        typedef void (*wg_fn)(const float*, const float*, const int64_t*, int, float*, float*, int64_t, int, int, int, int, int);
-        wg_fn kfn = nullptr;
-#define LQ_W4(NG_, NH_) if (ng == NG_ && nh == NH_) kfn = tpw <= 1 ? (wg_fn)wgrad_wg4_kernel<1, NG_, NH_> : (wg_fn)wgrad_wg4_kernel<2, NG_, NH_>;
-        LQ_W4(1, 1) LQ_W4(1, 2) LQ_W4(2, 1) LQ_W4(2, 2) LQ_W4(1, 4) LQ_W4(4, 1) LQ_W4(2, 4) LQ_W4(4, 2) LQ_W4(4, 4)
-        LQ_W4(1, 3) LQ_W4(3, 1) LQ_W4(2, 3) LQ_W4(3, 2) LQ_W4(3, 3) LQ_W4(3, 4) LQ_W4(4, 3)
-#undef LQ_W4
-        hipLaunchKernelGGL(kfn, dim3(nch), dim3(64 * WGW_WAVES), lds4, st, G, H, hidx, h_act, partW, partB, N, J, Kd, TI, TJ,
                            wgrad_chunk_rows(N));
     } else if (use_wg && TI * TJ <= WGW_WAVES * WGW_MAXT && TI <= 8 && TJ <= 8 && lds <= 64 * 1024) {
         const int wide = 32 * (TI > TJ ? TI : TJ);
@@ -599,6 +474,7 @@ extern "C" int lipvq_wgrad_f32(const float* G, const float* H, const int64_t* hi
         hipLaunchKernelGGL(wgrad_kernel, dim3(nch, TI * TJ), dim3(64), 0, st, G, H, hidx, h_act, partW, partB, N, J, Kd, TJ,
                            wgrad_chunk_rows(N));
     }
+    if (direct) return check_launch("wgrad");
     const size_t ne = (size_t)J * Kd, nb = gb ? (size_t)J : 0;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((ne + nb + 31) / 32)), dim3(256), 0, st, partW, partB, gW, gb, nch, ne,
                        nb);
