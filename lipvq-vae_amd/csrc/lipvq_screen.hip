@@ -32,19 +32,33 @@ extern "C" size_t lipvq_nearest_prep_bytes(int K, int D) {
     return prep_layout(K, D).total;
 }
 
-// column means: 64 columns x 4 row groups per workgroup, double accumulation in a fixed order (deterministic)
-__global__ __launch_bounds__(256) void prep_mean_kernel(const float* __restrict__ cb, float* __restrict__ mu,
-                                                        unsigned* __restrict__ hdr, int K, int D, int Dpad) {
-    __shared__ double part[4][64];
+// column means: 64 columns x 16 row groups per workgroup, double accumulation in a fixed order (deterministic).  (With 4 row
+// groups a thread walked K/4 strided rows one after the other: 103 us at K = 1024 -- a quarter of a screen launch, paid by every
+// training step at large batches and by the first tokenize call after each codebook update.)
+#define PREP_MEAN_GROUPS 16
+__global__ __launch_bounds__(64 * PREP_MEAN_GROUPS) void prep_mean_kernel(const float* __restrict__ cb, float* __restrict__ mu,
+                                                                          unsigned* __restrict__ hdr, int K, int D, int Dpad) {
+    __shared__ double part[PREP_MEAN_GROUPS][64];
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int d = blockIdx.x * 64 + c;
-    double s = 0.0;
-    if (d < D)
-        for (int k = g; k < K; k += 4) s += (double)cb[(size_t)k * D + d];
-    part[g][c] = s;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;              // four independent chains: four loads in flight per thread
+    if (d < D) {
+        int k = g;
+        for (; k + 3 * PREP_MEAN_GROUPS < K; k += 4 * PREP_MEAN_GROUPS) {
+            s0 += (double)cb[(size_t)k * D + d];
+            s1 += (double)cb[(size_t)(k + PREP_MEAN_GROUPS) * D + d];
+            s2 += (double)cb[(size_t)(k + 2 * PREP_MEAN_GROUPS) * D + d];
+            s3 += (double)cb[(size_t)(k + 3 * PREP_MEAN_GROUPS) * D + d];
+        }
+        for (; k < K; k += PREP_MEAN_GROUPS) s0 += (double)cb[(size_t)k * D + d];
+    }
+    part[g][c] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (g == 0 && d < Dpad) {
-        const float m = (d < D) ? (float)((((part[0][c] + part[1][c]) + part[2][c]) + part[3][c]) / (double)K) : 0.0f;
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < PREP_MEAN_GROUPS; ++q) t += part[q][c];
+        const float m = (d < D) ? (float)(t / (double)K) : 0.0f;
         mu[d] = m;
         atomicMax(&hdr[4], __float_as_uint(fabsf(m)));          // max |mu|: the fused kernel's launch-wide scale (lipvq_fused.hip)
     }
@@ -110,7 +124,7 @@ extern "C" int lipvq_nearest_prepare_f32(const float* codebook, void* prep, int 
     hipError_t e = hipMemsetAsync(base, 0, 64, st);
     if (e != hipSuccess) return fail(LIPVQ_EHIP, "nearest_prepare: %s", hipGetErrorString(e));
     float* mu = (float*)(base + L.o_mu);
-    hipLaunchKernelGGL(prep_mean_kernel, dim3((L.Dpad + 63) / 64), dim3(256), 0, st, codebook, mu, (unsigned*)base, K, D, L.Dpad);
+    hipLaunchKernelGGL(prep_mean_kernel, dim3((L.Dpad + 63) / 64), dim3(64 * PREP_MEAN_GROUPS), 0, st, codebook, mu, (unsigned*)base, K, D, L.Dpad);
     hipLaunchKernelGGL(prep_e2_kernel, dim3((L.ntiles * 32 + 255) / 256), dim3(256), 0, st, codebook, mu, base + L.o_tiles,
                        (unsigned*)base, K, D, L);
     hipLaunchKernelGGL(prep_scale_kernel, dim3(1), dim3(1), 0, st, (unsigned*)base);
