@@ -311,6 +311,10 @@ __global__ __launch_bounds__(64 * MLPS_WAVES) void mlp3_wg_kernel(Mlp3Args a) {
     const int64_t row = row0 + n;
     const bool valid = row < a.N;
     const int64_t rowc = valid ? row : a.N - 1;
+    // 16-byte accesses to the saved pre-activations / gradients where base and row stride allow (lq_tile_store16)
+    auto al16 = [](const void* p, int ld) { return p && ((((uintptr_t)p) & 15) == 0) && (ld & 3) == 0; };
+    const bool vec0 = al16(a.out0, a.J0), vec1 = al16(a.out1, a.J1), vec2o = al16(a.out2, a.J2), vec2y = al16(a.y, a.J2);
+    const bool vec0m = BWD && al16(a.mul0, a.J0), vec1m = BWD && al16(a.mul1, a.J1);
 
     // ---- stage the input tile, transposed; backward: fold act2'(pre2) in and save g2 ----
     for (int f = tid; f < 32 * K0p; f += 64 * MLPS_WAVES) {
@@ -337,20 +341,18 @@ __global__ __launch_bounds__(64 * MLPS_WAVES) void mlp3_wg_kernel(Mlp3Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = B0[32 * t + 2 * r + h];
         mlps_chain(P0 + (size_t)t * L.S0 * 64 + lane, L.S0, xT + h * MLPS_LD + n, acc);
+        if (!BWD) {
+            if (a.out0) lq_tile_store16(a.out0, a.J0, row, valid, t, h, acc, a.J0, vec0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int f = 32 * t + 2 * r + h;
-            float v = acc[r];
-            if (!BWD) {
-                if (a.out0 && valid) a.out0[(size_t)row * a.J0 + f] = v;
-                v = lq_act_apply(v, a.act0);
-            } else {
-                const size_t o = (size_t)rowc * a.J0 + f;
-                v = v * lq_act_grad(a.mul0[o], a.act0);
-                if (valid) a.out0[o] = v;
-            }
-            h0T[f * MLPS_LD + n] = v;
+            for (int r = 0; r < 16; ++r) acc[r] = lq_act_apply(acc[r], a.act0);
+        } else {
+            const f32x16 m = lq_tile_load16(a.mul0, a.J0, rowc, t, h, a.J0, vec0m);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = acc[r] * lq_act_grad(m[r], a.act0);
+            lq_tile_store16(a.out0, a.J0, row, valid, t, h, acc, a.J0, vec0);
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h0T[(32 * t + 2 * r + h) * MLPS_LD + n] = acc[r];
     }
     __syncthreads();
 
@@ -360,20 +362,18 @@ __global__ __launch_bounds__(64 * MLPS_WAVES) void mlp3_wg_kernel(Mlp3Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = B1[32 * t + 2 * r + h];
         mlps_chain(P1 + (size_t)t * L.S1 * 64 + lane, L.S1, h0T + h * MLPS_LD + n, acc);
+        if (!BWD) {
+            if (a.out1) lq_tile_store16(a.out1, a.J1, row, valid, t, h, acc, a.J1, vec1);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int f = 32 * t + 2 * r + h;
-            float v = acc[r];
-            if (!BWD) {
-                if (a.out1 && valid) a.out1[(size_t)row * a.J1 + f] = v;
-                v = lq_act_apply(v, a.act1);
-            } else {
-                const size_t o = (size_t)rowc * a.J1 + f;
-                v = v * lq_act_grad(a.mul1[o], a.act1);
-                if (valid) a.out1[o] = v;
-            }
-            h1T[f * MLPS_LD + n] = v;
+            for (int r = 0; r < 16; ++r) acc[r] = lq_act_apply(acc[r], a.act1);
+        } else {
+            const f32x16 m = lq_tile_load16(a.mul1, a.J1, rowc, t, h, a.J1, vec1m);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = acc[r] * lq_act_grad(m[r], a.act1);
+            lq_tile_store16(a.out1, a.J1, row, valid, t, h, acc, a.J1, vec1);
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h1T[(32 * t + 2 * r + h) * MLPS_LD + n] = acc[r];
     }
     if (BWD && !a.y) return;         // the caller does not need d/d(input)
     __syncthreads();
@@ -384,16 +384,12 @@ __global__ __launch_bounds__(64 * MLPS_WAVES) void mlp3_wg_kernel(Mlp3Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = B2[32 * t + 2 * r + h];
         mlps_chain(P2 + (size_t)t * L.S2 * 64 + lane, L.S2, h1T + h * MLPS_LD + n, acc);
-        if (valid) {
+        if (!BWD && a.out2) lq_tile_store16(a.out2, a.J2, row, valid, t, h, acc, a.J2, vec2o);
+        if (!BWD) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int f = 32 * t + 2 * r + h;
-                if (f < a.J2) {
-                    if (!BWD && a.out2) a.out2[(size_t)row * a.J2 + f] = acc[r];
-                    a.y[(size_t)row * a.J2 + f] = BWD ? acc[r] : lq_act_apply(acc[r], a.act2);
-                }
-            }
+            for (int r = 0; r < 16; ++r) acc[r] = lq_act_apply(acc[r], a.act2);
         }
+        lq_tile_store16(a.y, a.J2, row, valid, t, h, acc, a.J2, vec2y);
     }
 }
 

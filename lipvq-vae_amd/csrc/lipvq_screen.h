@@ -71,7 +71,10 @@ struct ScreenCfg {
 // PACK bookkeeping (tile index in the low mantissa bits, lq_track_one) where the bookkeeping is the bottleneck: few MFMAs per
 // tile (S <= 4: 12 or fewer MFMAs against 80 bookkeeping instructions); wider latents hide it under 24+ MFMAs
 #ifndef LQ_PACK_FOR
-#define LQ_PACK_FOR(S) ((S) <= 4)
+#ifndef LQ_PACK_MAX_S
+#define LQ_PACK_MAX_S 4
+#endif
+#define LQ_PACK_FOR(S) ((S) <= LQ_PACK_MAX_S)
 #endif
 // the stand-alone screen kernel: at most 80 KiB of stage ring, so that two workgroups share a CU
 template <int S>
