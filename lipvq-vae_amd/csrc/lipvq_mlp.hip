@@ -291,14 +291,15 @@ __device__ __forceinline__ void mlps_chain(const float* __restrict__ Pt, int S, 
     }
 }
 
-template <bool BWD>
+// NSUB 32-row sub-tiles per workgroup: a "unit" of a layer is (output tile t, sub-tile), units are dealt to the 8 waves.  With one
+// sub-tile the reference's widths keep 2 (layer 0), 4 (layer 1) and 2 (layer 2) of the 8 waves busy and pay three workgroup
+// barriers per 32 rows; with two, 4 / 8 / 4 waves work and the barriers are shared by 64 rows.
+template <bool BWD, int NSUB>
 __global__ __launch_bounds__(64 * MLPS_WAVES) void mlp3_wg_kernel(Mlp3Args a) {
     extern __shared__ float mlps_lds[];
     const PackedLayout L = packed_layout(a.K0, a.J0, a.J1, a.J2);
     const int K0p = 2 * L.S0;
-    float* xT = mlps_lds;                        // [K0p][33]
-    float* h0T = xT + (size_t)K0p * MLPS_LD;     // [J0][33]
-    float* h1T = h0T + (size_t)a.J0 * MLPS_LD;   // [J1][33]
+    const size_t plane = ((size_t)K0p + a.J0 + a.J1) * MLPS_LD;      // floats per sub-tile: xT [K0p][33], h0T [J0][33], h1T [J1][33]
     const float* __restrict__ P0 = a.packed + L.oP0;
     const float* __restrict__ B0 = a.packed + L.oB0;
     const float* __restrict__ P1 = a.packed + L.oP1;
@@ -307,19 +308,16 @@ __global__ __launch_bounds__(64 * MLPS_WAVES) void mlp3_wg_kernel(Mlp3Args a) {
     const float* __restrict__ B2 = a.packed + L.oB2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, h = lane >> 5;
-    const int64_t row0 = (int64_t)blockIdx.x * 32;
-    const int64_t row = row0 + n;
-    const bool valid = row < a.N;
-    const int64_t rowc = valid ? row : a.N - 1;
+    const int64_t wg_row0 = (int64_t)blockIdx.x * (32 * NSUB);
     // 16-byte accesses to the saved pre-activations / gradients where base and row stride allow (lq_tile_store16)
     auto al16 = [](const void* p, int ld) { return p && ((((uintptr_t)p) & 15) == 0) && (ld & 3) == 0; };
     const bool vec0 = al16(a.out0, a.J0), vec1 = al16(a.out1, a.J1), vec2o = al16(a.out2, a.J2), vec2y = al16(a.y, a.J2);
     const bool vec0m = BWD && al16(a.mul0, a.J0), vec1m = BWD && al16(a.mul1, a.J1);
 
-    // ---- stage the input tile, transposed; backward: fold act2'(pre2) in and save g2 ----
-    for (int f = tid; f < 32 * K0p; f += 64 * MLPS_WAVES) {
-        const int r = f / K0p, k = f - r * K0p;
-        const int64_t rw = row0 + r;
+    // ---- stage the input rows, transposed; backward: fold act2'(pre2) in and save g2 ----
+    for (int f = tid; f < 32 * NSUB * K0p; f += 64 * MLPS_WAVES) {
+        const int r = f / K0p, k = f - r * K0p;                  // r: row of the workgroup's 32 NSUB
+        const int64_t rw = wg_row0 + r;
         const bool ok = rw < a.N;
         const int64_t rc = ok ? rw : a.N - 1;
         float v = 0.0f;
@@ -331,12 +329,18 @@ __global__ __launch_bounds__(64 * MLPS_WAVES) void mlp3_wg_kernel(Mlp3Args a) {
                 if (a.out2 && ok) a.out2[(size_t)rw * a.K0 + k] = v;
             }
         }
-        xT[k * MLPS_LD + r] = v;
+        mlps_lds[(size_t)(r >> 5) * plane + (size_t)k * MLPS_LD + (r & 31)] = v;
     }
     __syncthreads();
 
     // ---- layer 0 ----
-    for (int t = wave; t < L.T0; t += MLPS_WAVES) {
+    for (int u = wave; u < L.T0 * NSUB; u += MLPS_WAVES) {
+        const int t = u / NSUB, sub = u - t * NSUB;
+        float* xT = mlps_lds + (size_t)sub * plane;
+        float* h0T = xT + (size_t)K0p * MLPS_LD;
+        const int64_t row = wg_row0 + 32 * sub + n;
+        const bool valid = row < a.N;
+        const int64_t rowc = valid ? row : a.N - 1;
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = B0[32 * t + 2 * r + h];
@@ -357,7 +361,13 @@ __global__ __launch_bounds__(64 * MLPS_WAVES) void mlp3_wg_kernel(Mlp3Args a) {
     __syncthreads();
 
     // ---- layer 1 ----
-    for (int t = wave; t < L.T1; t += MLPS_WAVES) {
+    for (int u = wave; u < L.T1 * NSUB; u += MLPS_WAVES) {
+        const int t = u / NSUB, sub = u - t * NSUB;
+        float* h0T = mlps_lds + (size_t)sub * plane + (size_t)K0p * MLPS_LD;
+        float* h1T = h0T + (size_t)a.J0 * MLPS_LD;
+        const int64_t row = wg_row0 + 32 * sub + n;
+        const bool valid = row < a.N;
+        const int64_t rowc = valid ? row : a.N - 1;
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = B1[32 * t + 2 * r + h];
@@ -379,7 +389,11 @@ __global__ __launch_bounds__(64 * MLPS_WAVES) void mlp3_wg_kernel(Mlp3Args a) {
     __syncthreads();
 
     // ---- layer 2 ----
-    for (int t = wave; t < L.T2; t += MLPS_WAVES) {
+    for (int u = wave; u < L.T2 * NSUB; u += MLPS_WAVES) {
+        const int t = u / NSUB, sub = u - t * NSUB;
+        float* h1T = mlps_lds + (size_t)sub * plane + ((size_t)K0p + a.J0) * MLPS_LD;
+        const int64_t row = wg_row0 + 32 * sub + n;
+        const bool valid = row < a.N;
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = B2[32 * t + 2 * r + h];
@@ -392,9 +406,7 @@ __global__ __launch_bounds__(64 * MLPS_WAVES) void mlp3_wg_kernel(Mlp3Args a) {
         lq_tile_store16(a.y, a.J2, row, valid, t, h, acc, a.J2, vec2y);
     }
 }
-
 typedef void (*mlp3_fn)(Mlp3Args);
-
 template <bool BWD>
 static mlp3_fn mlp3_select(int T0, int T1) {
 #define LQ_CASE(a_, b_) if (T0 == a_ && T1 == b_) return mlp3_kernel<a_, b_, BWD>;
@@ -418,13 +430,23 @@ static int64_t mlp3_small_tiles() {
 template <bool BWD>
 static int launch_mlp3_wg(const Mlp3Args& a, hipStream_t st, const char* what, bool* done) {
     *done = false;
-    const int64_t ntiles = (a.N + 31) / 32;
-    const size_t lds = ((size_t)2 * ((a.K0 + 1) / 2) + a.J0 + a.J1) * MLPS_LD * sizeof(float);
-    if (ntiles > mlp3_small_tiles() || lds > 150 * 1024) return LIPVQ_OK;
-    static LqLdsReserve reserved;               // per-device, thread-safe (lipvq_common.h)
-    if (int rc = lipvq_reserve_lds(reserved, (const void*)mlp3_wg_kernel<BWD>, 150 * 1024, what)) return rc;
+    const size_t plane = ((size_t)2 * ((a.K0 + 1) / 2) + a.J0 + a.J1) * MLPS_LD * sizeof(float);
+    // two 32-row sub-tiles per workgroup from 4 096 rows on (more waves busy per layer, barriers shared by 64 rows); training-step
+    // batches keep one, so that N = 80 still spreads over three workgroups.  LIPVQ_MLP3_SUB=1|2: measurement knob.
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("LIPVQ_MLP3_SUB"); forced = e ? atoi(e) : 0; }
+    // (two only while two such workgroups still share a CU's LDS: the 208-wide decoder input is faster with one; four is slower
+    // everywhere: 3.75 -> 4.25 ms for the cfg2 training step)
+    int nsub = (forced == 1 || forced == 2 || forced == 4) ? forced : ((a.N >= 4096 && 2 * plane <= 80 * 1024) ? 2 : 1);
+    while (nsub > 1 && plane * nsub > 150 * 1024) nsub >>= 1;
+    const int64_t ntiles = (a.N + 32 * nsub - 1) / (32 * nsub);
+    const size_t lds = plane * nsub;
+    if ((a.N + 31) / 32 > mlp3_small_tiles() || lds > 150 * 1024) return LIPVQ_OK;
+    static LqLdsReserve reserved[3];            // per instantiation: per-device, thread-safe (lipvq_common.h)
+    auto kfn = nsub == 4 ? mlp3_wg_kernel<BWD, 4> : nsub == 2 ? mlp3_wg_kernel<BWD, 2> : mlp3_wg_kernel<BWD, 1>;
+    if (int rc = lipvq_reserve_lds(reserved[nsub == 4 ? 2 : nsub - 1], (const void*)kfn, 150 * 1024, what)) return rc;
     if (ntiles > 0x7fffffffLL) return LIPVQ_OK;
-    hipLaunchKernelGGL(mlp3_wg_kernel<BWD>, dim3((unsigned)ntiles), dim3(64 * MLPS_WAVES), lds, st, a);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)ntiles), dim3(64 * MLPS_WAVES), lds, st, a);
     *done = true;
     return check_launch(what);
 }
