@@ -129,6 +129,13 @@ size_t lipvq_tokenize_workspace_bytes(int64_t N, int D);
 int lipvq_tokenize_f32(const float* x, const float* packed, const float* const* raw6, const float* codebook,
                        const void* prep, int64_t* idx, float* zq, int64_t* usage, float* ze_out, void* workspace,
                        int64_t N, int A, int J0, int J1, int D, int K, void* stream);
+/* The forward half of a training step in the same launch: lipvq_tokenize_f32 that also stores what autograd saves for
+ * the backward of v5:71-74 -- z_e [N][D] and the pre-activations pre0 [N][J0], pre1 [N][J1], pre2 [N][D] (all required,
+ * 16-byte aligned), bit-identical to lipvq_mlp3_f32(x, .., pre0, pre1, pre2). */
+int lipvq_tokenize_train_f32(const float* x, const float* packed, const float* const* raw6, const float* codebook,
+                             const void* prep, int64_t* idx, float* zq, int64_t* usage, float* ze_out, float* pre0,
+                             float* pre1, float* pre2, void* workspace, int64_t N, int A, int J0, int J1, int D, int K,
+                             void* stream);
 
 /* ---- fast mode (opt-in): the encoder's three GEMMs on fp16 MFMAs with fp32 accumulation -- the half-precision
  * encoder of BASELINE.json's config 2 / SURVEY section 7.  NOT bit-identical to lipvq_tokenize_f32: a fraction of a

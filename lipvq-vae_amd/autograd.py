@@ -42,7 +42,13 @@ class _LLFQFn(torch.autograd.Function):
         dec_packed = module._packed_decoder()
         codebook = module.quantizer.codebook.detach()
         need_grad = any(ctx.needs_input_grad[2:])
-        if need_grad:
+        fused_ok = x.shape[0] > module.EXACT_ROWS_MAX and ops.tokenize_supported(module.feature_dim, 64, module.hidden_dim,
+                                                                                 module.latent_dim, module.num_codes)
+        if need_grad and fused_ok:
+            # large training batches: encoder + quantizer + everything the backward needs in ONE launch (lipvq_tokenize_train_f32)
+            # instead of mlp3 (saved pre-activations) + the stand-alone screen over z_e
+            idx, z_q, z_e, pre_e = module._tokenize_fused(x, module.code_usage, want_pre=True)
+        elif need_grad:
             z_e, pre_e = ops.mlp3(x, enc_packed, _ENC_ACTS, save_pre=True)
             idx, z_q = module._quantize(z_e, module.code_usage)
         elif x.shape[0] > module.EXACT_ROWS_MAX and ops.tokenize_supported(module.feature_dim, 64, module.hidden_dim,

@@ -92,6 +92,9 @@ struct TokArgs {
     int* amb_count;              // workspace[0]
     int* amb_list;               // [N]
     const float* w2q;            // layer-2 weights re-laid out for streaming (S > 8 only; lives in the workspace)
+    float* pre0;                 // TRAIN instances: the three pre-activations [N][64], [N][128], [N][D] the backward needs
+    float* pre1;
+    float* pre2;
     int64_t N;
     int A, D, K;
     float gamma;
@@ -101,8 +104,11 @@ struct TokArgs {
 // FAST: the encoder's three GEMMs as fp16 MFMAs (v_mfma_f32_32x32x16_f16, fp32 accumulation) -- the "fast" mode
 // of SURVEY section 7 / BASELINE config 2's half-precision encoder: NOT bit-identical to the oracle (a fraction of a
 // percent of the indices differ, all between near-equidistant codes); everything after z_e is the parity path.
-template <int S, bool FAST>
+// TRAIN: also stores the pre-activations of the three layers (16-byte stores, lq_tile_store16) -- the forward half of a training
+// step in this one launch instead of mlp3_wg_kernel (with saved pre-activations) + the stand-alone screen + its z_e round trip.
+template <int S, bool FAST, bool TRAIN = false>
 __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
+    static_assert(!(FAST && TRAIN), "training uses the parity arithmetic");
     constexpr int TCF = fused_ring_tc(S), NBF = fused_ring_nb(S);
     constexpr int T0 = 2, T1 = 4, T2 = (S + 1) / 2;         // S odd (D = 208): the last 32-feature tile is half used
     constexpr int S1 = 16 * T0, S2 = 16 * T1;               // k-steps (pairs) of layers 1 and 2
@@ -254,6 +260,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
         float n2 = 0.0f;
         // sigmoid, centring, row statistics and the optional z_e store of one finished 32-feature tile
         auto finish_tile = [&](const int t, f32x16& acc) {
+            if constexpr (TRAIN) lq_tile_store16(a.pre2, a.D, row, row < a.N, t, h, acc, a.D, true);
 #if !defined(LQ_ABL_NOSIGMOID) && !defined(LQ_SCALAR_SIGMOID)
             if constexpr (!FAST) {
                 // the canonical sigmoid, two elements per instruction; a tile that holds a NaN or an infinity (wave-uniform test,
@@ -407,6 +414,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
 #pragma unroll
                 for (int t = 0; t < T0; ++t) {
                     const f32x16 pre = h0[t];
+                    if constexpr (TRAIN) lq_tile_store16(a.pre0, 32 * T0, row, row < a.N, t, h, pre, 32 * T0, true);
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
 #ifndef LQ_ABL_NOGELU
@@ -496,6 +504,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
                 if (t > 0) gelu_fixup(h1[t - 1], pend);
 #endif
                 pend = acc;
+                if constexpr (TRAIN) lq_tile_store16(a.pre1, 32 * T1, row, row < a.N, t, h, acc, 32 * T1, true);
             }
             LQ_STAMP(1);
             // the last tile's GELU runs inside the first layer-2 chain: steps 0 .. 47 of that chain only read h1[0..2]
@@ -677,11 +686,11 @@ static size_t fused_lds_bytes(int A, int K) {
     return fl * sizeof(float) + ring + (K <= FUSED_HIST_MAX ? (size_t)K * 4 : 0);
 }
 
-template <int S, bool FAST>
+template <int S, bool FAST, bool TRAIN = false>
 static int launch_tokenize(const TokArgs& a, hipStream_t st) {
     const size_t lds = fused_lds_bytes<S, FAST>(a.A, a.K);
     if (lds > 160 * 1024) return fail(LIPVQ_EUNSUPPORTED, "tokenize: %zu B of LDS needed", lds);
-    auto kfn = tokenize_kernel<S, FAST>;
+    auto kfn = tokenize_kernel<S, FAST, TRAIN>;
     static LqLdsReserve reserved;               // per instantiation: per-device, thread-safe (lipvq_common.h)
     if (int rc = lipvq_reserve_lds(reserved, (const void*)kfn, lds, "tokenize")) return rc;
     int64_t nblk = (a.N + FUSED_WAVES * 32 - 1) / (FUSED_WAVES * 32);
@@ -764,7 +773,8 @@ extern "C" size_t lipvq_tokenize_workspace_bytes(int64_t N, int D) {
 // usage (may be NULL, accumulated), ze_out (may be NULL).  workspace[0] (int) = rows decided by the exact kernel.
 static int tokenize_impl(const float* x, const float* packed, const void* packed16, const float* const* raw6,
                          const float* codebook, const void* prep, int64_t* idx, float* zq, int64_t* usage, float* ze_out,
-                         void* workspace, int64_t N, int A, int J0, int J1, int D, int K, void* stream) {
+                         void* workspace, int64_t N, int A, int J0, int J1, int D, int K, void* stream,
+                         float* pre0 = nullptr, float* pre1 = nullptr, float* pre2 = nullptr) {
     if (N < 0) return fail(LIPVQ_EINVAL, "tokenize: N < 0");
     if (N == 0) return LIPVQ_OK;
     if (!x || !packed || !raw6 || !codebook || !prep || !idx || !workspace) return fail(LIPVQ_EINVAL, "tokenize: null pointer");
@@ -794,9 +804,18 @@ static int tokenize_impl(const float* x, const float* packed, const void* packed
         hipLaunchKernelGGL(w2q_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, packed + PL.oP2, w2q, PL.T2, PL.S2);
     }
     TokArgs a{x, packed, (const unsigned char*)packed16, (const unsigned char*)prep, codebook, idx, zq,
-              (unsigned long long*)usage, ze_buf, amb_count, amb_list, w2q, N, A, D, K, LIPVQ_SCREEN_GAMMA};
+              (unsigned long long*)usage, ze_buf, amb_count, amb_list, w2q, pre0, pre1, pre2, N, A, D, K, LIPVQ_SCREEN_GAMMA};
     int rc;
-    if (packed16) {
+    if (pre0) {
+        if ((((uintptr_t)pre0 | (uintptr_t)pre1 | (uintptr_t)pre2) & 15) != 0)
+            return fail(LIPVQ_EINVAL, "tokenize_train: the pre-activation buffers must be 16-byte aligned");
+        switch (D) {
+            case 32: rc = launch_tokenize<2, false, true>(a, st); break;
+            case 64: rc = launch_tokenize<4, false, true>(a, st); break;
+            case 128: rc = launch_tokenize<8, false, true>(a, st); break;
+            default: rc = launch_tokenize<13, false, true>(a, st); break;
+        }
+    } else if (packed16) {
         switch (D) {
             case 32: rc = launch_tokenize<2, true>(a, st); break;
             case 64: rc = launch_tokenize<4, true>(a, st); break;
@@ -821,6 +840,17 @@ extern "C" int lipvq_tokenize_f32(const float* x, const float* packed, const flo
                                   const void* prep, int64_t* idx, float* zq, int64_t* usage, float* ze_out,
                                   void* workspace, int64_t N, int A, int J0, int J1, int D, int K, void* stream) {
     return tokenize_impl(x, packed, nullptr, raw6, codebook, prep, idx, zq, usage, ze_out, workspace, N, A, J0, J1, D, K, stream);
+}
+
+// The forward half of a training step (v5:71-74 with everything autograd saves): lipvq_tokenize_f32 that also writes the three
+// pre-activations pre0 [N][J0], pre1 [N][J1], pre2 [N][D] and z_e -- the same values lipvq_mlp3_f32(.., pre0, pre1, pre2) stores.
+extern "C" int lipvq_tokenize_train_f32(const float* x, const float* packed, const float* const* raw6, const float* codebook,
+                                        const void* prep, int64_t* idx, float* zq, int64_t* usage, float* ze_out, float* pre0,
+                                        float* pre1, float* pre2, void* workspace, int64_t N, int A, int J0, int J1, int D, int K,
+                                        void* stream) {
+    if (!ze_out || !pre0 || !pre1 || !pre2) return fail(LIPVQ_EINVAL, "tokenize_train: z_e and the three pre-activation buffers are required");
+    return tokenize_impl(x, packed, nullptr, raw6, codebook, prep, idx, zq, usage, ze_out, workspace, N, A, J0, J1, D, K, stream,
+                         pre0, pre1, pre2);
 }
 
 // Fast mode: the encoder's GEMMs on fp16 MFMAs (packed16 = lipvq_mlp3_pack_f16_f32 of the same weights; `packed` still

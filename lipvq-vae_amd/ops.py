@@ -367,9 +367,10 @@ def mlp3_pack_f16(W0, W1, W2):
 
 
 def tokenize(x, packed: PackedMlp3, raw, codebook, prep: PreparedCodebook, usage=None, want_zq=True, want_ze=False,
-             workspace=None, packed16=None):
+             workspace=None, packed16=None, want_pre=False):
     """(idx, zq, ze, workspace) of the fused encode + quantize launch (lipvq_tokenize_f32).  raw = the encoder's six
-    unpacked tensors (W0, b0, W1, b1, W2 normalised, b2): the exact kernel re-encodes uncertified rows with them."""
+    unpacked tensors (W0, b0, W1, b1, W2 normalised, b2): the exact kernel re-encodes uncertified rows with them.
+    want_pre=True (training forward, lipvq_tokenize_train_f32): also returns the three pre-activations as a 5th element."""
     raw = tuple(_chk(t, f"raw[{i}]") for i, t in enumerate(raw))
     raw_arr = (_C.c_void_p * 6)(*[t.data_ptr() for t in raw])
     x, codebook = _chk(x, "x"), _chk(codebook, "codebook")
@@ -382,8 +383,18 @@ def tokenize(x, packed: PackedMlp3, raw, codebook, prep: PreparedCodebook, usage
     dev = x.device
     idx = torch.empty(N, device=dev, dtype=torch.int64)
     zq = torch.empty((N, D), device=dev, dtype=torch.float32) if want_zq else None
-    ze = torch.empty((N, D), device=dev, dtype=torch.float32) if want_ze else None
+    ze = torch.empty((N, D), device=dev, dtype=torch.float32) if (want_ze or want_pre) else None
     ws = workspace if workspace is not None else tokenize_workspace(N, D, dev)
+    if want_pre:
+        if packed16 is not None:
+            raise ValueError("tokenize: the fast mode has no training variant")
+        pre = (torch.empty((N, packed.J0), device=dev, dtype=torch.float32), torch.empty((N, packed.J1), device=dev, dtype=torch.float32),
+               torch.empty((N, D), device=dev, dtype=torch.float32))
+        with _on(dev):
+            check(lib.lipvq_tokenize_train_f32(_ptr(x), _ptr(packed.buf), raw_arr, _ptr(codebook), _ptr(prep.buf), _ptr(idx), _ptr(zq),
+                                               _ptr(usage), _ptr(ze), _ptr(pre[0]), _ptr(pre[1]), _ptr(pre[2]), _ptr(ws), N, A,
+                                               packed.J0, packed.J1, D, K, _stream()), "lipvq_tokenize_train_f32")
+        return idx, zq, ze, ws, pre
     with _on(dev):
         if packed16 is not None:            # fast mode (fp16 encoder GEMMs): not bit-identical, see include/lipvq.h
             if want_ze:

@@ -203,7 +203,7 @@ class LLFQVAE_V4(_TokenizerBase):
         packed, _, _ = self._packed_encoder()
         return ops.mlp3(self._as_rows(x), packed, (ACT_GELU, ACT_GELU, ACT_SIGMOID))
 
-    def _tokenize_fused(self, x, usage, want_ze=False, fast=False):
+    def _tokenize_fused(self, x, usage, want_ze=False, fast=False, want_pre=False):
         """(idx, z_q, z_e | None) from ONE persistent launch: z_e never leaves registers unless asked for
         (csrc/lipvq_fused.hip).  Caller checks ops.tokenize_supported()."""
         cb = self.quantizer.codebook.detach()
@@ -217,6 +217,11 @@ class LLFQVAE_V4(_TokenizerBase):
         if fast:
             packed16 = self._enc16_cache.get((w0, w1, self.to_latent.W, self.to_latent.ci),
                                              lambda: ops.mlp3_pack_f16(w0, w1, Wn))
+        if want_pre:                                         # training forward: z_e and the three pre-activations as well
+            idx, zq, ze, ws, pre = ops.tokenize(x, packed, (w0, b0, w1, b1, Wn, b2), cb, prep, usage=usage, workspace=self._tok_ws,
+                                                want_pre=True)
+            self.last_exact_rows = ws
+            return idx, zq, ze, pre
         idx, zq, ze, ws = ops.tokenize(x, packed, (w0, b0, w1, b1, Wn, b2), cb, prep, usage=usage, want_ze=want_ze,
                                        workspace=self._tok_ws, packed16=packed16)
         self.last_exact_rows = ws

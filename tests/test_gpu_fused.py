@@ -142,3 +142,38 @@ def test_no_grad_forward_takes_the_fused_launch_and_agrees(oracle):
     assert torch.equal(z_a, z_b) and torch.equal(idx_a, model.last_indices) and loss_a.item() == loss_b.item()
     f = oracle.llfq_forward(p, x.cpu().numpy())
     assert np.array_equal(z_b.cpu().numpy(), f["z_q"]) and abs(loss_b.item() - f["loss"]) <= 1e-5 * abs(f["loss"])
+
+
+@pytest.mark.parametrize("N,A,D,K", [(5000, 7, 64, 1024), (2100, 12, 208, 1024), (3000, 7, 32, 256), (2500, 12, 128, 1000)])
+def test_training_forward_launch_equals_unfused(oracle, N, A, D, K):
+    """lipvq_tokenize_train_f32 (encoder + quantizer + everything autograd saves, one launch) against lipvq_mlp3_f32 with saved
+    pre-activations + the stand-alone quantizer: z_e, the three pre-activations, indices and z_q bit for bit; and the module's
+    gradients at a batch that takes this route equal the ones the unfused route gives."""
+    from lipvq_vae_amd import ops
+    from lipvq_vae_amd.autograd import _ENC_ACTS
+    p, model = _setup(N + D, A, D, K, oracle)
+    x = O.make_inputs(N + 1, N, A)
+    xt = torch.from_numpy(x).cuda()
+    idx, zq, ze, pre = model._tokenize_fused(xt, None, want_pre=True)
+    ze_u, pre_u = ops.mlp3(xt, model._packed_encoder()[0], _ENC_ACTS, save_pre=True)
+    idx_u, zq_u = model._quantize(ze_u, None)
+    assert torch.equal(ze, ze_u) and torch.equal(idx, idx_u) and torch.equal(zq, zq_u)
+    for a, b in zip(pre, pre_u):
+        assert a.shape == b.shape and torch.equal(a, b)
+    assert np.array_equal(ze.cpu().numpy(), oracle.llfq_encode(p, x))
+    # gradients through the module (N > EXACT_ROWS_MAX: the fused training forward) vs the same step forced onto the unfused route
+    assert N > model.EXACT_ROWS_MAX
+    _, loss = model(xt)
+    loss.backward()
+    g_fused = {k: v.grad.clone() for k, v in model.named_parameters()}
+    model.zero_grad()
+    old = model.EXACT_ROWS_MAX
+    try:
+        type(model).EXACT_ROWS_MAX = 1 << 30            # (> N: forward() takes mlp3 + exact rows kernel)
+        _, loss2 = model(xt)
+        loss2.backward()
+    finally:
+        type(model).EXACT_ROWS_MAX = old
+    assert abs(loss.item() - loss2.item()) <= 1e-6 * abs(loss2.item())
+    for k, v in model.named_parameters():
+        assert torch.allclose(g_fused[k], v.grad, rtol=0, atol=1e-5 * max(1e-12, float(v.grad.abs().max()))), k
