@@ -1,0 +1,53 @@
+"""Dev tool (GPU): randomized soak of the quantizer routes against the all-pairs exact kernel (no screen, no lists):
+fused tokenize, stand-alone screened nearest, exact rows -- random shapes, seeds and adversarial rows (duplicated codes,
+bisector near-ties incl. codes congruent mod 32, rows sitting on codes).  python scripts/dev/soak.py [seconds]"""
+import sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
+import numpy as np, torch
+import lipvq_vae_amd
+from lipvq_vae_amd import ops
+from lipvq_vae_amd.tokenizer import LLFQVAE_V4
+from bench import trained_like_
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(12345)
+t0, cases, rows, unc = time.time(), 0, 0, 0
+while time.time() - t0 < budget:
+    D = int(rng.choice([32, 64, 128, 208]))
+    K = int(rng.choice([37, 256, 1000, 1024, 2048, 8192])) if D != 208 else int(rng.choice([128, 1024]))
+    A = int(rng.choice([3, 7, 12]))
+    N = int(rng.choice([1, 33, 257, 2049, 4100, 30000, 100001]))
+    torch.manual_seed(int(rng.integers(1 << 30)))
+    model = LLFQVAE_V4(A, D, num_codes=K).cuda()
+    trained_like_(model, A, seed=int(rng.integers(1 << 30)))
+    cb = model.quantizer.codebook.data
+    if K > 40 and rng.random() < 0.7:                       # duplicated codes (some in the same lane of the screen, some not)
+        for _ in range(int(rng.integers(1, 6))):
+            a = int(rng.integers(K)); b = int((a + 32 * rng.integers(1, max(2, K // 32))) % K) if rng.random() < 0.5 else int(rng.integers(K))
+            cb[b] = cb[a]
+    model.invalidate_caches()
+    x = torch.randn(N, A, device="cuda") * float(rng.choice([0.3, 1.0, 3.0]))
+    ze = model.encode(x)
+    if rng.random() < 0.6 and N > 8:                        # adversarial latents: bisectors and exact code hits, straight into the quantizers
+        m = max(1, N // 4)
+        ia = torch.randint(0, K, (m,), device="cuda"); ib = torch.randint(0, K, (m,), device="cuda")
+        same_lane = torch.rand(m, device="cuda") < 0.5
+        ib = torch.where(same_lane, (ia + 32 * torch.randint(1, max(2, K // 32), (m,), device="cuda")) % K, ib)
+        t = (0.5 + (torch.randint(-3, 4, (m, 1), device="cuda").float()) * 1e-8)
+        ze = ze.clone(); ze[:m] = cb[ia] * t + cb[ib] * (1 - t); ze[m:m + max(1, m // 4)] = cb[ia[:max(1, m // 4)]]
+    ref, _, _ = ops.nearest(ze, cb)
+    if ops.nearest_screen_supported(K, D):
+        idx_s, zq_s, ws = ops.nearest_screened(ze, cb, ops.nearest_prepare(cb), return_workspace=True)
+        assert torch.equal(idx_s, ref), ("screened", N, A, D, K)
+        assert torch.equal(zq_s, cb[ref])
+        unc += int(ws[0])
+    idx_r, _ = ops.nearest_rows(ze, cb)
+    assert torch.equal(idx_r, ref), ("rows", N, A, D, K)
+    if ops.tokenize_supported(A, 64, 128, D, K):
+        idx_f, zq_f = model.tokenize(x, count_usage=False)
+        ref_f, _, _ = ops.nearest(model.encode(x), cb)
+        assert torch.equal(idx_f, ref_f), ("fused", N, A, D, K)
+        assert torch.equal(zq_f, cb[ref_f])
+    cases += 1; rows += N
+print(f"soak: {cases} random cases, {rows} rows, {unc} uncertified rows through the lists -- every route equals the all-pairs exact kernel")
