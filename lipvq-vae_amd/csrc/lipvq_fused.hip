@@ -37,9 +37,9 @@
 #endif
 // stage ring of the fused kernel (LDS left beside the encoder weights): S <= 4: four buffers of two/four tiles; S = 8: the
 // weights take 98 KB, three buffers of one tile
-#ifdef LQ_EXP_RING_TC             /* experiment builds: ring shape from the command line */
-constexpr int fused_ring_tc(int S) { return LQ_EXP_RING_TC; }
-constexpr int fused_ring_nb(int S) { return LQ_EXP_RING_NB; }
+#ifdef LQ_EXP_RING_TC             /* experiment builds: the S = 4 instance's ring shape from the command line */
+constexpr int fused_ring_tc(int S) { return S == 4 ? LQ_EXP_RING_TC : (S <= 2) ? 4 : (S <= 4) ? 2 : 1; }
+constexpr int fused_ring_nb(int S) { return S == 4 ? LQ_EXP_RING_NB : (S <= 4) ? 4 : 3; }
 #else
 constexpr int fused_ring_tc(int S) { return (S <= 2) ? 4 : (S <= 4) ? 2 : 1; }
 constexpr int fused_ring_nb(int S) { return (S <= 4) ? 4 : 3; }
