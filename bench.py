@@ -380,6 +380,8 @@ def main():
                      "peak_note": "frac: algorithmic flop / (encoder flop / 157.3 TF/s fp32 MFMA + 3 x distance flop / 2500 TF/s "
                                   "fp16 MFMA); frac_algorithmic_floor: the same without the 3x (no credit for the split)",
                      "algorithmic_bytes_per_launch": float(N) * (4 * A + 4 * D + 8),
+                     # SURVEY 8d asks for both fractions: the same launch against the HBM roof (it is compute bound by a wide margin)
+                     "hbm_frac": (float(N) * (4 * A + 4 * D + 8) / (tok_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if tok_ms > 0 else 0.0,
                      "rows_decided_by_exact_kernel": exact_rows},
     }
     if sustained is not None:
