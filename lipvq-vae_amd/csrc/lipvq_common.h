@@ -56,7 +56,11 @@ __host__ __device__ static inline float lq_act_apply(float v, int act) {
 // d act(v) / d v evaluated at the pre-activation v
 __host__ __device__ static inline float lq_act_grad(float v, int act) {
     switch (act) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        case LIPVQ_ACT_GELU: return lq_gelu_grad_dev(v);          // straight-line form (lipvq_math.h), 2e-7 from lq_gelu_grad
+#else
         case LIPVQ_ACT_GELU: return lq_gelu_grad(v);
+#endif
         case LIPVQ_ACT_SIGMOID: { const float s = lq_sigmoid(v); return s * (1.0f - s); }
         case LIPVQ_ACT_RELU: return v > 0.0f ? 1.0f : 0.0f;
         default: return 1.0f;

@@ -237,6 +237,46 @@ __device__ __forceinline__ lq_v2f lq_sigmoid2_finite(lq_v2f x) {
     const lq_v2f e = p * sc;
     return lq_rcp2_ge1(lq_bc2(1.0f) + e);
 }
+/* d/dx gelu(x) = Phi(x) + x phi(x), straight-line on x*x < 18 (device code: the backward chains evaluate it for every saved
+ * pre-activation, 192 per row and stack): Phi through the SAME erf polynomial as lq_gelu_poly -- erf(x/sqrt 2) = (x/sqrt 2) s(x^2/9 - 1)
+ * -- and exp(-x^2/2) through lq_expf's polynomial with ONE exact scaling (the argument stays in (-9, 0]: no clamps, no
+ * denormal care).  Within 2e-7 of lq_gelu_grad (which takes erf's and exp's general branches and is what the oracle runs);
+ * gradients are compared with 1e-5 of their scale.  Elsewhere: lq_gelu_grad itself. */
+__device__ __forceinline__ float lq_gelu_grad_dev(float x) {
+    const float t = x * x;
+    if (!(t < 18.0f)) return lq_gelu_grad(x);
+    const float u = lq_fma(t, 0.11111111111111111111f, -1.0f);
+    float s = 0.00012666420661844313f;
+    s = lq_fma(s, u, -0.00043783686123788357f);
+    s = lq_fma(s, u, 0.0008924771682359278f);
+    s = lq_fma(s, u, -0.002175821689888835f);
+    s = lq_fma(s, u, 0.005515238270163536f);
+    s = lq_fma(s, u, -0.01217574905604124f);
+    s = lq_fma(s, u, 0.02415713667869568f);
+    s = lq_fma(s, u, -0.043842192739248276f);
+    s = lq_fma(s, u, 0.07253222167491913f);
+    s = lq_fma(s, u, -0.11009667813777924f);
+    s = lq_fma(s, u, 0.15749694406986237f);
+    s = lq_fma(s, u, -0.2287982553243637f);
+    s = lq_fma(s, u, 0.4701318144798279f);
+    const float cdf = lq_fma(x * 0.35355339059327376220f, s, 0.5f);
+    const float a = -0.5f * t;                                   /* (-9, 0] */
+    const float magic = 12582912.0f;
+    const float nf = lq_fma(a, 1.44269504088896341f, magic);
+    const float n = nf - magic;
+    float r = lq_fma(n, -0.693145751953125f, a);
+    r = lq_fma(n, -1.42860682030941723e-6f, r);
+    float q = 0.00019907570094801486f;
+    q = lq_fma(q, r, 0.0013933652080595493f);
+    q = lq_fma(q, r, 0.00833328627049923f);
+    q = lq_fma(q, r, 0.04166646674275398f);
+    q = lq_fma(q, r, 0.1666666716337204f);
+    q = lq_fma(q, r, 0.5f);
+    const float p = lq_fma(r * r, q, r) + 1.0f;
+    const float e = p * lq_u2f((lq_f2u(nf) << 23) + 0x3F800000u);
+    return lq_fma(x * 0.39894228040143267794f, e, cdf);
+}
+
 /* running check for lq_sigmoid2_finite: chk stays 0 (or -0) while every element seen is finite, and turns NaN for good
  * once one is NaN or +-inf (0 * inf = NaN) */
 __device__ __forceinline__ lq_v2f lq_nonfinite_acc2(lq_v2f x, lq_v2f chk) { return lq_fma2(x, lq_bc2(0.0f), chk); }

@@ -159,3 +159,14 @@ def test_training_gradients_are_reproducible_in_deterministic_mode(oracle):
     finally:
         torch.use_deterministic_algorithms(prev)
     assert all(torch.equal(a, b) for a, b in zip(*grads))
+
+
+def test_gelu_derivative_on_device_tracks_the_canonical_one(ops, oracle):
+    """lipvq_act_bwd_f32 evaluates the GELU derivative in a straight-line form on the device (lq_gelu_grad_dev); the oracle
+    runs lq_gelu_grad (general erf / exp branches).  Dense sweep incl. the hand-over at |x| = sqrt(18), large |x|, 0, NaN."""
+    x = np.concatenate([np.linspace(-12, 12, 200001), [4.2426405, 4.2426410, -4.2426405, 0.0, 1e-30, 88.0, -88.0]]).astype(np.float32)
+    ref = oracle.math_probe(x, 5)                                  # lq_gelu_grad
+    got = ops.act_bwd(torch.ones(x.size, 1, device="cuda"), dev(x.reshape(-1, 1)), O.ACT_GELU).cpu().numpy().ravel()
+    assert np.abs(got - ref).max() <= 3e-7, np.abs(got - ref).max()
+    nan = ops.act_bwd(torch.ones(1, 1, device="cuda"), torch.full((1, 1), float("nan"), device="cuda"), O.ACT_GELU)
+    assert torch.isnan(nan).all()
