@@ -237,10 +237,16 @@ def main():
     gx = torch.Generator(device="cpu").manual_seed(1234 + rank)
     x = torch.randn(B, T, A, generator=gx).to(dev).reshape(N, A)     # flattened as tensor_utils.py:1066-1067 does
 
-    # two histograms: the all-reduce of step k runs asynchronously (RCCL's own stream) under step k+1.
+    # Per-step code-usage histograms, all-reduced in BUCKETS of M steps: two sets of M rows [M][K] int64; every step counts into
+    # its own row, after M steps ONE asynchronous all-reduce covers the set (32 KiB for M = 4, K = 1024) while the next M steps
+    # fill the other set.  Every step's GLOBAL histogram still exists (M steps later at most); what changes is how often a
+    # collective kernel has to find a CU on a chip whose every CU holds a persistent tokenizer workgroup (two waves of 256
+    # registers per SIMD leave no room beside it, so a collective launched per step either delays that step's launch or waits
+    # for its end: ~25-30 us of a 440 us step).  xGMI rings are per-link bound: fewer, larger messages.
     # LIPVQ_BENCH_COLLECTIVE=capi routes it through the library's own RCCL binding (lipvq_allreduce_counts, include/lipvq.h)
     # instead of torch.distributed's process group (the default: the same RCCL underneath).
-    ubuf = [torch.zeros_like(model.code_usage), torch.zeros_like(model.code_usage)]
+    M = max(1, int(os.environ.get("LIPVQ_BENCH_USAGE_BUCKET", "4")))
+    ubuf = [torch.zeros((M,) + tuple(model.code_usage.shape), dtype=model.code_usage.dtype, device=dev) for _ in range(2)]
     pending = [None, None]
     capi_comm = None
     if dist is not None and os.environ.get("LIPVQ_BENCH_COLLECTIVE", "torch") == "capi" and backend == "nccl":
@@ -256,13 +262,24 @@ def main():
             pending[b] = None
     ev_pairs = []
     step_no = [0]
+    last_row = [None]
+
+    def reduce_set(b):
+        if capi_comm is not None:
+            pending[b] = capi_comm.all_reduce(ubuf[b].view(-1))
+        elif dist is not None:
+            pending[b] = dist.all_reduce(ubuf[b], async_op=True)    # global code-usage histograms of M steps
 
     def step(timed):
-        b = step_no[0] & 1
+        s_ = step_no[0]
+        b, m = (s_ // M) & 1, s_ % M
         step_no[0] += 1
-        wait_pending(b)                     # the stream waits for that reduction before the buffer is reused
-        ubuf[b].zero_()
-        model.code_usage = ubuf[b]
+        if m == 0:
+            wait_pending(b)                 # the stream waits for that set's reduction before its rows are reused
+        row = ubuf[b][m]
+        row.zero_()
+        model.code_usage = row
+        last_row[0] = row
         # == LLFQVAE_V4.tokenize: ONE fused launch (encoder + Lipschitz layer + MFMA screen, csrc/lipvq_fused.hip)
         # followed by the exact kernel for the rows the screen could not certify.  HIP events bracket it
         # on the stream it is launched on (torch's current stream is handed to the C ABI).
@@ -273,11 +290,18 @@ def main():
         if timed:
             e1.record()
             ev_pairs.append((e0, e1))
-        if capi_comm is not None:
-            pending[b] = capi_comm.all_reduce(ubuf[b])
-        elif dist is not None:
-            pending[b] = dist.all_reduce(ubuf[b], async_op=True)   # global code-usage histogram (8 KiB for K=1024)
+        if m == M - 1:
+            reduce_set(b)
         return idx, zq
+
+    def flush_partial():
+        """A set that is only partly filled when a timed region ends is reduced as well (rows not yet written are zeros or old
+        rows: harmless, they are rewritten before they are read)."""
+        s_ = step_no[0]
+        if s_ % M != 0:
+            b = (s_ // M) & 1
+            reduce_set(b)
+            step_no[0] = (s_ // M + 1) * M         # the next step starts a fresh set
 
     def fence():
         torch.cuda.synchronize()
@@ -286,6 +310,7 @@ def main():
         torch.cuda.synchronize()
 
     def drain():
+        flush_partial()
         for b in (0, 1):
             wait_pending(b)
 
@@ -328,9 +353,9 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         # every rank's last histogram is the GLOBAL one: world x N rows
-        usage_rows = int(ubuf[(step_no[0] - 1) & 1].sum().item())
+        usage_rows = int(last_row[0].sum().item())
     else:
-        usage_rows = int(ubuf[(step_no[0] - 1) & 1].sum().item())
+        usage_rows = int(last_row[0].sum().item())
     idx_timed = idx.clone()
 
     tok_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / max(1, len(ev_pairs))
@@ -366,8 +391,8 @@ def main():
         "config": {"workload": f"{args.workload}: B={B} T={T} action_dim={A} codebook K={K} d={D}, "
                                f"fp32 encoder + fp32 argmin (parity mode), per-GPU batch fixed",
                    "rows_per_gpu": N,
-                   "parallelism": f"batch-sharded x{world} ({be}), all-reduce of code usage [K] int64 per step, "
-                                  f"overlapped with the next step",
+                   "parallelism": f"batch-sharded x{world} ({be}), per-step code usage [K] int64 all-reduced in "
+                                  f"buckets of {M} steps, overlapped with the following steps",
                    "global_usage_rows_last_step": usage_rows},
         "roofline": {"bound": "mfma",
                      "kernel": ("tokenize_kernel (+ nearest_rows_encode_kernel for uncertified rows)" if fused else
