@@ -135,6 +135,59 @@ def cpu_baseline(model, x_dev, idx_dev, budget_s=10.0):
     return base, gate
 
 
+def measure_traffic_live(workload, kernels, timeout_s=150):
+    """HBM bytes per launch of the metric's kernels, measured NOW: two child runs of this file under `rocprofv3 --pmc`
+    (FETCH_SIZE and WRITE_SIZE in separate passes, counters only -- no trace domain), after the timed region so that the
+    profiler never touches `value`.  Unit and gfx950 correction as MI355X_MICROARCH.md's HBM section prescribes: both counters
+    are in KiB; FETCH_SIZE under-reports wide reads by 2x on gfx950.  Returns (bytes_per_launch, source, detail) or raises."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        raise RuntimeError("rocprofv3 not found")
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        raise RuntimeError("this process is itself running under a profiler; no nested counter run")
+    tmp = tempfile.mkdtemp(prefix="lipvq_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    child = [sys.executable, str(ROOT / "bench.py"), "--workload", workload, "--steps", "5", "--warmup", "2",
+             "--no-cpu-baseline", "--sustained", "0", "--metric-only", "--traffic", "off"]
+    means = {}
+    try:
+        for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+            d = os.path.join(tmp, kind)
+            r = subprocess.run([rp, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            if r.returncode != 0:
+                raise RuntimeError(f"rocprofv3 --pmc {counter} exited {r.returncode}: {r.stdout.decode(errors='replace')[-300:]}")
+            acc = collections.defaultdict(list)
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row["Counter_Name"] == counter:
+                            acc[row["Kernel_Name"].split("(")[0]].append(float(row["Counter_Value"]))
+            means[kind] = {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    detail, total = {}, 0.0
+    for k in sorted(set(means["fetch"]) | set(means["write"])):
+        if not any(t in k for t in kernels):
+            continue
+        f, w = means["fetch"].get(k, (0.0, 0)), means["write"].get(k, (0.0, 0))
+        rb, wb = 2.0 * f[0] * 1024.0, w[0] * 1024.0
+        detail[k] = {"dispatches": max(f[1], w[1]), "read_bytes": rb, "write_bytes": wb}
+        total += rb + wb
+    if not detail:
+        raise RuntimeError("no dispatch of the metric's kernels in the counter output")
+    return total, ("live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate child runs of bench.py --steps 5 --metric-only "
+                   "on this GPU, after the timed region); mean per dispatch, summed over the launch's kernels; reads x2 "
+                   "(gfx950 FETCH_SIZE correction)"), detail
+
+
 def self_launch(args):
     """Plain `python bench.py --gpus N`: start N fresh ranks.  This process has made no GPU call (importing torch does
     not initialise HIP) and makes none; the ranks are children of torch.distributed.run, never an exec of this process."""
@@ -195,6 +248,8 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sustained", type=int, default=1000, help="back-to-back launches of the sustained reading (0 = skip)")
+    ap.add_argument("--traffic", default="live", choices=("live", "file", "off"),
+                    help="roofline.traffic: measured now under rocprofv3 --pmc (N=1 only), read from profiles/hbm_traffic.json, or null")
     ap.add_argument("--metric-only", action="store_true",
                     help="skip the fast-mode / full-forward / training-step side readings (profiling runs: every dispatch is then the metric's)")
     ap.add_argument("--rehearse-launcher", action="store_true", help=argparse.SUPPRESS)
@@ -373,12 +428,19 @@ def main():
     peak_blend = algo_flop / t_floor / 1e12
     achieved = algo_flop / (tok_ms * 1e-3) / 1e12 if tok_ms > 0 else 0.0
     exact_rows = int(model.last_exact_rows[0]) if model.last_exact_rows is not None else None
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_detail = None, None, None
+    if args.traffic == "live" and world == 1 and not args.metric_only:
+        try:
+            traffic, traffic_src, traffic_detail = measure_traffic_live(
+                args.workload, ("tokenize_kernel", "nearest_rows") if ops.tokenize_supported(A, 64, model.hidden_dim, D, K)
+                else ("mlp3_wg_kernel", "screen_kernel", "nearest_rows"))
+        except Exception as e:  # noqa: BLE001 -- the profiler is optional equipment; the committed measurement stands in
+            traffic_src = f"live measurement failed ({type(e).__name__}: {str(e)[:200]}); "
     tfile = ROOT / "profiles" / "hbm_traffic.json"           # PMC-derived bytes per launch (separate rocprofv3 --pmc runs)
-    if tfile.exists():
+    if traffic is None and args.traffic != "off" and tfile.exists():
         t = json.loads(tfile.read_text())
         if t.get("workload") == args.workload:
-            traffic, traffic_src = t.get("bytes_per_launch"), t.get("source")
+            traffic, traffic_src = t.get("bytes_per_launch"), (traffic_src or "") + "committed: " + str(t.get("source"))
     fused = ops.tokenize_supported(A, 64, model.hidden_dim, D, K)
     be = (f"{dist.get_backend()} world_size={dist.get_world_size()}, collective via "
           f"{'lipvq_allreduce_counts (C ABI -> RCCL)' if capi_comm is not None else 'torch.distributed'}"
@@ -399,7 +461,7 @@ def main():
                                 "mlp3_wg_kernel + screen_kernel (+ nearest_rows_kernel for uncertified rows)"),
                      "achieved": achieved, "peak": peak_blend, "unit": "TFLOP/s", "frac": achieved / peak_blend,
                      "frac_algorithmic_floor": (t_floor_alg * 1e3) / tok_ms if tok_ms > 0 else 0.0,
-                     "traffic": traffic, "traffic_source": traffic_src,
+                     "traffic": traffic, "traffic_source": traffic_src, "traffic_detail": traffic_detail,
                      "ms_per_launch": tok_ms, "algorithmic_flop_per_launch": algo_flop,
                      "floor_ms": t_floor * 1e3, "floor_algorithmic_ms": t_floor_alg * 1e3,
                      "peak_note": "frac: algorithmic flop / (encoder flop / 157.3 TF/s fp32 MFMA + 3 x distance flop / 2500 TF/s "
