@@ -242,9 +242,8 @@ __device__ __forceinline__ lq_v2f lq_sigmoid2_finite(lq_v2f x) {
  * -- and exp(-x^2/2) through lq_expf's polynomial with ONE exact scaling (the argument stays in (-9, 0]: no clamps, no
  * denormal care).  Within 2e-7 of lq_gelu_grad (which takes erf's and exp's general branches and is what the oracle runs);
  * gradients are compared with 1e-5 of their scale.  Elsewhere: lq_gelu_grad itself. */
-__device__ __forceinline__ float lq_gelu_grad_dev(float x) {
+__device__ __forceinline__ float lq_gelu_grad_poly(float x) {      /* the straight-line part: valid for x * x < 18 */
     const float t = x * x;
-    if (!(t < 18.0f)) return lq_gelu_grad(x);
     const float u = lq_fma(t, 0.11111111111111111111f, -1.0f);
     float s = 0.00012666420661844313f;
     s = lq_fma(s, u, -0.00043783686123788357f);
@@ -276,6 +275,7 @@ __device__ __forceinline__ float lq_gelu_grad_dev(float x) {
     const float e = p * lq_u2f((lq_f2u(nf) << 23) + 0x3F800000u);
     return lq_fma(x * 0.39894228040143267794f, e, cdf);
 }
+__device__ __forceinline__ float lq_gelu_grad_dev(float x) { return (x * x < 18.0f) ? lq_gelu_grad_poly(x) : lq_gelu_grad(x); }
 
 /* running check for lq_sigmoid2_finite: chk stays 0 (or -0) while every element seen is finite, and turns NaN for good
  * once one is NaN or +-inf (0 * inf = NaN) */

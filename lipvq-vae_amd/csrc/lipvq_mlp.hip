@@ -406,6 +406,218 @@ __global__ __launch_bounds__(64 * MLPS_WAVES) void mlp3_wg_kernel(Mlp3Args a) {
         lq_tile_store16(a.y, a.J2, row, valid, t, h, acc, a.J2, vec2y);
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// Large batches: persistent workgroups with the packed weights RESIDENT IN LDS.  mlp3_wg_kernel pays, for every 64 rows, the
+// L2 latency of its weight stream (8 k-steps of cover), three workgroup barriers with 2-4 of 8 waves idle in the narrow
+// layers, and the HBM latency of the saved pre-activations after each chain; measured at N = 524 288 it ran 3-4x above both
+// its matrix-pipe and its HBM time (backward of the encoder stack 562 us; 131 us of MFMA, ~150 us of HBM traffic).  Here one
+// workgroup per CU copies the whole packed stack into LDS once (67 KB for the reference's widths), then every WAVE walks its
+// own 32-row tiles through the three layers exactly like mlp3_kernel -- activations stay in registers (the MFMA result tile IS
+// the next layer's B operand), no barrier after the prologue -- with the A operand one conflict-free ds_read_b32 per MFMA,
+// the saved pre-activations of a layer requested BEFORE that layer's MFMA chain and consumed after it, and all row-major
+// traffic in 64-byte pieces per lane (lq_tile_load16 / lq_tile_store16).  Same packed layout, same k-ordered chains from the
+// bias: the same bits as the other two kernels.
+// ------------------------------------------------------------------------------------------
+#define MLPL_WAVES 8
+
+__device__ __forceinline__ void mlpl_act16(f32x16& v, int act) {
+    if (act == LIPVQ_ACT_GELU) {
+        f32x16 o;
+        float m = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[r] = lq_gelu_poly(v[r]); m = fmaxf(m, v[r] * v[r]); }
+        if (!(m < 18.0f)) {                                    // rare: some |x| >= sqrt(18) in this lane (a NaN went through the polynomial as a NaN)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = lq_gelu(v[r]);
+        }
+        v = o;
+    } else if (act != LIPVQ_ACT_NONE) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = lq_act_apply(v[r], act);
+    }
+}
+
+// g[r] *= act'(m[r]).  Straight-line over the 16 elements (one rare, out-of-line fix-up per tile instead of a branch and an
+// inlined erf/exp tail per element: with those the backward of the encoder stack took 629 us, 350 of them in here).
+__device__ __noinline__ float mlpl_gelu_grad_slow(float x) { return lq_gelu_grad(x); }
+
+__device__ __forceinline__ void mlpl_actgrad16(f32x16& g, f32x16 m, int act) {
+    if (act == LIPVQ_ACT_GELU) {
+        f32x16 d;
+        float mx = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { d[r] = lq_gelu_grad_poly(m[r]); mx = fmaxf(mx, m[r] * m[r]); }
+        if (!(mx < 18.0f)) {
+#pragma unroll 1
+            for (int r = 0; r < 16; ++r) {
+                float v = d[0];                                      // rotate through element 0: no dynamic register indexing
+                if (!(m[0] * m[0] < 18.0f)) v = mlpl_gelu_grad_slow(m[0]);
+                f32x16 dn, mn;
+#pragma unroll
+                for (int q = 0; q < 15; ++q) { dn[q] = d[q + 1]; mn[q] = m[q + 1]; }
+                dn[15] = v; mn[15] = m[0];
+                d = dn;
+                m = mn;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[r] = g[r] * d[r];
+    } else if (act == LIPVQ_ACT_SIGMOID) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float sg = lq_sigmoid(m[r]); g[r] = g[r] * (sg * (1.0f - sg)); }
+    } else if (act == LIPVQ_ACT_RELU) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[r] = g[r] * (m[r] > 0.0f ? 1.0f : 0.0f);
+    }
+}
+
+// one 32 x 32 tile of a row-major operand in the MFMA B-operand layout (rows past N clamp to N - 1 on loads, are skipped on stores)
+__device__ __forceinline__ f32x16 mlpl_load(const float* __restrict__ base, const int64_t* __restrict__ gather, int ld, int64_t row0,
+                                            int64_t N, int t, int lane, int J, bool vec) {
+    int64_t rr = row0 + (lane & 31);
+    rr = rr < N ? rr : N - 1;
+    if (gather) rr = gather[rr];
+    return lq_tile_load16(base, ld, rr, t, lane >> 5, J, vec);
+}
+__device__ __forceinline__ void mlpl_store(float* __restrict__ base, int ld, int64_t row0, int64_t N, int t, int lane, const f32x16& v,
+                                           int J, bool vec) {
+    const int64_t rr = row0 + (lane & 31);
+    lq_tile_store16(base, ld, rr, rr < N, t, lane >> 5, v, J, vec);
+}
+
+template <int T0, int T1, bool BWD>
+__global__ __launch_bounds__(64 * MLPL_WAVES) void mlp3_lds_kernel(Mlp3Args a) {
+    extern __shared__ __attribute__((aligned(16))) float mlpl_w[];
+    const PackedLayout L = packed_layout(a.K0, a.J0, a.J1, a.J2);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    {   // the packed stack -> LDS (total is a multiple of 32 floats; the host checked the 16-byte alignment)
+        const float4* __restrict__ src = reinterpret_cast<const float4*>(a.packed);
+        float4* dst = reinterpret_cast<float4*>(mlpl_w);
+        for (int i = tid; i < (int)(L.total / 4); i += 64 * MLPL_WAVES) dst[i] = src[i];
+    }
+    __syncthreads();
+    const float* P0 = mlpl_w + L.oP0 + lane;
+    const float* B0 = mlpl_w + L.oB0 + h;
+    const float* P1 = mlpl_w + L.oP1 + lane;
+    const float* B1 = mlpl_w + L.oB1 + h;
+    const float* P2 = mlpl_w + L.oP2 + lane;
+    const float* B2 = mlpl_w + L.oB2 + h;
+    auto al16 = [](const void* p, int ld) { return p && ((((uintptr_t)p) & 15) == 0) && (ld & 3) == 0; };
+    const bool vecx = al16(a.x, a.K0), vecp = BWD && al16(a.in_pre, a.K0);
+    const bool vec0 = al16(a.out0, a.J0), vec1 = al16(a.out1, a.J1), vec2o = al16(a.out2, BWD ? a.K0 : a.J2), vec2y = al16(a.y, a.J2);
+    const bool vec0m = BWD && al16(a.mul0, a.J0), vec1m = BWD && al16(a.mul1, a.J1);
+    const int KT0 = (a.K0 + 31) / 32;
+    const int64_t ntiles = (a.N + 31) / 32;
+    const int64_t nwaves = (int64_t)gridDim.x * MLPL_WAVES;
+
+    for (int64_t tile = (int64_t)blockIdx.x * MLPL_WAVES + wave; tile < ntiles; tile += nwaves) {
+        const int64_t row0 = tile * 32;
+        // one 32-feature slice of the input rows as a B operand; backward: act2'(pre2) folded in and g2 saved
+        f32x16 xraw, praw;
+        auto in_issue = [&](int kt) {
+            xraw = mlpl_load(a.x, a.gather_idx, a.K0, row0, a.N, kt, lane, a.K0, vecx);
+            if (BWD && a.in_pre) praw = mlpl_load(a.in_pre, nullptr, a.K0, row0, a.N, kt, lane, a.K0, vecp);
+        };
+        auto in_finish = [&](int kt) -> f32x16 {
+            f32x16 v = xraw;
+            if (BWD) {
+                if (a.in_pre) mlpl_actgrad16(v, praw, a.act_in);
+                if (a.out2) mlpl_store(a.out2, a.K0, row0, a.N, kt, lane, v, a.K0, vec2o);
+            }
+            return v;
+        };
+
+        // ---- layer 0: K0 -> 32 T0 ----
+        in_issue(0);
+        f32x16 m0[T0];                                           // requested before the chain, consumed after it
+        if (BWD) {
+#pragma unroll
+            for (int t = 0; t < T0; ++t) m0[t] = mlpl_load(a.mul0, nullptr, a.J0, row0, a.N, t, lane, a.J0, vec0m);
+        }
+        f32x16 xb = in_finish(0);
+        f32x16 acc0[T0];
+#pragma unroll
+        for (int t = 0; t < T0; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[t][r] = B0[32 * t + 2 * r];
+        for (int kt = 0; kt < KT0; ++kt) {
+            if (kt + 1 < KT0) in_issue(kt + 1);                  // (wave-uniform) the next slice is in flight under this one's MFMAs
+            const int sl = L.S0 - 16 * kt;                       // k-steps left
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (r < sl) {
+#pragma unroll
+                    for (int t = 0; t < T0; ++t)
+                        acc0[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(P0[((size_t)t * L.S0 + 16 * kt + r) * 64], xb[r], acc0[t], 0, 0, 0);
+                }
+            }
+            if (kt + 1 < KT0) xb = in_finish(kt + 1);
+        }
+        f32x16 m1[T1];
+        if (BWD) {
+#pragma unroll
+            for (int t = 0; t < T0; ++t) mlpl_actgrad16(acc0[t], m0[t], a.act0);
+            // the next layer's multipliers: after m0 is dead (registers), before this layer's stores (vmcnt counts both in order)
+#pragma unroll
+            for (int t = 0; t < T1; ++t) m1[t] = mlpl_load(a.mul1, nullptr, a.J1, row0, a.N, t, lane, a.J1, vec1m);
+#pragma unroll
+            for (int t = 0; t < T0; ++t) mlpl_store(a.out0, a.J0, row0, a.N, t, lane, acc0[t], a.J0, vec0);
+        } else {
+#pragma unroll
+            for (int t = 0; t < T0; ++t) {
+                if (a.out0) mlpl_store(a.out0, a.J0, row0, a.N, t, lane, acc0[t], a.J0, vec0);
+                mlpl_act16(acc0[t], a.act0);
+            }
+        }
+
+        // ---- layer 1: 32 T0 -> 32 T1 ----
+        f32x16 acc1[T1];
+#pragma unroll
+        for (int t = 0; t < T1; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[t][r] = B1[32 * t + 2 * r];
+#pragma unroll
+        for (int s = 0; s < 16 * T0; ++s) {
+#pragma unroll
+            for (int t = 0; t < T1; ++t)
+                acc1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(P1[((size_t)t * (16 * T0) + s) * 64], acc0[s / 16][s % 16], acc1[t], 0, 0, 0);
+        }
+        if (BWD) {
+#pragma unroll
+            for (int t = 0; t < T1; ++t) {
+                mlpl_actgrad16(acc1[t], m1[t], a.act1);
+                mlpl_store(a.out1, a.J1, row0, a.N, t, lane, acc1[t], a.J1, vec1);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < T1; ++t) {
+                if (a.out1) mlpl_store(a.out1, a.J1, row0, a.N, t, lane, acc1[t], a.J1, vec1);
+                mlpl_act16(acc1[t], a.act1);
+            }
+        }
+
+        // ---- layer 2: 32 T1 -> J2, one 32-feature output tile at a time (backward: only if the caller wants d/d input) ----
+        if (!BWD || a.y) {
+            for (int t2 = 0; t2 < L.T2; ++t2) {
+                f32x16 acc2;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[r] = B2[32 * t2 + 2 * r];
+                const float* P2t = P2 + (size_t)t2 * (16 * T1) * 64;
+#pragma unroll
+                for (int s = 0; s < 16 * T1; ++s)
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(P2t[(size_t)s * 64], acc1[s / 16][s % 16], acc2, 0, 0, 0);
+                if (!BWD) {
+                    if (a.out2) mlpl_store(a.out2, a.J2, row0, a.N, t2, lane, acc2, a.J2, vec2o);
+                    mlpl_act16(acc2, a.act2);
+                }
+                mlpl_store(a.y, a.J2, row0, a.N, t2, lane, acc2, a.J2, vec2y);
+            }
+        }
+    }
+}
 typedef void (*mlp3_fn)(Mlp3Args);
 template <bool BWD>
 static mlp3_fn mlp3_select(int T0, int T1) {
@@ -451,6 +663,50 @@ static int launch_mlp3_wg(const Mlp3Args& a, hipStream_t st, const char* what, b
     return check_launch(what);
 }
 
+
+// rows from which the LDS-resident kernel is used (LIPVQ_MLP3_LDS_ROWS: measurement knob; 0 = never)
+static int64_t mlp3_lds_rows() {
+    static int64_t v = -1;
+    if (v < 0) {
+        const char* e = getenv("LIPVQ_MLP3_LDS_ROWS");
+        v = e ? atoll(e) : 32768;
+        if (v == 0) v = INT64_MAX;
+    }
+    return v;
+}
+
+template <bool BWD>
+static mlp3_fn mlp3_lds_select(int T0, int T1) {      // the reference's hidden widths (64, 128) only; others keep mlp3_wg_kernel
+#define LQ_CASE(a_, b_) if (T0 == a_ && T1 == b_) return mlp3_lds_kernel<a_, b_, BWD>;
+    LQ_CASE(2, 4) LQ_CASE(4, 2)
+#undef LQ_CASE
+    return nullptr;
+}
+
+template <bool BWD>
+static int launch_mlp3_lds(const Mlp3Args& a, hipStream_t st, const char* what, bool* done) {
+    *done = false;
+    if (a.N < mlp3_lds_rows()) return LIPVQ_OK;
+    const PackedLayout L = packed_layout(a.K0, a.J0, a.J1, a.J2);
+    const size_t lds = L.total * sizeof(float);
+    if (lds > 156 * 1024 || (((uintptr_t)a.packed) & 15)) return LIPVQ_OK;
+    mlp3_fn fn = mlp3_lds_select<BWD>(a.J0 / 32, a.J1 / 32);
+    if (!fn) return LIPVQ_OK;
+    static LqLdsReserve reserved[2];             // per instantiation: per-device, thread-safe (lipvq_common.h)
+    if (int rc = lipvq_reserve_lds(reserved[a.J0 == 64 ? 0 : 1], (const void*)fn, 156 * 1024, what)) return rc;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    const int64_t ntiles = (a.N + 31) / 32;
+    int64_t blocks = (ntiles + MLPL_WAVES - 1) / MLPL_WAVES;
+    if (blocks > cus) blocks = cus;                  // one persistent workgroup per CU
+    hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(64 * MLPL_WAVES), lds, st, a);
+    *done = true;
+    return check_launch(what);
+}
+
 static int launch_mlp3(mlp3_fn fn, const Mlp3Args& a, hipStream_t st, const char* what) {
     int64_t ntiles = (a.N + 31) / 32;
     int64_t blocks = (ntiles + 3) / 4;
@@ -470,6 +726,8 @@ extern "C" int lipvq_mlp3_f32(const float* x, const int64_t* gather_idx, const f
     Mlp3Args a{x, gather_idx, packed, y, pre0, pre1, pre2, nullptr, nullptr, nullptr,
                N, K0, J0, J1, J2, act0, act1, act2, LIPVQ_ACT_NONE};
     bool done;
+    if (int e = launch_mlp3_lds<false>(a, (hipStream_t)stream, "mlp3_lds", &done)) return e;
+    if (done) return LIPVQ_OK;
     if (int e = launch_mlp3_wg<false>(a, (hipStream_t)stream, "mlp3_wg", &done)) return e;
     if (done) return LIPVQ_OK;
     mlp3_fn fn = mlp3_select<false>(J0 / 32, J1 / 32);       // fallback (input tile wider than LDS): instantiated widths only
@@ -490,6 +748,8 @@ extern "C" int lipvq_mlp3_bwd_f32(const float* gy, const float* pre0, const floa
     Mlp3Args a{gy, nullptr, packed_bwd, gx, g1, g0, g2, (act2 != LIPVQ_ACT_NONE) ? pre2 : nullptr, pre1, pre0,
                N, J2, J1, J0, K0, act1, act0, LIPVQ_ACT_NONE, act2};
     bool done;
+    if (int e = launch_mlp3_lds<true>(a, (hipStream_t)stream, "mlp3_lds_bwd", &done)) return e;
+    if (done) return LIPVQ_OK;
     if (int e = launch_mlp3_wg<true>(a, (hipStream_t)stream, "mlp3_wg_bwd", &done)) return e;
     if (done) return LIPVQ_OK;
     mlp3_fn fn = mlp3_select<true>(J1 / 32, J0 / 32);

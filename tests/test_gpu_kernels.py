@@ -78,6 +78,72 @@ def test_mlp3_gather(ops, oracle):
     assert np.array_equal(y.cpu().numpy(), y_ref)
 
 
+LDS_ROWS = 32768          # csrc/lipvq_mlp.hip: from this many rows on the LDS-resident persistent kernel runs the stack
+
+
+@pytest.mark.parametrize("K0,J0,J1,J2,acts,gather", [
+    (64, 64, 128, 7, (O.ACT_GELU, O.ACT_GELU, O.ACT_NONE), True),          # the decoder, fed by codebook rows
+    (7, 64, 128, 64, (O.ACT_GELU, O.ACT_GELU, O.ACT_SIGMOID), False),      # the encoder
+    (208, 64, 128, 12, (O.ACT_GELU, O.ACT_GELU, O.ACT_NONE), False),       # D = 208 decoder
+    (12, 64, 128, 208, (O.ACT_GELU, O.ACT_GELU, O.ACT_SIGMOID), False),    # D = 208 encoder: 7 output tiles
+    (33, 128, 64, 5, (O.ACT_RELU, O.ACT_GELU, O.ACT_RELU), False),         # odd fan-in, two input slices
+])
+def test_mlp3_large_batch_kernel_bit_exact(ops, oracle, K0, J0, J1, J2, acts, gather):
+    """The persistent weights-in-LDS kernel (N >= 32 768) against the canonical oracle, ragged last tile included."""
+    N = LDS_ROWS + 45
+    rng = np.random.default_rng(K0 * 31 + J2)
+    W0 = rng.standard_normal((J0, K0)).astype(np.float32) * 0.4
+    W1 = rng.standard_normal((J1, J0)).astype(np.float32) * 0.2
+    W2 = rng.standard_normal((J2, J1)).astype(np.float32) * 0.2
+    b0, b1, b2 = (rng.standard_normal(J).astype(np.float32) for J in (J0, J1, J2))
+    packed = ops.mlp3_pack(*(dev(a) for a in (W0, b0, W1, b1, W2, b2)))
+    if gather:
+        table = rng.uniform(-1, 1, (300, K0)).astype(np.float32)
+        idx = rng.integers(0, 300, N).astype(np.int64)
+        x = table[idx]
+        y, pre = ops.mlp3(dev(table), packed, acts, gather_idx=dev(idx), save_pre=True)
+    else:
+        x = rng.standard_normal((N, K0)).astype(np.float32) * 1.5
+        x[5, :] = 40.0                                    # pre-activations beyond the GELU polynomial's range
+        y, pre = ops.mlp3(dev(x), packed, acts, save_pre=True)
+    y_ref, pre_ref = oracle.mlp3(x, W0, b0, W1, b1, W2, b2, acts, save_pre=True)
+    for got, ref, name in ((pre[0], pre_ref[0], "pre0"), (pre[1], pre_ref[1], "pre1"), (pre[2], pre_ref[2], "pre2"), (y, y_ref, "y")):
+        assert np.array_equal(got.cpu().numpy(), ref), name
+    y2 = ops.mlp3(dev(table), packed, acts, gather_idx=dev(idx)) if gather else ops.mlp3(dev(x), packed, acts)
+    assert torch.equal(y2, y)
+
+
+@pytest.mark.parametrize("K0,J0,J1,J2,acts,want_gx", [
+    (7, 64, 128, 64, (O.ACT_GELU, O.ACT_GELU, O.ACT_SIGMOID), False),      # encoder backward (no d/d input)
+    (64, 64, 128, 7, (O.ACT_GELU, O.ACT_GELU, O.ACT_NONE), True),          # decoder backward
+    (208, 64, 128, 12, (O.ACT_GELU, O.ACT_GELU, O.ACT_NONE), True),
+    (12, 64, 128, 208, (O.ACT_GELU, O.ACT_GELU, O.ACT_SIGMOID), True),
+])
+def test_mlp3_bwd_large_batch_kernel_equals_small_batch_kernel(ops, K0, J0, J1, J2, acts, want_gx):
+    """Backward-data of N >= 32 768 rows (persistent weights-in-LDS kernel) == the same rows sent in pieces below that size
+    (workgroup-per-tile kernel, which the training fixtures pin): the same chains, the same bits."""
+    N = LDS_ROWS + 77
+    g = torch.Generator(device="cuda").manual_seed(K0 + J2)
+    W0 = torch.randn(J0, K0, device="cuda", generator=g) * 0.3
+    W1 = torch.randn(J1, J0, device="cuda", generator=g) * 0.2
+    W2 = torch.randn(J2, J1, device="cuda", generator=g) * 0.2
+    pk = ops.mlp3_pack_bwd(W0, W1, W2)
+    gy = torch.randn(N, J2, device="cuda", generator=g)
+    pre = [torch.randn(N, J, device="cuda", generator=g) * 2.0 for J in (J0, J1, J2)]
+    pre[1][3, :] = 9.0                                     # beyond the straight-line GELU' range
+    if acts[2] == O.ACT_NONE:
+        pre[2] = None
+    big = ops.mlp3_bwd(gy, pre, pk, acts, want_gx=want_gx)
+    cut = 20000
+    parts = [ops.mlp3_bwd(gy[a:b].contiguous(), [None if p is None else p[a:b].contiguous() for p in pre], pk, acts, want_gx=want_gx)
+             for a, b in ((0, cut), (cut, N))]
+    for i, name in enumerate(("g2", "g1", "g0", "gx")):
+        if big[i] is None:
+            assert parts[0][i] is None
+            continue
+        assert torch.equal(big[i], torch.cat([parts[0][i], parts[1][i]])), name
+
+
 @pytest.mark.parametrize("N,K,D,dist", [
     (1000, 256, 32, O.DIST_NORM), (777, 1024, 64, O.DIST_NORM), (300, 1000, 128, O.DIST_NORM),
     (80, 1024, 208, O.DIST_NORM), (100, 37, 24, O.DIST_NORM), (64, 50, 7, O.DIST_NORM),
