@@ -277,8 +277,10 @@ __global__ __launch_bounds__(64 * WGW_WAVES) void wgrad_wg5_kernel(const float* 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
     }
-    // this thread's float4 slots of a block (slot u: float4 tid + 512 u of the [ROWS][Jp4] / [ROWS][Kp4] image)
-    f32x4 gq[NG], hq[NH];
+    // this thread's float4 slots of a block (slot u: float4 tid + 512 u of the [ROWS][Jp4] / [ROWS][Kp4] image).  PF register
+    // sets = blocks in flight; more than one bought nothing (PF = 4 at 64 rows: 178 -> 184 us), occupancy did (see the launch).
+    constexpr int PF = 1;
+    f32x4 gq[PF][NG], hq[PF][NH];
     auto fetchG = [&](int64_t rb, int u) -> f32x4 {                    // clamped address, masked value: no branch
         const int i = tid + 512 * u;
         const int row = (i / Jp4) < ROWS ? (i / Jp4) : ROWS - 1, col = i % Jp4;
@@ -312,24 +314,24 @@ __global__ __launch_bounds__(64 * WGW_WAVES) void wgrad_wg5_kernel(const float* 
         }
         return v;
     };
-    auto fetch = [&](int64_t rb) {
+    auto fetch = [&](int slot, int64_t rb) {
 #pragma unroll
-        for (int u = 0; u < NG; ++u) gq[u] = fetchG(rb, u);
+        for (int u = 0; u < NG; ++u) gq[slot][u] = fetchG(rb, u);
 #pragma unroll
-        for (int u = 0; u < NH; ++u) hq[u] = fetchH(rb, u);
+        for (int u = 0; u < NH; ++u) hq[slot][u] = fetchH(rb, u);
     };
-    auto stage = [&](float* buf, int64_t rb) {
+    auto stage = [&](float* buf, int slot, int64_t rb) {
 #pragma unroll
         for (int u = 0; u < NG; ++u) {
             const int i = tid + 512 * u;
-            if (GFULL || i < ROWS * Jp4) reinterpret_cast<f32x4*>(buf)[i] = gq[u];          // (i = row * Jp4 + col)
+            if (GFULL || i < ROWS * Jp4) reinterpret_cast<f32x4*>(buf)[i] = gq[slot][u];    // (i = row * Jp4 + col)
         }
 #pragma unroll
         for (int u = 0; u < NH; ++u) {
             const int i = tid + 512 * u;
             if (HFULL || i < ROWS * Kp4) {
                 const int row = i / Kp4, col = i % Kp4;
-                const f32x4 v = wg5_act(hq[u], h_act);                 // activation, then the masks (act(0) need not be 0)
+                const f32x4 v = wg5_act(hq[slot][u], h_act);           // activation, then the masks (act(0) need not be 0)
                 const bool in = rb + row < r1;
                 reinterpret_cast<f32x4*>(buf + ROWS * Jp)[i] =
                     (f32x4){(in && 4 * col + 0 < Kd) ? v.x : 0.f, (in && 4 * col + 1 < Kd) ? v.y : 0.f,
@@ -338,39 +340,46 @@ __global__ __launch_bounds__(64 * WGW_WAVES) void wgrad_wg5_kernel(const float* 
         }
     };
 
-    fetch(r0);
-    stage(wg_lds, r0);
-    fetch(r0 + ROWS);                                          // (past the chunk: clamped addresses, staged as zeros)
+#pragma unroll
+    for (int d = 0; d < PF; ++d) fetch(d, r0 + (int64_t)d * ROWS);     // (past the chunk: clamped addresses, staged as zeros)
+    stage(wg_lds, 0, r0);
+    fetch(0, r0 + (int64_t)PF * ROWS);
     lq_wg_barrier();
-    for (int b = 0; b < nblk; ++b) {
-        const float* cur = wg_lds + (b & 1) * BUF;
-        float* nxt = wg_lds + ((b + 1) & 1) * BUF;
+    for (int b = 0; b < nblk; b += PF) {
 #pragma unroll
-        for (int q = 0; q < TPW; ++q) {
-            const int t = wave + q * WGW_WAVES;
-            if (t < T) {                                       // wave-uniform
-                const int ti = t / TJ, tj = t % TJ;
-                const float* ga = cur + kh * Jp + 32 * ti + li;
-                const float* hb = cur + ROWS * Jp + kh * Kp + 32 * tj + li;
+        for (int pu = 0; pu < PF; ++pu) {
+            const int bb = b + pu;
+            if (bb >= nblk) break;                                 // workgroup-uniform
+            const float* cur = wg_lds + (bb & 1) * BUF;
+            float* nxt = wg_lds + ((bb + 1) & 1) * BUF;
 #pragma unroll
-                for (int part = 0; part < ROWS / 32; ++part) {
-                    float av[16], bv[16];
+            for (int q = 0; q < TPW; ++q) {
+                const int t = wave + q * WGW_WAVES;
+                if (t < T) {                                       // wave-uniform
+                    const int ti = t / TJ, tj = t % TJ;
+                    const float* ga = cur + kh * Jp + 32 * ti + li;
+                    const float* hb = cur + ROWS * Jp + kh * Kp + 32 * tj + li;
 #pragma unroll
-                    for (int s2 = 0; s2 < 16; ++s2) { av[s2] = ga[2 * (16 * part + s2) * Jp]; bv[s2] = hb[2 * (16 * part + s2) * Kp]; }
+                    for (int part = 0; part < ROWS / 32; ++part) {
+                        float av[16], bv[16];
 #pragma unroll
-                    for (int s2 = 0; s2 < 16; ++s2) {
-                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], bv[s2], acc[q], 0, 0, 0);
-                        bsum[q] += av[s2];
+                        for (int s2 = 0; s2 < 16; ++s2) { av[s2] = ga[2 * (16 * part + s2) * Jp]; bv[s2] = hb[2 * (16 * part + s2) * Kp]; }
+#pragma unroll
+                        for (int s2 = 0; s2 < 16; ++s2) {
+                            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], bv[s2], acc[q], 0, 0, 0);
+                            bsum[q] += av[s2];
+                        }
                     }
                 }
             }
+            // block bb+1 (in registers for PF iterations) -> the other buffer, whose last readers passed the barrier that ended
+            // iteration bb-1; then its register slot takes the loads of block bb+1+PF
+            const int slot = (pu + 1) % PF;
+            const int64_t rb1 = r0 + (int64_t)(bb + 1) * ROWS;
+            stage(nxt, slot, rb1);
+            fetch(slot, rb1 + (int64_t)PF * ROWS);
+            lq_wg_barrier();
         }
-        // block b+1 (in registers since the previous iteration) -> the other buffer, whose last readers passed the barrier
-        // that ended iteration b-1; then the loads of block b+2
-        const int64_t rb1 = r0 + (int64_t)(b + 1) * ROWS;
-        stage(nxt, rb1);
-        fetch(rb1 + ROWS);
-        lq_wg_barrier();
     }
     float* pw = partW + (size_t)blockIdx.x * J * Kd;
 #pragma unroll
@@ -449,15 +458,23 @@ extern "C" int lipvq_wgrad_f32(const float* G, const float* H, const int64_t* hi
         typedef void (*wg5_fn)(const float*, const float*, const int64_t*, int, float*, float*, int64_t, int, int, int);
         wg5_fn kfn = nullptr;
         // 64-row blocks while two buffers fit LDS (TI + TJ <= 10), 32-row blocks for the 208-wide pairs
-#define LQ_W5(TI_, TJ_) if (TI == TI_ && TJ == TJ_) kfn = (wg5_fn)wgrad_wg5_kernel<TI_, TJ_, (TI_ + TJ_ <= 10 ? 64 : 32)>;
+        // 64-row blocks for the narrow pairs; 32-row blocks from 192 columns on (TI + TJ >= 6): two 64-row buffers of those are
+        // 98 KB and more -- one workgroup per CU, every barrier and staging phase exposed -- while at 32 rows two or three
+        // workgroups share a CU and fill each other's gaps: 128x64 178 -> 146 us, 64x128 217 -> 174 us at N = 524 288 (the narrow
+        // pairs lose 5-15 % at 32 rows; a deeper register prefetch instead of occupancy changed nothing).
+        // LIPVQ_WGRAD_ROWS=32|64 forces one size (measurement knob).
+        static int rows_knob = -1;
+        if (rows_knob < 0) { const char* e = getenv("LIPVQ_WGRAD_ROWS"); rows_knob = e ? atoi(e) : 0; }
+        const bool r64 = TI + TJ <= 10 && (rows_knob == 64 || (rows_knob != 32 && TI + TJ < 6));
+#define LQ_W5(TI_, TJ_) if (TI == TI_ && TJ == TJ_) kfn = r64 ? (wg5_fn)wgrad_wg5_kernel<TI_, TJ_, (TI_ + TJ_ <= 10 ? 64 : 32)> : (wg5_fn)wgrad_wg5_kernel<TI_, TJ_, 32>;
         LQ_W5(1, 1) LQ_W5(1, 2) LQ_W5(1, 4) LQ_W5(1, 7) LQ_W5(2, 1) LQ_W5(2, 2) LQ_W5(2, 4) LQ_W5(2, 7)
         LQ_W5(4, 1) LQ_W5(4, 2) LQ_W5(4, 4) LQ_W5(4, 7) LQ_W5(7, 1) LQ_W5(7, 2) LQ_W5(7, 4) LQ_W5(7, 7)
 #undef LQ_W5
-        const int rows5 = TI + TJ <= 10 ? 64 : 32;
+        const int rows5 = r64 ? 64 : 32;
         const size_t lds5 = (size_t)2 * rows5 * 32 * (TI + TJ) * sizeof(float);
-        static LqLdsReserve reserved5[16];          // per instantiation: per-device, thread-safe (lipvq_common.h)
+        static LqLdsReserve reserved5[32];          // per instantiation: per-device, thread-safe (lipvq_common.h)
         if (lds5 > 64 * 1024)
-            if (int rc = lipvq_reserve_lds(reserved5[ci * 4 + cj], (const void*)kfn, lds5, "wgrad")) return rc;
+            if (int rc = lipvq_reserve_lds(reserved5[(r64 ? 16 : 0) + ci * 4 + cj], (const void*)kfn, lds5, "wgrad")) return rc;
         hipLaunchKernelGGL(kfn, dim3(nch), dim3(64 * WGW_WAVES), lds5, st, G, H, hidx, h_act, partW, partB, N, J, Kd,
                            wgrad_chunk_rows(N));
     } else if (use_wg && TI * TJ <= WGW_WAVES * WGW_MAXT && TI <= 8 && TJ <= 8 && lds <= 64 * 1024) {

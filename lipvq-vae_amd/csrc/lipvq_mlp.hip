@@ -418,6 +418,14 @@ __global__ __launch_bounds__(64 * MLPS_WAVES) void mlp3_wg_kernel(Mlp3Args a) {
 // the saved pre-activations of a layer requested BEFORE that layer's MFMA chain and consumed after it, and all row-major
 // traffic in 64-byte pieces per lane (lq_tile_load16 / lq_tile_store16).  Same packed layout, same k-ordered chains from the
 // bias: the same bits as the other two kernels.
+// Measured at N = 524 288 (scripts/dev/measure_mlp3_bwd.py, measure_mlp3_fwd.py): encoder backward 562 -> 440 us, decoder
+// backward 328 -> 300 us, decoder forward 385 -> 204 us (245 saving the pre-activations).  Ablations of the encoder backward
+// (builds with one part removed): no stores 243, no multiplier loads 218 (identity activations), no MFMA 231 (memory alone:
+// 940 MB at 4.1 TB/s, plain torch streams reach 5.4-5.9 here), MFMA alone 110 (= the pipe's peak), act' 160.  The three parts
+// add up instead of overlapping: the fp32 MFMA and the wave's own VALU share issue (lipvq_fused.hip has the probe), and two
+// waves per SIMD (245 VGPRs) is all the occupancy there is.  Tried and not kept, all correct: non-temporal loads/stores
+// (+6-60 %), whole-line traffic through wave-private LDS patches (+20 %), next-tile input prefetch (+6 %), all multiplier loads
+// at the tile top (+5 %), 12 waves per workgroup (+6 % forward, spills backward).
 // ------------------------------------------------------------------------------------------
 #define MLPL_WAVES 8
 
@@ -669,7 +677,7 @@ static int64_t mlp3_lds_rows() {
     static int64_t v = -1;
     if (v < 0) {
         const char* e = getenv("LIPVQ_MLP3_LDS_ROWS");
-        v = e ? atoll(e) : 32768;
+        v = e ? atoll(e) : 65536;              // crossover with mlp3_wg_kernel (backward: 35 vs 56 us at 32 768, 67 vs 65 at 65 536, 145 vs 117 at 131 072)
         if (v == 0) v = INT64_MAX;
     }
     return v;

@@ -19,7 +19,8 @@ def timed(fn, n=10):
 
 print("LIPVQ_WGRAD_CHUNK =", os.environ.get("LIPVQ_WGRAD_CHUNK", "(default)"))
 for N in (524288, 65536):
-    for J, Kd in ((128, 64), (64, 128), (64, 7), (7, 128)):
+    for J, Kd, act in ((128, 64, ops.ACT_GELU), (64, 128, ops.ACT_GELU), (64, 7, ops.ACT_NONE), (7, 128, ops.ACT_GELU), (64, 64, ops.ACT_NONE),
+                       (128, 64, ops.ACT_NONE)):
         G, H = torch.randn(N, J, device="cuda"), torch.randn(N, Kd, device="cuda")
-        t = timed(lambda: ops.wgrad(G, H))
-        print(f"wgrad N={N} J={J} Kd={Kd}: {t:.1f} us, {2.0 * N * J * Kd / t / 1e6:.1f} TFLOP/s")
+        t = timed(lambda: ops.wgrad(G, H, h_act=act))
+        print(f"wgrad N={N} J={J} Kd={Kd} act={act}: {t:.1f} us, {2.0 * N * J * Kd / t / 1e6:.1f} TFLOP/s, {4.0 * N * (J + Kd) / t / 1e3:.0f} GB/s")

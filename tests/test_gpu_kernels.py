@@ -78,7 +78,7 @@ def test_mlp3_gather(ops, oracle):
     assert np.array_equal(y.cpu().numpy(), y_ref)
 
 
-LDS_ROWS = 32768          # csrc/lipvq_mlp.hip: from this many rows on the LDS-resident persistent kernel runs the stack
+LDS_ROWS = 65536          # csrc/lipvq_mlp.hip: from this many rows on the LDS-resident persistent kernel runs the stack
 
 
 @pytest.mark.parametrize("K0,J0,J1,J2,acts,gather", [
@@ -89,7 +89,7 @@ LDS_ROWS = 32768          # csrc/lipvq_mlp.hip: from this many rows on the LDS-r
     (33, 128, 64, 5, (O.ACT_RELU, O.ACT_GELU, O.ACT_RELU), False),         # odd fan-in, two input slices
 ])
 def test_mlp3_large_batch_kernel_bit_exact(ops, oracle, K0, J0, J1, J2, acts, gather):
-    """The persistent weights-in-LDS kernel (N >= 32 768) against the canonical oracle, ragged last tile included."""
+    """The persistent weights-in-LDS kernel (N >= 65 536) against the canonical oracle, ragged last tile included."""
     N = LDS_ROWS + 45
     rng = np.random.default_rng(K0 * 31 + J2)
     W0 = rng.standard_normal((J0, K0)).astype(np.float32) * 0.4
@@ -120,7 +120,7 @@ def test_mlp3_large_batch_kernel_bit_exact(ops, oracle, K0, J0, J1, J2, acts, ga
     (12, 64, 128, 208, (O.ACT_GELU, O.ACT_GELU, O.ACT_SIGMOID), True),
 ])
 def test_mlp3_bwd_large_batch_kernel_equals_small_batch_kernel(ops, K0, J0, J1, J2, acts, want_gx):
-    """Backward-data of N >= 32 768 rows (persistent weights-in-LDS kernel) == the same rows sent in pieces below that size
+    """Backward-data of N >= 65 536 rows (persistent weights-in-LDS kernel) == the same rows sent in pieces below that size
     (workgroup-per-tile kernel, which the training fixtures pin): the same chains, the same bits."""
     N = LDS_ROWS + 77
     g = torch.Generator(device="cuda").manual_seed(K0 + J2)
@@ -134,7 +134,7 @@ def test_mlp3_bwd_large_batch_kernel_equals_small_batch_kernel(ops, K0, J0, J1, 
     if acts[2] == O.ACT_NONE:
         pre[2] = None
     big = ops.mlp3_bwd(gy, pre, pk, acts, want_gx=want_gx)
-    cut = 20000
+    cut = 40000
     parts = [ops.mlp3_bwd(gy[a:b].contiguous(), [None if p is None else p[a:b].contiguous() for p in pre], pk, acts, want_gx=want_gx)
              for a, b in ((0, cut), (cut, N))]
     for i, name in enumerate(("g2", "g1", "g0", "gx")):
