@@ -401,26 +401,38 @@ __global__ __launch_bounds__(64 * WGW_WAVES) void wgrad_wg5_kernel(const float* 
     }
 }
 
-// gW / gb = sum over chunks of the partial slabs (one launch for both): 32 elements x 8 chunk groups per block (group g sums chunks g, g+8, ... in
-// double), the 8 group sums are combined in a fixed order: deterministic.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partW, const float* __restrict__ partB,
-                                                           float* __restrict__ gW, float* __restrict__ gb, int nchunks,
-                                                           size_t n_w, size_t n_b) {
-    __shared__ double sh[8][32];
+// gW / gb = sum over chunks of the partial slabs (one launch for both): 32 elements x 32 chunk groups per block (group g sums
+// chunks g, g+32, ... in double, four loads in flight), the 32 group sums are combined in a fixed order: deterministic.  (With 8
+// groups of 256 threads the 261 blocks of a 128x64 layer read their 16.7 MB at 0.9 TB/s: 18.6 us per layer, 112 us per step.)
+#define WGR_GROUPS 32
+__global__ __launch_bounds__(32 * WGR_GROUPS) void wgrad_reduce_kernel(const float* __restrict__ partW, const float* __restrict__ partB,
+                                                                      float* __restrict__ gW, float* __restrict__ gb, int nchunks,
+                                                                      size_t n_w, size_t n_b) {
+    __shared__ double sh[WGR_GROUPS][33];
     const int le = threadIdx.x & 31, g = threadIdx.x >> 5;
     const size_t e = (size_t)blockIdx.x * 32 + le;             // [0, n_w): weight gradient, [n_w, n_w + n_b): bias gradient
     const bool isw = e < n_w, isb = !isw && e < n_w + n_b;
     const float* part = isw ? partW : partB;
     const size_t stride = isw ? n_w : n_b, off = isw ? e : e - n_w;
     double s = 0.0;
-    if (isw || isb)
-        for (int c = g; c < nchunks; c += 8) s += (double)part[(size_t)c * stride + off];
+    if (isw || isb) {
+        int c = g;
+        for (; c + 3 * WGR_GROUPS < nchunks; c += 4 * WGR_GROUPS) {
+            const float v0 = part[(size_t)c * stride + off], v1 = part[(size_t)(c + WGR_GROUPS) * stride + off];
+            const float v2 = part[(size_t)(c + 2 * WGR_GROUPS) * stride + off], v3 = part[(size_t)(c + 3 * WGR_GROUPS) * stride + off];
+            s += (double)v0;
+            s += (double)v1;
+            s += (double)v2;
+            s += (double)v3;
+        }
+        for (; c < nchunks; c += WGR_GROUPS) s += (double)part[(size_t)c * stride + off];
+    }
     sh[g][le] = s;
     __syncthreads();
     if (g == 0 && (isw || isb)) {
         double t = sh[0][le];
 #pragma unroll
-        for (int q = 1; q < 8; ++q) t += sh[q][le];
+        for (int q = 1; q < WGR_GROUPS; ++q) t += sh[q][le];
         (isw ? gW : gb)[off] = (float)t;
     }
 }
@@ -493,7 +505,7 @@ extern "C" int lipvq_wgrad_f32(const float* G, const float* H, const int64_t* hi
     }
     if (direct) return check_launch("wgrad");
     const size_t ne = (size_t)J * Kd, nb = gb ? (size_t)J : 0;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((ne + nb + 31) / 32)), dim3(256), 0, st, partW, partB, gW, gb, nch, ne,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((ne + nb + 31) / 32)), dim3(32 * WGR_GROUPS), 0, st, partW, partB, gW, gb, nch, ne,
                        nb);
     return check_launch("wgrad");
 }
@@ -547,7 +559,9 @@ extern "C" int lipvq_scatter_add_det_f32(const float* g, const int64_t* idx, flo
 // Large batches: a workgroup owns a slice of DC columns and a chunk of rows, accumulates its [K][DC] share in LDS (ds_add_f32:
 // two rows of a wave collide only when they picked the same code) and flushes it with one global atomic per non-zero element.
 // The plain kernel above issues N D global atomics onto K D addresses: 286 us at N = 524 288, K = 1024, D = 64 (L2 atomic
-// throughput); this one 4-8x fewer, the rest at LDS speed.
+// throughput); this one 4-8x fewer, the rest at LDS speed.  What bounds it now is ds_add_f32 itself (~3 cycles per lane-add and
+// CU: halving the workgroups doubles the time, and one 16-wave workgroup per CU with bank-padded rows and half the flush
+// atomics ran the same 185-190 us).
 template <int DC>
 __global__ __launch_bounds__(256) void scatter_add_lds_kernel(const float* __restrict__ g, const int64_t* __restrict__ idx,
                                                               float* __restrict__ gC, int64_t N, int K, int D, int64_t rows_per_wg) {
