@@ -183,6 +183,16 @@ int lipvq_scatter_add_f32(const float* g, const int64_t* idx, float* gC, int64_t
  * bit-identical gradients (what torch.use_deterministic_algorithms(True) asks of index_add_).  gC is accumulated into. */
 int lipvq_scatter_add_det_f32(const float* g, const int64_t* idx, float* gC, int64_t N, int K, int D, void* stream);
 
+/* The same sum for a large batch without floating-point atomics (csrc/lipvq_scatter.hip): rows are counting-sorted by code
+ * (stable), every code's rows are summed in segments of 256 rows in row order and the segment sums added in segment order.
+ * The order depends on (idx, N) only, so repeated runs give bit-identical results (it is NOT the strictly sequential order
+ * of lipvq_scatter_add_det_f32).  gC is accumulated into.  lipvq_scatter_add_sorted_supported: N >= 32768, K <= 2048.
+ * workspace: lipvq_scatter_add_sorted_workspace_bytes() (0 when unsupported). */
+int lipvq_scatter_add_sorted_supported(int64_t N, int K, int D);
+size_t lipvq_scatter_add_sorted_workspace_bytes(int64_t N, int K, int D);
+int lipvq_scatter_add_sorted_f32(const float* g, const int64_t* idx, float* gC, void* workspace, int64_t N, int K, int D,
+                                 void* stream);
+
 /* Backward of lipvq_lipschitz_scale_f32: gWn [D][H] -> gW [D][H], gci [D]. */
 int lipvq_lipschitz_bwd_f32(const float* W, const float* ci, const float* gWn, float* gW, float* gci, int D,
                             int H, void* stream);

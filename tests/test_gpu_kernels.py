@@ -207,6 +207,39 @@ def test_scatter_add_deterministic_is_sequential_fp32(N, K, D):
     assert np.abs(c - want).max() <= 1e-4 * (1 + np.abs(want).max())
 
 
+@pytest.mark.parametrize("N,K,D,skew", [
+    (32768 + 13, 1024, 64, False), (70001, 37, 64, True), (262144, 1024, 208, True), (40000, 2048, 32, False),
+    (65536, 1000, 7, True), (100000, 8192, 128, True), (50000, 16384, 16, False), (33000, 2049, 64, True),
+])
+def test_scatter_add_sorted_route(N, K, D, skew):
+    """Counting-sort route of large batches (csrc/lipvq_scatter.hip): equals a float64 index_add_ to fp32 summation accuracy, is
+    bit-identical run after run (no atomics), equals the strictly sequential kernel bit for bit on codes whose rows fit one
+    256-row segment; codes without rows stay zero; hot codes span many segments."""
+    from lipvq_vae_amd import ops
+    gen = torch.Generator(device="cuda").manual_seed(N + K)
+    g = torch.randn(N, D, device="cuda", generator=gen)
+    if skew:                                                   # a few hot codes, many empty ones
+        w = torch.rand(K, device="cuda", generator=gen) ** 8
+        w[K // 2:] *= (torch.rand(K - K // 2, device="cuda", generator=gen) > 0.5)
+        idx = torch.multinomial(w / w.sum(), N, replacement=True, generator=gen)
+    else:
+        idx = torch.randint(0, K, (N,), device="cuda", generator=gen)
+    ref = torch.zeros(K, D, device="cuda", dtype=torch.float64).index_add_(0, idx, g.double())
+    a = ops.scatter_add(g, idx, K, deterministic=False, route="sorted")
+    b = ops.scatter_add(g, idx, K, deterministic=False, route="sorted")
+    assert torch.equal(a, b)
+    counts = torch.bincount(idx, minlength=K)
+    scale = (g.abs().max() * counts.max().clamp(min=1).sqrt()).item()
+    assert float((a.double() - ref).abs().max()) <= 2e-6 * max(scale, float(ref.abs().max()))
+    assert torch.all(a[counts == 0] == 0)
+    # codes whose rows fit one segment are summed in plain ascending row order: the same bits as the sequential kernel
+    seq = ops.scatter_add(g, idx, K, deterministic=True)
+    small = (counts > 0) & (counts <= 256)
+    assert torch.equal(a[small], seq[small])
+    if N >= 65536:
+        assert torch.equal(ops.scatter_add(g, idx, K, deterministic=False), a)    # the default route of a large batch
+
+
 def test_training_gradients_are_reproducible_in_deterministic_mode(oracle):
     from lipvq_vae_amd.tokenizer import LLFQVAE_V4
     A, D, K, N = 7, 64, 256, 4000
