@@ -184,14 +184,17 @@ int lipvq_scatter_add_f32(const float* g, const int64_t* idx, float* gC, int64_t
 int lipvq_scatter_add_det_f32(const float* g, const int64_t* idx, float* gC, int64_t N, int K, int D, void* stream);
 
 /* The same sum for a large batch without floating-point atomics (csrc/lipvq_scatter.hip): rows are counting-sorted by code
- * (stable), every code's rows are summed in segments of 256 rows in row order and the segment sums added in segment order.
- * The order depends on (idx, N) only, so repeated runs give bit-identical results (it is NOT the strictly sequential order
- * of lipvq_scatter_add_det_f32).  gC is accumulated into.  lipvq_scatter_add_sorted_supported: N >= 32768, K <= 2048.
+ * (stable), then
+ *   sequential = 0: every code's rows are summed in segments of 256 rows in row order and the segment sums added in segment
+ *                   order.  The order depends on (idx, N) only: repeated runs give bit-identical results;
+ *   sequential = 1: one chain per (code, column) over ALL its rows in ascending row order -- the order of
+ *                   lipvq_scatter_add_det_f32 and of torch's deterministic index_add_, bit for bit (a hot code is one long chain).
+ * gC is accumulated into.  lipvq_scatter_add_sorted_supported: N >= 32768, K <= 16384.
  * workspace: lipvq_scatter_add_sorted_workspace_bytes() (0 when unsupported). */
 int lipvq_scatter_add_sorted_supported(int64_t N, int K, int D);
 size_t lipvq_scatter_add_sorted_workspace_bytes(int64_t N, int K, int D);
 int lipvq_scatter_add_sorted_f32(const float* g, const int64_t* idx, float* gC, void* workspace, int64_t N, int K, int D,
-                                 void* stream);
+                                 int sequential, void* stream);
 
 /* Backward of lipvq_lipschitz_scale_f32: gWn [D][H] -> gW [D][H], gci [D]. */
 int lipvq_lipschitz_bwd_f32(const float* W, const float* ci, const float* gWn, float* gW, float* gci, int D,

@@ -64,7 +64,7 @@ SIGNATURES = {
     "lipvq_scatter_add_det_f32": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
     "lipvq_scatter_add_sorted_supported": (_i, [_i64, _i, _i]),
     "lipvq_scatter_add_sorted_workspace_bytes": (_sz, [_i64, _i, _i]),
-    "lipvq_scatter_add_sorted_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "lipvq_scatter_add_sorted_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "lipvq_lipschitz_bwd_f32": (_i, [_vp] * 5 + [_i, _i, _vp]),
     "lipvq_scaled_diff_f32": (_i, [_vp, _vp, _vp, C.c_float, _vp, _vp, _i64, _vp]),
     "lipvq_linear_f32": (_i, [_vp] * 4 + [_i64, _i, _i, _vp]),

@@ -197,25 +197,29 @@ __device__ __forceinline__ int scs_code_of_item(const int* itemoff, int K, int i
 }
 
 // One wave per (segment, slice of 64 columns): lane = column; rows in sorted (= ascending row) order, one fp32 chain per column.
+// SEQUENTIAL: a segment is ALL rows of a code (item = code): the strictly sequential order of lipvq_scatter_add_det_f32.
+template <bool SEQUENTIAL>
 __global__ __launch_bounds__(256) void sc_sum_kernel(const float* __restrict__ g, const int* __restrict__ perm,
                                                      const int* __restrict__ offsets, const int* __restrict__ itemoff,
                                                      float* __restrict__ partial, float* __restrict__ gC, int K, int D, int slices) {
     extern __shared__ int sc_io[];                            // itemoff [K + 1]: the binary search below runs on LDS
-    for (int i = threadIdx.x; i <= K; i += 256) sc_io[i] = itemoff[i];
-    __syncthreads();
+    if (!SEQUENTIAL) {
+        for (int i = threadIdx.x; i <= K; i += 256) sc_io[i] = itemoff[i];
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int item = (int)(wid / slices), slice = (int)(wid % slices);
-    if (item >= sc_io[K]) return;                             // (wave-uniform; no barrier below)
-    const int k = scs_code_of_item(sc_io, K, item);
-    const int seg = item - sc_io[k];
-    const int p0 = offsets[k] + seg * SCS_SEG;
-    int p1 = p0 + SCS_SEG;
+    if (item >= (SEQUENTIAL ? K : sc_io[K])) return;          // (wave-uniform; no barrier below)
+    const int k = SEQUENTIAL ? item : scs_code_of_item(sc_io, K, item);
+    const int p0 = SEQUENTIAL ? offsets[k] : offsets[k] + (item - sc_io[k]) * SCS_SEG;
+    int p1 = SEQUENTIAL ? offsets[k + 1] : p0 + SCS_SEG;
     if (p1 > offsets[k + 1]) p1 = offsets[k + 1];
+    if (p1 <= p0) return;                                     // (a code without rows)
     const int col = 64 * slice + lane;
     const bool cv = col < D;
     const float* __restrict__ gc = g + (cv ? col : 0);
-    float acc = 0.0f;
+    float acc = SEQUENTIAL && cv ? gC[(size_t)k * D + col] : 0.0f;     // sequential: the chain starts from what gC holds, like index_add_
     for (int p = p0; p < p1; p += 64) {
         const int mine = p + lane < p1 ? perm[p + lane] : 0;  // (lanes past the end: row 0, loaded and not added)
         const int n = p1 - p < 64 ? p1 - p : 64;
@@ -236,6 +240,7 @@ __global__ __launch_bounds__(256) void sc_sum_kernel(const float* __restrict__ g
         }
     }
     if (!cv) return;
+    if (SEQUENTIAL) { gC[(size_t)k * D + col] = acc; return; }
     const bool single = sc_io[k + 1] - sc_io[k] == 1;         // the code's only segment: this wave owns gC[k][col]
     if (single) gC[(size_t)k * D + col] += acc;
     else partial[(size_t)item * D + col] = acc;
@@ -273,7 +278,7 @@ extern "C" size_t lipvq_scatter_add_sorted_workspace_bytes(int64_t N, int K, int
 }
 
 extern "C" int lipvq_scatter_add_sorted_f32(const float* g, const int64_t* idx, float* gC, void* workspace, int64_t N, int K, int D,
-                                            void* stream) {
+                                            int sequential, void* stream) {
     if (!g || !idx || !gC || !workspace) return fail(LIPVQ_EINVAL, "scatter_add_sorted: null pointer");
     if (!lipvq_scatter_add_sorted_supported(N, K, D))
         return fail(LIPVQ_EUNSUPPORTED, "scatter_add_sorted: N=%lld K=%d D=%d outside the supported range (N >= 32768, K <= %d)",
@@ -296,16 +301,22 @@ extern "C" int lipvq_scatter_add_sorted_f32(const float* g, const int64_t* idx, 
         if (int rc = lipvq_reserve_lds(reserved_place, (const void*)sc_place_kernel, lds_place, "scatter_add_sorted")) return rc;
     if (lds_count > 64 * 1024)
         if (int rc = lipvq_reserve_lds(reserved_count, (const void*)sc_count_kernel, lds_count, "scatter_add_sorted")) return rc;
-    if (lds_sum > 64 * 1024)
-        if (int rc = lipvq_reserve_lds(reserved_sum, (const void*)sc_sum_kernel, lds_sum, "scatter_add_sorted")) return rc;
+    if (lds_sum > 64 * 1024 && !sequential)
+        if (int rc = lipvq_reserve_lds(reserved_sum, (const void*)sc_sum_kernel<false>, lds_sum, "scatter_add_sorted")) return rc;
     hipLaunchKernelGGL(sc_count_kernel, dim3(nb), dim3(64 * waves), lds_count, st, idx, cnt, N, K);
     hipLaunchKernelGGL(sc_scan_blocks_kernel, dim3((K + 63) / 64), dim3(1024), 0, st, cnt, tot, nb, K);
     hipLaunchKernelGGL(sc_scan_codes_kernel, dim3(1), dim3(1024), 0, st, tot, offsets, itemoff, K);
     hipLaunchKernelGGL(sc_place_kernel, dim3(nb), dim3(64 * waves), lds_place, st, idx, cnt, offsets, perm, N, K, bits);
     const int slices = (D + 63) / 64;
+    if (sequential) {                                          // one chain per (code, column) over ALL its rows in ascending row order
+        const int64_t nwaves = (int64_t)K * slices;
+        hipLaunchKernelGGL(sc_sum_kernel<true>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, g, perm, offsets, itemoff, partial, gC,
+                           K, D, slices);
+        return check_launch("scatter_add_sorted");
+    }
     const int64_t nwaves = scs_max_items(N, K) * slices;
-    hipLaunchKernelGGL(sc_sum_kernel, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), lds_sum, st, g, perm, offsets, itemoff, partial, gC, K,
-                       D, slices);
+    hipLaunchKernelGGL(sc_sum_kernel<false>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), lds_sum, st, g, perm, offsets, itemoff, partial,
+                       gC, K, D, slices);
     hipLaunchKernelGGL(sc_combine_kernel, dim3(K), dim3(256), 0, st, partial, itemoff, gC, K, D);
     return check_launch("scatter_add_sorted");
 }

@@ -221,23 +221,33 @@ def wgrad(G, H, h_act=ACT_NONE, hidx=None, want_bias=True):
 
 def scatter_add(g, idx, K, deterministic=None, route=None):
     """gC[k] = sum of the rows of g whose idx is k (the gather's backward / index_add_).  deterministic=None follows
-    torch.are_deterministic_algorithms_enabled(): the strictly sequential kernel.  Otherwise batches of 65 536 rows and
-    more take the counting-sort route (no floating-point atomics, reproducible run to run; csrc/lipvq_scatter.hip: 70 vs
-    185 us at N = 524 288, D = 64; on a par at 65 536) and smaller ones fp32 atomics.  route="atomics" | "sorted" forces one (tests, measurements)."""
+    torch.are_deterministic_algorithms_enabled(): strictly ascending row order per code, bit-identical to a sequential fp32
+    index_add_.  Large batches go through a stable counting sort of the rows by code (csrc/lipvq_scatter.hip; no
+    floating-point atomics): deterministic from 32 768 rows on (2.6 ms -> 0.1 ms at N = 524 288), otherwise from 65 536 rows
+    on in 256-row segments (reproducible run to run; 70 vs 185 us) -- smaller batches: the scanning kernel / fp32 atomics.
+    route = "atomics" | "sorted" | "sequential_sorted" | "sequential_scan" forces one (tests, measurements)."""
     g, idx = _chk(g, "g"), _chk(idx, "idx", torch.int64)
     N, D = g.shape
     if deterministic is None:
         deterministic = torch.are_deterministic_algorithms_enabled()
+    if route is None:
+        sortable = bool(lib.lipvq_scatter_add_sorted_supported(N, K, D))
+        if deterministic:
+            route = "sequential_sorted" if sortable else "sequential_scan"
+        else:
+            route = "sorted" if (sortable and N >= 65536) else "atomics"
     gC = torch.zeros((K, D), device=g.device, dtype=torch.float32)
     with _on(g.device):
-        if deterministic and route is None:
+        if route == "sequential_scan":
             check(lib.lipvq_scatter_add_det_f32(_ptr(g), _ptr(idx), _ptr(gC), N, K, D, _stream()), "lipvq_scatter_add_det_f32")
-        elif route == "sorted" or (route is None and N >= 65536 and lib.lipvq_scatter_add_sorted_supported(N, K, D)):
+        elif route in ("sorted", "sequential_sorted"):
             ws = torch.empty(lib.lipvq_scatter_add_sorted_workspace_bytes(N, K, D), device=g.device, dtype=torch.uint8)
-            check(lib.lipvq_scatter_add_sorted_f32(_ptr(g), _ptr(idx), _ptr(gC), _ptr(ws), N, K, D, _stream()),
-                  "lipvq_scatter_add_sorted_f32")
-        else:
+            check(lib.lipvq_scatter_add_sorted_f32(_ptr(g), _ptr(idx), _ptr(gC), _ptr(ws), N, K, D,
+                                                   1 if route == "sequential_sorted" else 0, _stream()), "lipvq_scatter_add_sorted_f32")
+        elif route == "atomics":
             check(lib.lipvq_scatter_add_f32(_ptr(g), _ptr(idx), _ptr(gC), N, K, D, _stream()), "lipvq_scatter_add_f32")
+        else:
+            raise ValueError(f"scatter_add: unknown route {route!r}")
     return gC
 
 

@@ -188,9 +188,10 @@ def test_ste_and_mse(ops, oracle):
     assert abs(out[0] - a) <= 1e-6 * abs(a) and abs(out[1] - b) <= 1e-6 * abs(b)
 
 
-@pytest.mark.parametrize("N,K,D", [(5000, 37, 64), (80, 1024, 208), (70001, 256, 32)])
+@pytest.mark.parametrize("N,K,D", [(5000, 37, 64), (80, 1024, 208), (70001, 256, 32), (40000, 1024, 208), (33001, 5000, 7)])
 def test_scatter_add_deterministic_is_sequential_fp32(N, K, D):
-    """lipvq_scatter_add_det_f32 equals a sequential fp32 index_add_ over rows 0..N-1, bit for bit, on every run."""
+    """Deterministic mode equals a sequential fp32 index_add_ over rows 0..N-1, bit for bit, on every run -- both the
+    scanning kernel (lipvq_scatter_add_det_f32) and, from 32 768 rows on, the counting-sort route in sequential mode."""
     from lipvq_vae_amd import ops
     rng = np.random.default_rng(N)
     g = rng.standard_normal((N, D)).astype(np.float32)
@@ -203,7 +204,10 @@ def test_scatter_add_deterministic_is_sequential_fp32(N, K, D):
     a = ops.scatter_add(gt, it, K, deterministic=True)
     b = ops.scatter_add(gt, it, K, deterministic=True)
     assert torch.equal(a, b) and np.array_equal(a.cpu().numpy(), want)
-    c = ops.scatter_add(gt, it, K, deterministic=False).cpu().numpy()          # atomics: same sum up to fp32 ordering
+    assert np.array_equal(ops.scatter_add(gt, it, K, route="sequential_scan").cpu().numpy(), want)
+    if N >= 32768:
+        assert np.array_equal(ops.scatter_add(gt, it, K, route="sequential_sorted").cpu().numpy(), want)
+    c = ops.scatter_add(gt, it, K, deterministic=False).cpu().numpy()          # atomics / segments: same sum up to fp32 ordering
     assert np.abs(c - want).max() <= 1e-4 * (1 + np.abs(want).max())
 
 
