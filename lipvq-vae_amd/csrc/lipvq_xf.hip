@@ -123,28 +123,29 @@ extern "C" int lipvq_spectral_norm_bwd_f32(const float* gWsn, const float* Wsn, 
 #define XF_KT 64
 __device__ __forceinline__ float xf_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 
+template <int DH>
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, float* __restrict__ lse,
                                                         const unsigned char* __restrict__ keep, float inv_keep, int S, int D, int H) {
-    __shared__ float sk[XF_KT][XF_DH + 1], svv[XF_KT][XF_DH + 1];
+    __shared__ float sk[XF_KT][DH + 1], svv[XF_KT][DH + 1];
     const int dh = D / H, h = blockIdx.y;
     const int tid = threadIdx.x, qi = tid >> 4, p = tid & 15;
     const int q = blockIdx.x * XF_QB + qi;
     const int qc = q < S ? q : S - 1;
     const float scale = 1.0f / lq_sqrt((float)dh);
-    float qr[XF_DH], acc[XF_DH];
+    float qr[DH], acc[DH];
 #pragma unroll
-    for (int d = 0; d < XF_DH; ++d) {
+    for (int d = 0; d < DH; ++d) {
         qr[d] = d < dh ? qkv[(size_t)qc * 3 * D + h * dh + d] * scale : 0.0f;
         acc[d] = 0.0f;
     }
     float m = -INFINITY, l = 0.0f;
     for (int k0 = 0; k0 < S; k0 += XF_KT) {
         __syncthreads();
-        for (int i = tid; i < XF_KT * dh; i += 256) {
-            const int j = i / dh, d = i - j * dh;
+        for (int i = tid; i < XF_KT * DH; i += 256) {
+            const int j = i / DH, d = i - j * DH;
             const int kj = k0 + j < S ? k0 + j : S - 1;
-            sk[j][d] = qkv[(size_t)kj * 3 * D + D + h * dh + d];
-            svv[j][d] = qkv[(size_t)kj * 3 * D + 2 * D + h * dh + d];
+            sk[j][d] = d < dh ? qkv[(size_t)kj * 3 * D + D + h * dh + d] : 0.0f;            // (columns past the head width: zeros)
+            svv[j][d] = d < dh ? qkv[(size_t)kj * 3 * D + 2 * D + h * dh + d] : 0.0f;
         }
         __syncthreads();
 #pragma unroll
@@ -153,15 +154,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
             if (k0 + j < S) {
                 float s = 0.0f;
 #pragma unroll
-                for (int d = 0; d < XF_DH; ++d)
-                    if (d < dh) s = lq_fma(qr[d], sk[j][d], s);
+                for (int d = 0; d < DH; ++d)
+                    s = lq_fma(qr[d], sk[j][d], s);
                 const float mn = fmaxf(m, s);
                 const float c = xf_exp(m - mn), e = xf_exp(s - mn);
                 l = lq_fma(l, c, e);
                 const float w = keep ? (keep[((size_t)h * S + qc) * S + k0 + j] ? e * inv_keep : 0.0f) : e;
 #pragma unroll
-                for (int d = 0; d < XF_DH; ++d)
-                    if (d < dh) acc[d] = lq_fma(acc[d], c, w * svv[j][d]);
+                for (int d = 0; d < DH; ++d)
+                    acc[d] = lq_fma(acc[d], c, w * svv[j][d]);
                 m = mn;
             }
         }
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 #pragma unroll
     for (int off = 1; off < 16; off <<= 1) l += __shfl_xor(l, off, 64);
 #pragma unroll
-    for (int d = 0; d < XF_DH; ++d) {
+    for (int d = 0; d < DH; ++d) {
         float a = acc[d] * c;
 #pragma unroll
         for (int off = 1; off < 16; off <<= 1) a += __shfl_xor(a, off, 64);
@@ -194,7 +195,10 @@ extern "C" int lipvq_attention_f32(const float* qkv, float* out, float* lse, con
     if (S <= 0 || D <= 0 || H <= 0 || D % H != 0 || D / H > XF_DH)
         return fail(LIPVQ_EUNSUPPORTED, "attention: S=%lld D=%d H=%d (head width 1..%d)", (long long)S, D, H, XF_DH);
     if (S > 65535LL * XF_QB || (keep && !(keep_prob > 0.0f))) return fail(LIPVQ_EINVAL, "attention: bad S / keep_prob");
-    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)((S + XF_QB - 1) / XF_QB), H), dim3(256), 0, (hipStream_t)stream, qkv, out, lse,
+    // head width padded to 8, 16 or 32 columns (compile-time loops: the reference's 8 heads give 8 at D = 64, 26 at D = 208)
+    const int dh = D / H;
+    auto kfn = dh <= 8 ? attention_kernel<8> : (dh <= 16 ? attention_kernel<16> : attention_kernel<32>);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)((S + XF_QB - 1) / XF_QB), H), dim3(256), 0, (hipStream_t)stream, qkv, out, lse,
                        keep, keep ? 1.0f / keep_prob : 1.0f, (int)S, D, H);
     return check_launch("attention");
 }
@@ -202,20 +206,21 @@ extern "C" int lipvq_attention_f32(const float* qkv, float* out, float* lse, con
 // Backward.  delta[h][i] = sum_d dO[i][hd] O[i][hd];  P_ij = exp(s_ij - lse_i);  dP_ij = (keep_ij / keep_prob) dO_i . V_j;
 // dS_ij = P_ij (dP_ij - delta_i);  dQ_i = scale sum_j dS_ij K_j;  dK_j = scale sum_i dS_ij Q_i;  dV_j = sum_i (keep_ij/keep_prob) P_ij dO_i.
 // attention_bwd_q: workgroup = 16 queries x 16 key lanes (as the forward) -> dQ;  attention_bwd_kv: 16 keys x 16 query lanes -> dK, dV.
+template <int DH>
 __global__ __launch_bounds__(256) void attention_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
                                                               const float* __restrict__ go, const float* __restrict__ lse,
                                                               float* __restrict__ gqkv, float* __restrict__ delta,
                                                               const unsigned char* __restrict__ keep, float inv_keep, int S, int D, int H) {
-    __shared__ float sk[XF_KT][XF_DH + 1], svv[XF_KT][XF_DH + 1];
+    __shared__ float sk[XF_KT][DH + 1], svv[XF_KT][DH + 1];
     const int dh = D / H, h = blockIdx.y;
     const int tid = threadIdx.x, qi = tid >> 4, p = tid & 15;
     const int q = blockIdx.x * XF_QB + qi;
     const int qc = q < S ? q : S - 1;
     const float scale = 1.0f / lq_sqrt((float)dh);
-    float qr[XF_DH], gor[XF_DH], acc[XF_DH];
+    float qr[DH], gor[DH], acc[DH];
     float dl = 0.0f;
 #pragma unroll
-    for (int d = 0; d < XF_DH; ++d) {
+    for (int d = 0; d < DH; ++d) {
         qr[d] = d < dh ? qkv[(size_t)qc * 3 * D + h * dh + d] * scale : 0.0f;
         gor[d] = d < dh ? go[(size_t)qc * D + h * dh + d] : 0.0f;
         if (d < dh) dl = lq_fma(gor[d], o[(size_t)qc * D + h * dh + d], dl);
@@ -225,11 +230,11 @@ __global__ __launch_bounds__(256) void attention_bwd_q_kernel(const float* __res
     if (p == 0 && q < S) delta[(size_t)h * S + q] = dl;
     for (int k0 = 0; k0 < S; k0 += XF_KT) {
         __syncthreads();
-        for (int i = tid; i < XF_KT * dh; i += 256) {
-            const int j = i / dh, d = i - j * dh;
+        for (int i = tid; i < XF_KT * DH; i += 256) {
+            const int j = i / DH, d = i - j * DH;
             const int kj = k0 + j < S ? k0 + j : S - 1;
-            sk[j][d] = qkv[(size_t)kj * 3 * D + D + h * dh + d];
-            svv[j][d] = qkv[(size_t)kj * 3 * D + 2 * D + h * dh + d];
+            sk[j][d] = d < dh ? qkv[(size_t)kj * 3 * D + D + h * dh + d] : 0.0f;
+            svv[j][d] = d < dh ? qkv[(size_t)kj * 3 * D + 2 * D + h * dh + d] : 0.0f;
         }
         __syncthreads();
 #pragma unroll
@@ -238,19 +243,19 @@ __global__ __launch_bounds__(256) void attention_bwd_q_kernel(const float* __res
             if (k0 + j < S) {
                 float s = 0.0f, dp = 0.0f;
 #pragma unroll
-                for (int d = 0; d < XF_DH; ++d)
-                    if (d < dh) { s = lq_fma(qr[d], sk[j][d], s); dp = lq_fma(gor[d], svv[j][d], dp); }
+                for (int d = 0; d < DH; ++d)
+                    { s = lq_fma(qr[d], sk[j][d], s); dp = lq_fma(gor[d], svv[j][d], dp); }
                 const float pr = xf_exp(s - ls);
                 if (keep) dp = keep[((size_t)h * S + qc) * S + k0 + j] ? dp * inv_keep : 0.0f;
                 const float ds = pr * (dp - dl) * scale;
 #pragma unroll
-                for (int d = 0; d < XF_DH; ++d)
-                    if (d < dh) acc[d] = lq_fma(ds, sk[j][d], acc[d]);
+                for (int d = 0; d < DH; ++d)
+                    acc[d] = lq_fma(ds, sk[j][d], acc[d]);
             }
         }
     }
 #pragma unroll
-    for (int d = 0; d < XF_DH; ++d) {
+    for (int d = 0; d < DH; ++d) {
         float a = acc[d];
 #pragma unroll
         for (int off = 1; off < 16; off <<= 1) a += __shfl_xor(a, off, 64);
@@ -260,31 +265,32 @@ __global__ __launch_bounds__(256) void attention_bwd_q_kernel(const float* __res
         for (int d = p; d < dh; d += 16) gqkv[(size_t)q * 3 * D + h * dh + d] = acc[d];
 }
 
+template <int DH>
 __global__ __launch_bounds__(256) void attention_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ go,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                float* __restrict__ gqkv, const unsigned char* __restrict__ keep,
                                                                float inv_keep, int S, int D, int H) {
-    __shared__ float sq[XF_KT][XF_DH + 1], sg[XF_KT][XF_DH + 1];
+    __shared__ float sq[XF_KT][DH + 1], sg[XF_KT][DH + 1];
     __shared__ float sl[XF_KT], sd[XF_KT];
     const int dh = D / H, h = blockIdx.y;
     const int tid = threadIdx.x, ki = tid >> 4, p = tid & 15;
     const int k = blockIdx.x * XF_QB + ki;
     const int kc = k < S ? k : S - 1;
     const float scale = 1.0f / lq_sqrt((float)dh);
-    float kr[XF_DH], vr[XF_DH], ak[XF_DH], av[XF_DH];
+    float kr[DH], vr[DH], ak[DH], av[DH];
 #pragma unroll
-    for (int d = 0; d < XF_DH; ++d) {
+    for (int d = 0; d < DH; ++d) {
         kr[d] = d < dh ? qkv[(size_t)kc * 3 * D + D + h * dh + d] : 0.0f;
         vr[d] = d < dh ? qkv[(size_t)kc * 3 * D + 2 * D + h * dh + d] : 0.0f;
         ak[d] = 0.0f; av[d] = 0.0f;
     }
     for (int q0 = 0; q0 < S; q0 += XF_KT) {
         __syncthreads();
-        for (int i = tid; i < XF_KT * dh; i += 256) {
-            const int j = i / dh, d = i - j * dh;
+        for (int i = tid; i < XF_KT * DH; i += 256) {
+            const int j = i / DH, d = i - j * DH;
             const int qj = q0 + j < S ? q0 + j : S - 1;
-            sq[j][d] = qkv[(size_t)qj * 3 * D + h * dh + d] * scale;
-            sg[j][d] = go[(size_t)qj * D + h * dh + d];
+            sq[j][d] = d < dh ? qkv[(size_t)qj * 3 * D + h * dh + d] * scale : 0.0f;
+            sg[j][d] = d < dh ? go[(size_t)qj * D + h * dh + d] : 0.0f;
         }
         if (tid < XF_KT) {
             const int qj = q0 + tid < S ? q0 + tid : S - 1;
@@ -298,21 +304,21 @@ __global__ __launch_bounds__(256) void attention_bwd_kv_kernel(const float* __re
             if (q0 + j < S) {
                 float s = 0.0f, dp = 0.0f;
 #pragma unroll
-                for (int d = 0; d < XF_DH; ++d)
-                    if (d < dh) { s = lq_fma(sq[j][d], kr[d], s); dp = lq_fma(sg[j][d], vr[d], dp); }
+                for (int d = 0; d < DH; ++d)
+                    { s = lq_fma(sq[j][d], kr[d], s); dp = lq_fma(sg[j][d], vr[d], dp); }
                 const float pr = xf_exp(s - sl[j]);
                 float kp = 1.0f;
                 if (keep) kp = keep[((size_t)h * S + q0 + j) * S + kc] ? inv_keep : 0.0f;
                 const float ds = pr * (dp * kp - sd[j]);          // (the forward's q was pre-scaled: dK_j = sum_i dS_ij (scale Q_i))
                 const float pv = pr * kp;
 #pragma unroll
-                for (int d = 0; d < XF_DH; ++d)
-                    if (d < dh) { ak[d] = lq_fma(ds, sq[j][d], ak[d]); av[d] = lq_fma(pv, sg[j][d], av[d]); }
+                for (int d = 0; d < DH; ++d)
+                    { ak[d] = lq_fma(ds, sq[j][d], ak[d]); av[d] = lq_fma(pv, sg[j][d], av[d]); }
             }
         }
     }
 #pragma unroll
-    for (int d = 0; d < XF_DH; ++d) {
+    for (int d = 0; d < DH; ++d) {
         float a = ak[d], b = av[d];
 #pragma unroll
         for (int off = 1; off < 16; off <<= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
@@ -333,8 +339,11 @@ extern "C" int lipvq_attention_bwd_f32(const float* qkv, const float* out, const
     if (S > 65535LL * XF_QB || (keep && !(keep_prob > 0.0f))) return fail(LIPVQ_EINVAL, "attention_bwd: bad S / keep_prob");
     const dim3 grid((unsigned)((S + XF_QB - 1) / XF_QB), H);
     const float ik = keep ? 1.0f / keep_prob : 1.0f;
-    hipLaunchKernelGGL(attention_bwd_q_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, gout, lse, gqkv, delta, keep, ik, (int)S, D, H);
-    hipLaunchKernelGGL(attention_bwd_kv_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, gout, lse, delta, gqkv, keep, ik, (int)S, D, H);
+    const int dh = D / H;
+    auto kq = dh <= 8 ? attention_bwd_q_kernel<8> : (dh <= 16 ? attention_bwd_q_kernel<16> : attention_bwd_q_kernel<32>);
+    auto kkv = dh <= 8 ? attention_bwd_kv_kernel<8> : (dh <= 16 ? attention_bwd_kv_kernel<16> : attention_bwd_kv_kernel<32>);
+    hipLaunchKernelGGL(kq, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, gout, lse, gqkv, delta, keep, ik, (int)S, D, H);
+    hipLaunchKernelGGL(kkv, grid, dim3(256), 0, (hipStream_t)stream, qkv, gout, lse, delta, gqkv, keep, ik, (int)S, D, H);
     return check_launch("attention_bwd");
 }
 
