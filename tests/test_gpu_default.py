@@ -66,7 +66,9 @@ def _attention_ref(qkv, H, keep, keep_prob):
 
 
 @pytest.mark.parametrize("S,D,H,drop", [(80, 208, 8, False), (203, 64, 8, True), (1, 64, 8, False), (17, 256, 8, True),
-                                        (1000, 208, 8, False), (65, 32, 4, True)])
+                                        (1000, 208, 8, False), (65, 32, 4, True),
+                                        # one case per padded head width (8, 16, 32 columns) with heads narrower than the padding
+                                        (130, 128, 8, True), (77, 24, 8, False), (300, 104, 8, True), (2100, 64, 8, False)])
 def test_attention_forward_backward(ops, S, D, H, drop):
     g = torch.Generator().manual_seed(S + D)
     qkv = torch.randn(S, 3 * D, generator=g)
