@@ -87,6 +87,14 @@ size_t lipvq_mse_workspace_bytes(void);
 int lipvq_mse_pair_f32(const float* xr, const float* x, int64_t nx, const float* zq, const float* ze,
                        int64_t nz, float* out2, void* workspace, void* stream);
 
+/* The same two means in out3[0], out3[1], plus out3[2] = the tokenizer's loss built from them on the device in the
+ * reference's fp32 association:  LIPVQ_LOSS_LLFQ  (m0 + w m1) + w m1   (backbone_lfqvae_v5.py:83, w = 0.25)
+ *                                LIPVQ_LOSS_VQ    m0 + (m1 + w m1)     (backbone.py:50-51, 69-71, w = commitment_cost). */
+#define LIPVQ_LOSS_LLFQ 0
+#define LIPVQ_LOSS_VQ 1
+int lipvq_mse_pair_loss_f32(const float* xr, const float* x, int64_t nx, const float* zq, const float* ze, int64_t nz,
+                            float* out3, float w, int form, void* workspace, void* stream);
+
 
 /* ---- nearest code, fast path: MFMA screening + exact re-scoring (same results as
  *      lipvq_nearest_f32(.., LIPVQ_DIST_NORM); design: lipvq-vae_amd/csrc/lipvq_screen.hip) ------ */
@@ -162,6 +170,10 @@ int lipvq_tokenize_fast_f32(const float* x, const float* packed, const void* pac
 size_t lipvq_mlp3_packed_bwd_floats(int K0, int J0, int J1, int J2);
 int lipvq_mlp3_pack_bwd_f32(const float* W0, const float* W1, const float* W2, float* packed, int K0,
                             int J0, int J1, int J2, void* stream);
+/* Two stacks' backward packs in one launch (small training steps are launch-count bound). */
+int lipvq_mlp3_pack_bwd2_f32(const float* aW0, const float* aW1, const float* aW2, float* a_packed, int aK0, int aJ0, int aJ1,
+                             int aJ2, const float* bW0, const float* bW1, const float* bW2, float* b_packed, int bK0, int bJ0,
+                             int bJ1, int bJ2, void* stream);
 int lipvq_mlp3_bwd_f32(const float* gy, const float* pre0, const float* pre1, const float* pre2,
                        const float* packed_bwd, float* g2, float* g1, float* g0, float* gx, int64_t N,
                        int K0, int J0, int J1, int J2, int act0, int act1, int act2, void* stream);

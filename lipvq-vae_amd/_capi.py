@@ -40,6 +40,7 @@ SIGNATURES = {
     "lipvq_ste_f32": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "lipvq_mse_workspace_bytes": (_sz, []),
     "lipvq_mse_pair_f32": (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "lipvq_mse_pair_loss_f32": (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, C.c_float, _i, _vp, _vp]),
     "lipvq_nearest_prep_bytes": (_sz, [_i, _i]),
     "lipvq_nearest_prepare_f32": (_i, [_vp, _vp, _i, _i, _vp]),
     "lipvq_nearest_screened_supported": (_i, [_i, _i]),
@@ -57,6 +58,7 @@ SIGNATURES = {
     "lipvq_tokenize_fast_f32": (_i, [_vp] * 10 + [_i64] + [_i] * 5 + [_vp]),
     "lipvq_mlp3_packed_bwd_floats": (_sz, [_i, _i, _i, _i]),
     "lipvq_mlp3_pack_bwd_f32": (_i, [_vp] * 4 + [_i] * 4 + [_vp]),
+    "lipvq_mlp3_pack_bwd2_f32": (_i, [_vp] * 4 + [_i] * 4 + [_vp] * 4 + [_i] * 4 + [_vp]),
     "lipvq_mlp3_bwd_f32": (_i, [_vp] * 9 + [_i64] + [_i] * 7 + [_vp]),
     "lipvq_wgrad_workspace_bytes": (_sz, [_i64, _i, _i]),
     "lipvq_wgrad_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _i, _vp]),

@@ -63,9 +63,8 @@ class _LLFQFn(torch.autograd.Function):
             x_rec, pre_d = ops.mlp3(codebook, dec_packed, _DEC_ACTS, gather_idx=idx, save_pre=True)
         else:
             x_rec, pre_d = ops.mlp3(codebook, dec_packed, _DEC_ACTS, gather_idx=idx), None
-        mse = ops.mse_pair(x_rec, x, z_q, z_e)
-        q = mse[1] * 0.25
-        loss = (mse[0] + q) + q          # recon + 0.25*commit + 0.25*codebook, left to right (v5:83)
+        # recon + 0.25*commit + 0.25*codebook, left to right (v5:83): (m0 + q) + q with q = 0.25 m1, evaluated by the mse launch
+        loss = ops.mse_pair_loss(x_rec, x, z_q, z_e, 0.25, ops.LOSS_LLFQ)[2]
         module.last_indices = idx
         ctx.module = module
         if need_grad:
@@ -127,9 +126,8 @@ class _VQFn(torch.autograd.Function):
             x_rec, pre_d = ops.mlp3(z_st, dec_packed, _RELU3, save_pre=True)
         else:
             x_rec, pre_d = ops.mlp3(z_st, dec_packed, _RELU3), None
-        mse = ops.mse_pair(x_rec, x, z_q, z_e)
-        q_loss = mse[1] + module.commitment_cost * mse[1]          # vq:69-71
-        loss = mse[0] + q_loss                                     # vq:50-51
+        # q_loss = m1 + commitment_cost m1 (vq:69-71); loss = m0 + q_loss (vq:50-51): evaluated by the mse launch
+        loss = ops.mse_pair_loss(x_rec, x, z_q, z_e, float(module.commitment_cost), ops.LOSS_VQ)[2]
         module.last_indices = idx
         ctx.module = module
         if need_grad:

@@ -35,7 +35,8 @@ def llfq_backward(module, saved, g_loss):
     # recon = mean((x_rec - x)^2)  ->  d/dx_rec
     g_xrec = ops.scaled_diff(x_rec, x, 2.0 / (N * A), gscale=g)
     # decoder + to_output (input = codebook[idx])
-    pk = ops.mlp3_pack_bwd(dec0.weight.detach(), dec2.weight.detach(), outl.weight.detach())
+    pk, pk_enc = ops.mlp3_pack_bwd2((dec0.weight.detach(), dec2.weight.detach(), outl.weight.detach()),
+                                    (enc0.weight.detach(), enc2.weight.detach(), Wn))          # both stacks, one launch
     _, g1d, g0d, g_zq_dec = ops.mlp3_bwd(g_xrec, (pd0, pd1, None), pk, _DEC_ACTS, want_gx=True)
     gWd0, gbd0, gWd2, gbd2, gWo, gbo = _stack_grads(cb, (pd0, pd1), g_xrec, g1d, g0d, _DEC_ACTS, hidx=idx)
     # codebook: decoder path + 0.25 * codebook loss
@@ -43,8 +44,7 @@ def llfq_backward(module, saved, g_loss):
     g_cb = ops.scatter_add(g_zq, idx, K)
     # encoder side: 0.25 * commitment loss only (no straight-through estimator, v5:74-81)
     g_ze = ops.scaled_diff(z_e, z_q, 0.25 * 2.0 / (N * D), gscale=g)
-    pk = ops.mlp3_pack_bwd(enc0.weight.detach(), enc2.weight.detach(), Wn)
-    g2e, g1e, g0e, _ = ops.mlp3_bwd(g_ze, (pe0, pe1, pe2), pk, _ENC_ACTS, want_gx=False)
+    g2e, g1e, g0e, _ = ops.mlp3_bwd(g_ze, (pe0, pe1, pe2), pk_enc, _ENC_ACTS, want_gx=False)
     gWe0, gbe0, gWe2, gbe2, gWn, gbl = _stack_grads(x, (pe0, pe1), g2e, g1e, g0e, _ENC_ACTS)
     gWl, gci = ops.lipschitz_bwd(module.to_latent.W.detach(), module.to_latent.ci.detach(), gWn)
     return (gWe0, gbe0, gWe2, gbe2, gWl, gbl, gci, g_cb, gWd0, gbd0, gWd2, gbd2, gWo, gbo)
@@ -62,7 +62,8 @@ def vq_backward(module, saved, g_loss):
     e, d = module.encoder, module.decoder
 
     g_xrec = ops.scaled_diff(x_rec, x, 2.0 / (N * A), gscale=g)
-    pk = ops.mlp3_pack_bwd(d[0].weight.detach(), d[2].weight.detach(), d[4].weight.detach())
+    pk, pk_enc = ops.mlp3_pack_bwd2((d[0].weight.detach(), d[2].weight.detach(), d[4].weight.detach()),
+                                    (e[0].weight.detach(), e[2].weight.detach(), e[4].weight.detach()))
     g2d, g1d, g0d, g_zst = ops.mlp3_bwd(g_xrec, (pd0, pd1, pd2), pk, _RELU3, want_gx=True)
     gWd0, gbd0, gWd2, gbd2, gWd4, gbd4 = _stack_grads(z_st, (pd0, pd1), g2d, g1d, g0d, _RELU3)
     # embedding loss mse(z_q, z_e.detach()) -> embedding rows only (the decoder sees z_e through the STE)
@@ -70,7 +71,7 @@ def vq_backward(module, saved, g_loss):
     g_emb = ops.scatter_add(g_zq, idx, K)
     # z_e: straight-through decoder gradient + commitment
     g_ze = ops.scaled_diff(z_e, z_q, cc * 2.0 / (N * D), gscale=g, c=g_zst)
-    pk = ops.mlp3_pack_bwd(e[0].weight.detach(), e[2].weight.detach(), e[4].weight.detach())
+    pk = pk_enc
     g2e, g1e, g0e, _ = ops.mlp3_bwd(g_ze, (pe0, pe1, pe2), pk, _RELU3, want_gx=False)
     gWe0, gbe0, gWe2, gbe2, gWe4, gbe4 = _stack_grads(x, (pe0, pe1), g2e, g1e, g0e, _RELU3)
     return (gWe0, gbe0, gWe2, gbe2, gWe4, gbe4, gWd0, gbd0, gWd2, gbd2, gWd4, gbd4, g_emb)

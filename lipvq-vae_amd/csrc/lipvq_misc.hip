@@ -142,28 +142,47 @@ __global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restric
     if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
 }
 
+// out[0], out[1] = the two means; with `loss` also the tokenizer's loss from them in the reference's fp32 association
+// (LIPVQ_LOSS_LLFQ: (m0 + w m1) + w m1, backbone_lfqvae_v5.py:83;  LIPVQ_LOSS_VQ: m0 + (m1 + w m1), backbone.py:50-51,69-71) --
+// three tiny torch kernels per training step otherwise.
 __global__ __launch_bounds__(256) void mse_final_kernel(const double* __restrict__ partial, int64_t nx, int64_t nz,
-                                                        float* __restrict__ out2) {
+                                                        float* __restrict__ out, float* __restrict__ loss, float w, int form) {
     __shared__ double sh[4];
+    float m[2] = {0.0f, 0.0f};
     for (int which = 0; which < 2; ++which) {
         double acc = 0.0;
         for (int i = threadIdx.x; i < MSE_BLOCKS; i += blockDim.x) acc += partial[which * MSE_BLOCKS + i];
         const double t = block_sum(acc, sh);
-        if (threadIdx.x == 0) out2[which] = (float)(t / (double)(which == 0 ? nx : nz));
+        m[which] = (float)(t / (double)(which == 0 ? nx : nz));
+        if (threadIdx.x == 0) out[which] = m[which];
+    }
+    if (loss && threadIdx.x == 0) {
+        const float q = w * m[1];
+        *loss = form == LIPVQ_LOSS_VQ ? m[0] + (m[1] + q) : (m[0] + q) + q;
     }
 }
 
 extern "C" size_t lipvq_mse_workspace_bytes(void) { return 2 * MSE_BLOCKS * sizeof(double); }
 
-extern "C" int lipvq_mse_pair_f32(const float* xr, const float* x, int64_t nx, const float* zq,
-                                  const float* ze, int64_t nz, float* out2, void* workspace, void* stream) {
-    if (!xr || !x || !zq || !ze || !out2 || !workspace || nx <= 0 || nz <= 0)
-        return fail(LIPVQ_EINVAL, "mse_pair: bad argument");
+static int mse_pair_launch(const float* xr, const float* x, int64_t nx, const float* zq, const float* ze, int64_t nz, float* out,
+                           float* loss, float w, int form, void* workspace, void* stream, const char* who) {
+    if (!xr || !x || !zq || !ze || !out || !workspace || nx <= 0 || nz <= 0) return fail(LIPVQ_EINVAL, "%s: bad argument", who);
     hipStream_t st = (hipStream_t)stream;
     double* part = (double*)workspace;
     hipLaunchKernelGGL(mse_partial_kernel, dim3(MSE_BLOCKS, 2), dim3(256), 0, st, xr, x, nx, zq, ze, nz, part);
-    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, st, part, nx, nz, out2);
-    return check_launch("mse_pair");
+    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, st, part, nx, nz, out, loss, w, form);
+    return check_launch(who);
+}
+
+extern "C" int lipvq_mse_pair_f32(const float* xr, const float* x, int64_t nx, const float* zq,
+                                  const float* ze, int64_t nz, float* out2, void* workspace, void* stream) {
+    return mse_pair_launch(xr, x, nx, zq, ze, nz, out2, nullptr, 0.0f, 0, workspace, stream, "mse_pair");
+}
+
+extern "C" int lipvq_mse_pair_loss_f32(const float* xr, const float* x, int64_t nx, const float* zq, const float* ze, int64_t nz,
+                                       float* out3, float w, int form, void* workspace, void* stream) {
+    if (form != LIPVQ_LOSS_LLFQ && form != LIPVQ_LOSS_VQ) return fail(LIPVQ_EINVAL, "mse_pair_loss: unknown loss form %d", form);
+    return mse_pair_launch(xr, x, nx, zq, ze, nz, out3, out3 ? out3 + 2 : nullptr, w, form, workspace, stream, "mse_pair_loss");
 }
 
 

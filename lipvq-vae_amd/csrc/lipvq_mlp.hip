@@ -28,18 +28,20 @@
 struct PackLayer {
     const float* W;
     const float* b;
+    float* packed;             // the stack's packed buffer
     size_t oP, oB, n;          // offsets into the packed buffer; threads this layer needs
     int K, J, S, T, sf, sk;
 };
+#define PACK_MAX_LAYERS 6      // two stacks per launch
 struct PackArgs {
-    PackLayer l[3];
-    float* packed;
+    PackLayer l[PACK_MAX_LAYERS];
+    int nl;
 };
 
 __global__ void mlp3_pack_kernel(const PackArgs a) {
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     int li = 0;
-    if (gid >= a.l[0].n) { gid -= a.l[0].n; li = 1; if (gid >= a.l[1].n) { gid -= a.l[1].n; li = 2; } }
+    while (li < a.nl - 1 && gid >= a.l[li].n) { gid -= a.l[li].n; ++li; }
     const PackLayer& L = a.l[li];
     if (gid >= L.n) return;
     size_t nP = (size_t)L.T * L.S * 64;
@@ -49,9 +51,9 @@ __global__ void mlp3_pack_kernel(const PackArgs a) {
         int s = (int)(ts % L.S), t = (int)(ts / L.S);
         int f = 32 * t + feat_of_tile_row(lane & 31);
         int k = 2 * s + (lane >> 5);
-        a.packed[L.oP + gid] = (f < L.J && k < L.K) ? L.W[(size_t)f * L.sf + (size_t)k * L.sk] : 0.0f;
+        L.packed[L.oP + gid] = (f < L.J && k < L.K) ? L.W[(size_t)f * L.sf + (size_t)k * L.sk] : 0.0f;
     }
-    if (gid < (size_t)L.T * 32) a.packed[L.oB + gid] = (L.b && (int)gid < L.J) ? L.b[gid] : 0.0f;
+    if (gid < (size_t)L.T * 32) L.packed[L.oB + gid] = (L.b && (int)gid < L.J) ? L.b[gid] : 0.0f;
 }
 
 extern "C" size_t lipvq_mlp3_packed_floats(int K0, int J0, int J1, int J2) {
@@ -59,15 +61,20 @@ extern "C" size_t lipvq_mlp3_packed_floats(int K0, int J0, int J1, int J2) {
     return packed_layout(K0, J0, J1, J2).total;
 }
 
-static PackLayer pack_layer(const float* W, const float* b, size_t oP, size_t oB, int K, int J, int S, int T, int sf, int sk) {
+static PackLayer pack_layer(const float* W, const float* b, float* packed, size_t oP, size_t oB, int K, int J, int S, int T, int sf, int sk) {
     size_t n = (size_t)T * S * 64;
     if (n < (size_t)T * 32) n = (size_t)T * 32;
-    return PackLayer{W, b, oP, oB, n, K, J, S, T, sf, sk};
+    return PackLayer{W, b, packed, oP, oB, n, K, J, S, T, sf, sk};
 }
 
-static void pack_launch(const PackLayer& l0, const PackLayer& l1, const PackLayer& l2, float* packed, hipStream_t st) {
-    PackArgs a{{l0, l1, l2}, packed};
-    const size_t n = l0.n + l1.n + l2.n;
+static void pack_launch(const PackLayer* layers, int nl, hipStream_t st) {
+    PackArgs a;
+    size_t n = 0;
+    for (int i = 0; i < PACK_MAX_LAYERS; ++i) {
+        a.l[i] = layers[i < nl ? i : nl - 1];
+        if (i < nl) n += layers[i].n;
+    }
+    a.nl = nl;
     hipLaunchKernelGGL(mlp3_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
 }
 
@@ -85,9 +92,10 @@ extern "C" int lipvq_mlp3_pack_f32(const float* W0, const float* b0, const float
     if (int e = check_hidden("mlp3_pack", J0, J1)) return e;
     PackedLayout L = packed_layout(K0, J0, J1, J2);
     hipStream_t st = (hipStream_t)stream;
-    pack_launch(pack_layer(W0, b0, L.oP0, L.oB0, K0, J0, L.S0, L.T0, K0, 1),
-                pack_layer(W1, b1, L.oP1, L.oB1, J0, J1, L.S1, L.T1, J0, 1),
-                pack_layer(W2, b2, L.oP2, L.oB2, J1, J2, L.S2, L.T2, J1, 1), packed, st);
+    const PackLayer ls[3] = {pack_layer(W0, b0, packed, L.oP0, L.oB0, K0, J0, L.S0, L.T0, K0, 1),
+                             pack_layer(W1, b1, packed, L.oP1, L.oB1, J0, J1, L.S1, L.T1, J0, 1),
+                             pack_layer(W2, b2, packed, L.oP2, L.oB2, J1, J2, L.S2, L.T2, J1, 1)};
+    pack_launch(ls, 3, st);
     return check_launch("mlp3_pack");
 }
 
@@ -97,18 +105,39 @@ extern "C" size_t lipvq_mlp3_packed_bwd_floats(int K0, int J0, int J1, int J2) {
     return packed_layout(J2, J1, J0, K0).total;
 }
 
+// the three layers of one backward-data chain: layer 0' has in J2, out J1 and the virtual weight [J1][J2] = W2^T, i.e.
+// Wv[f][k] = W2[k][f] = W2[k*J1 + f]; and so on down the stack
+static void pack_bwd_layers(PackLayer* out, const float* W0, const float* W1, const float* W2, float* packed, int K0, int J0, int J1, int J2) {
+    const PackedLayout L = packed_layout(J2, J1, J0, K0);
+    out[0] = pack_layer(W2, nullptr, packed, L.oP0, L.oB0, J2, J1, L.S0, L.T0, 1, J1);
+    out[1] = pack_layer(W1, nullptr, packed, L.oP1, L.oB1, J1, J0, L.S1, L.T1, 1, J0);
+    out[2] = pack_layer(W0, nullptr, packed, L.oP2, L.oB2, J0, K0, L.S2, L.T2, 1, K0);
+}
+
 extern "C" int lipvq_mlp3_pack_bwd_f32(const float* W0, const float* W1, const float* W2, float* packed,
                                        int K0, int J0, int J1, int J2, void* stream) {
     if (!W0 || !W1 || !W2 || !packed) return fail(LIPVQ_EINVAL, "mlp3_pack_bwd: null pointer");
     if (K0 <= 0 || J2 <= 0) return fail(LIPVQ_EINVAL, "mlp3_pack_bwd: bad sizes");
     if (int e = check_hidden("mlp3_pack_bwd", J0, J1)) return e;
-    PackedLayout L = packed_layout(J2, J1, J0, K0);
-    hipStream_t st = (hipStream_t)stream;
-    // layer 0': in J2, out J1, virtual weight [J1][J2] = W2^T : Wv[f][k] = W2[k][f] = W2[k*J1 + f]
-    pack_launch(pack_layer(W2, nullptr, L.oP0, L.oB0, J2, J1, L.S0, L.T0, 1, J1),
-                pack_layer(W1, nullptr, L.oP1, L.oB1, J1, J0, L.S1, L.T1, 1, J0),
-                pack_layer(W0, nullptr, L.oP2, L.oB2, J0, K0, L.S2, L.T2, 1, K0), packed, st);
+    PackLayer ls[3];
+    pack_bwd_layers(ls, W0, W1, W2, packed, K0, J0, J1, J2);
+    pack_launch(ls, 3, (hipStream_t)stream);
     return check_launch("mlp3_pack_bwd");
+}
+
+// Two stacks (the tokenizer's decoder and encoder) in ONE launch: a training step of 80 rows is ~30 graph nodes of >= 4.5 us.
+extern "C" int lipvq_mlp3_pack_bwd2_f32(const float* aW0, const float* aW1, const float* aW2, float* a_packed, int aK0, int aJ0,
+                                        int aJ1, int aJ2, const float* bW0, const float* bW1, const float* bW2, float* b_packed,
+                                        int bK0, int bJ0, int bJ1, int bJ2, void* stream) {
+    if (!aW0 || !aW1 || !aW2 || !a_packed || !bW0 || !bW1 || !bW2 || !b_packed) return fail(LIPVQ_EINVAL, "mlp3_pack_bwd2: null pointer");
+    if (aK0 <= 0 || aJ2 <= 0 || bK0 <= 0 || bJ2 <= 0) return fail(LIPVQ_EINVAL, "mlp3_pack_bwd2: bad sizes");
+    if (int e = check_hidden("mlp3_pack_bwd2", aJ0, aJ1)) return e;
+    if (int e = check_hidden("mlp3_pack_bwd2", bJ0, bJ1)) return e;
+    PackLayer ls[6];
+    pack_bwd_layers(ls, aW0, aW1, aW2, a_packed, aK0, aJ0, aJ1, aJ2);
+    pack_bwd_layers(ls + 3, bW0, bW1, bW2, b_packed, bK0, bJ0, bJ1, bJ2);
+    pack_launch(ls, 6, (hipStream_t)stream);
+    return check_launch("mlp3_pack_bwd2");
 }
 
 // ------------------------------------------------------------------------------------------

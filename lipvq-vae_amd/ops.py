@@ -163,6 +163,23 @@ def mse_pair(xr, x, zq, ze) -> torch.Tensor:
     return out
 
 
+LOSS_LLFQ, LOSS_VQ = 0, 1
+
+
+def mse_pair_loss(xr, x, zq, ze, w: float, form: int) -> torch.Tensor:
+    """tensor([mean((xr-x)^2), mean((zq-ze)^2), loss]): the two means and the tokenizer's loss built from them on the device
+    (LOSS_LLFQ: (m0 + w m1) + w m1;  LOSS_VQ: m0 + (m1 + w m1)) -- the reference's fp32 association, no torch arithmetic."""
+    xr, x, zq, ze = _chk(xr, "xr"), _chk(x, "x"), _chk(zq, "zq"), _chk(ze, "ze")
+    if x.numel() == 0 or ze.numel() == 0:        # F.mse_loss of an empty tensor is nan
+        return torch.full((3,), float("nan"), device=x.device, dtype=torch.float32)
+    out = torch.empty(3, device=x.device, dtype=torch.float32)
+    ws = torch.empty(lib.lipvq_mse_workspace_bytes(), device=x.device, dtype=torch.uint8)
+    with _on(x.device):
+        check(lib.lipvq_mse_pair_loss_f32(_ptr(xr), _ptr(x), x.numel(), _ptr(zq), _ptr(ze), ze.numel(), _ptr(out), float(w), int(form),
+                                          _ptr(ws), _stream()), "lipvq_mse_pair_loss_f32")
+    return out
+
+
 # ---- backward ---------------------------------------------------------------------------------
 
 def mlp3_pack_bwd(W0, W1, W2) -> PackedMlp3:
@@ -176,6 +193,22 @@ def mlp3_pack_bwd(W0, W1, W2) -> PackedMlp3:
         check(lib.lipvq_mlp3_pack_bwd_f32(_ptr(W0), _ptr(W1), _ptr(W2), _ptr(buf), K0, J0, J1, J2, _stream()),
               "lipvq_mlp3_pack_bwd_f32")
     return PackedMlp3(buf, K0, J0, J1, J2)
+
+
+def mlp3_pack_bwd2(a, b):
+    """mlp3_pack_bwd of two stacks, a = (W0, W1, W2) and b = (W0, W1, W2), in one launch -> (PackedMlp3, PackedMlp3)."""
+    (aW0, aW1, aW2), (bW0, bW1, bW2) = ([_chk(t, "W") for t in a], [_chk(t, "W") for t in b])
+    dims = []
+    bufs = []
+    for W0, W1, W2 in ((aW0, aW1, aW2), (bW0, bW1, bW2)):
+        J0, K0 = W0.shape
+        J1, J2 = W1.shape[0], W2.shape[0]
+        dims.append((K0, J0, J1, J2))
+        bufs.append(torch.empty(lib.lipvq_mlp3_packed_bwd_floats(K0, J0, J1, J2), device=W0.device, dtype=torch.float32))
+    with _on(aW0.device):
+        check(lib.lipvq_mlp3_pack_bwd2_f32(_ptr(aW0), _ptr(aW1), _ptr(aW2), _ptr(bufs[0]), *dims[0],
+                                           _ptr(bW0), _ptr(bW1), _ptr(bW2), _ptr(bufs[1]), *dims[1], _stream()), "lipvq_mlp3_pack_bwd2_f32")
+    return PackedMlp3(bufs[0], *dims[0]), PackedMlp3(bufs[1], *dims[1])
 
 
 def mlp3_bwd(gy, pre, packed_bwd: PackedMlp3, acts, want_gx=True):

@@ -186,6 +186,12 @@ def test_ste_and_mse(ops, oracle):
     out = ops.mse_pair(dev(xr), dev(x), dev(zq), dev(ze)).cpu().numpy()
     # means are order-dependent sums: tolerance 1e-6 relative (double accumulation on both sides)
     assert abs(out[0] - a) <= 1e-6 * abs(a) and abs(out[1] - b) <= 1e-6 * abs(b)
+    # the loss built on the device from the two means: the reference's fp32 association, bit for bit
+    for w, form in ((0.25, ops.LOSS_LLFQ), (0.25, ops.LOSS_VQ), (0.37, ops.LOSS_VQ)):
+        o3 = ops.mse_pair_loss(dev(xr), dev(x), dev(zq), dev(ze), w, form)
+        m0, m1 = o3[0], o3[1]
+        want = (m0 + m1 * w) + m1 * w if form == ops.LOSS_LLFQ else m0 + (m1 + w * m1)
+        assert torch.equal(o3[:2].cpu(), torch.from_numpy(out)) and torch.equal(o3[2], want)
 
 
 @pytest.mark.parametrize("N,K,D", [(5000, 37, 64), (80, 1024, 208), (70001, 256, 32), (40000, 1024, 208), (33001, 5000, 7)])
