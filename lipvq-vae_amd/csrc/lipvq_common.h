@@ -38,6 +38,27 @@ __device__ __forceinline__ void lq_wg_barrier() {
 }
 #endif
 
+#if defined(__HIPCC__)
+// usage[k] += 1 for every lane with `active`, with duplicates inside the wave combined first: when many rows map
+// to few codes (the reference's default initialisation maps EVERY row to one code) per-row atomics on one address
+// serialise chip-wide (measured: 1.7 ms instead of 0.57 ms for a 524 288-row batch with 32 codes).  Up to four
+// leader rounds (each: the first active lane's code, a ballot of the lanes that share it, ONE atomic of the count)
+// then plain atomics for whatever is left (the typical well-spread case pays four cheap rounds).
+__device__ __forceinline__ void lq_usage_add(unsigned long long* __restrict__ usage, int k, bool active) {
+#pragma unroll 1
+    for (int round = 0; round < 4; ++round) {
+        const unsigned long long act = __ballot(active);
+        if (act == 0ull) return;                                   // wave-uniform
+        const int leader = __ffsll((long long)act) - 1;
+        const int kl = __shfl(k, leader, 64);
+        const unsigned long long same = __ballot(active && k == kl);
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&usage[kl], (unsigned long long)__popcll(same));
+        active = active && k != kl;
+    }
+    if (active) atomicAdd(&usage[k], 1ull);
+}
+#endif
+
 // error plumbing (defined in lipvq_misc.hip)
 int lipvq_fail(int code, const char* fmt, ...);
 int lipvq_check_launch(const char* what);

@@ -536,25 +536,6 @@ __device__ __forceinline__ void lq_screen_emit(const LqDecision& dec, bool certi
     out[0] = nothing ? -1 : ((second_in || n > LQ_CAND_MAX) ? -2 : n);
 }
 
-// usage[k] += 1 for every lane with `active`, with duplicates inside the wave combined first: when many rows map
-// to few codes (the reference's default initialisation maps EVERY row to one code) per-row atomics on one address
-// serialise chip-wide (measured: 1.7 ms instead of 0.57 ms for a 524 288-row batch with 32 codes).  Up to four
-// leader rounds (each: the first active lane's code, a ballot of the lanes that share it, ONE atomic of the count)
-// then plain atomics for whatever is left (the typical well-spread case pays four cheap rounds).
-__device__ __forceinline__ void lq_usage_add(unsigned long long* __restrict__ usage, int k, bool active) {
-#pragma unroll 1
-    for (int round = 0; round < 4; ++round) {
-        const unsigned long long act = __ballot(active);
-        if (act == 0ull) return;                                   // wave-uniform
-        const int leader = __ffsll((long long)act) - 1;
-        const int kl = __shfl(k, leader, 64);
-        const unsigned long long same = __ballot(active && k == kl);
-        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&usage[kl], (unsigned long long)__popcll(same));
-        active = active && k != kl;
-    }
-    if (active) atomicAdd(&usage[k], 1ull);
-}
-
 // z_q rows of certified rows: 16 lanes copy one codebook row (16 B each), 4 rows per pass
 // z_q rows of certified rows: 16 lanes copy 64 floats of one codebook row (16 B each per pass), 4 rows per pass of the wave, 8
 // passes = the wave's 32 rows; a "trip" covers floats [64 trip, 64 trip + 64) of the rows.
