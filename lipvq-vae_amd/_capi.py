@@ -72,6 +72,9 @@ SIGNATURES = {
     "lipvq_linear_f32": (_i, [_vp] * 4 + [_i64, _i, _i, _vp]),
     "lipvq_embed_rows_f32": (_i, [_vp] * 5 + [C.c_float, _vp, _vp, _i64, _i, _i] + [_i64] * 4 + [_vp]),
     "lipvq_embed_rows_bwd_f32": (_i, [_vp] * 10 + [_i64, _i, _i] + [_i64] * 4 + [_vp]),
+    "lipvq_embed_rows_bwd_ws_supported": (_i, [_i64, _i, _i, _i64]),
+    "lipvq_embed_rows_bwd_workspace_bytes": (_sz, [_i64, _i, _i, _i64]),
+    "lipvq_embed_rows_bwd_ws_f32": (_i, [_vp] * 11 + [_i64, _i, _i] + [_i64] * 4 + [_vp]),
     "lipvq_linear_act_f32": (_i, [_vp] * 5 + [_i64, _i, _i, _i, _vp]),
     "lipvq_bin_minmax_f32": (_i, [_vp] * 3 + [_i64, _i, _vp]),
     "lipvq_bin_discretize_f32": (_i, [_vp] * 4 + [_i64, _i, _i, _vp]),

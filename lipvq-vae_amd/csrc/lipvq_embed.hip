@@ -20,6 +20,8 @@
 // partners l^1, l^2, l^7, l^15 (four DPP adds);  mean = s*(1/E), var = sum((v-mean)^2)*(1/E) (fmaf chain, same order),
 // rstd = 1/sqrt(var+eps), y = fmaf((v-mean)*rstd, w, b).
 // ABI: include/lipvq.h.
+#include <stdlib.h>
+
 #include "lipvq_common.h"
 
 // ---------------------------------------------------------------------------------------------------
@@ -346,7 +348,132 @@ struct EmbedBwdArgs {
     float* g_lnb;
     int64_t N, src_rows, out_bstride, out_tstride, out_offset;
     int T, E;
+    float* gv;                 // large batches: the rows' gradients are written here (and scattered by a second pass), not added atomically
+    int64_t* idx_clean;        // ... with the indices made safe for that pass (a row with a bad index: code 0, zero gradient)
 };
+
+// Large batches (lipvq_embed_rows_bwd_ws_f32).  The kernel above adds every row's E-float gradient to its table row AND to its
+// time-embedding row with fp32 atomics: 2 N E atomics, the time-embedding ones onto T E addresses -- 8.7 ms at the metric's
+// batch (N = 524 280, E = 512, T = 10), 55 ms when the codes collapse onto one table row.  Here a wave owns ONE time step t and
+// walks batches b, b + W, ...: the time-embedding gradient stays in registers and costs one flush per wave; the row gradient is
+// written once (gv [N][E]) and summed per code by the counting-sort scatter (lipvq_scatter.hip): no atomics on the table either.
+template <int NJ>
+__global__ __launch_bounds__(256) void embed_rows_bwd_gv_kernel(const EmbedBwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int E4 = a.E >> 2;
+    const float fE = (float)a.E;
+    float4 w[NJ], aw[NJ], ab[NJ], ap[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int q = lane + 64 * j;
+        aw[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ab[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ap[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        w[j] = q < E4 ? reinterpret_cast<const float4*>(a.ln_w)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __shared__ float4 red[3][4][64 * NJ];                      // the four waves' (ap, aw, ab) before ONE wave flushes them
+    const int wave = threadIdx.x >> 6;
+    const int64_t gpt = gridDim.x / a.T;                       // workgroups per time step (host: >= 1)
+    if ((int64_t)blockIdx.x >= gpt * a.T) return;              // (whole workgroups: no barrier is skipped by part of one)
+    const int t = (int)(blockIdx.x % a.T);                     // the four waves of a workgroup share the time step
+    const int64_t wpt = gpt * 4;
+    const int64_t B = (a.N + a.T - 1) / a.T;
+    const float4* prow = a.pos ? reinterpret_cast<const float4*>(a.pos + (size_t)t * a.E) : nullptr;
+    for (int64_t b = (int64_t)(blockIdx.x / a.T) * 4 + wave; b < B; b += wpt) {
+        const int64_t n = b * a.T + t;
+        if (n >= a.N) break;                                   // (wave-uniform)
+        const int64_t k = a.idx ? a.idx[n] : n;
+        const bool ok = k >= 0 && k < a.src_rows;
+        float4* gvrow = a.gv ? reinterpret_cast<float4*>(a.gv + (size_t)n * a.E) : nullptr;
+        if (a.idx_clean && lane == 0) a.idx_clean[n] = ok ? k : 0;
+        if (!ok) {                                             // wave-uniform: a poisoned row contributes nothing
+            if (gvrow) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    if (lane + 64 * j < E4) gvrow[lane + 64 * j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            continue;
+        }
+        const float mean = a.stats[2 * n], rstd = a.stats[2 * n + 1];
+        const float4* srow = reinterpret_cast<const float4*>(a.src + (size_t)k * a.E);
+        const float4* grow =
+            reinterpret_cast<const float4*>(a.gout + (size_t)(b * a.out_bstride + t * a.out_tstride + a.out_offset));
+        float4 xh[NJ], gh[NJ];
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int q = lane + 64 * j;
+            if (q < E4) {
+                float4 c = srow[q];
+                if (prow) {
+                    const float4 p = prow[q];
+                    c.x = c.x + p.x; c.y = c.y + p.y; c.z = c.z + p.z; c.w = c.w + p.w;
+                }
+                c.x = (c.x - mean) * rstd; c.y = (c.y - mean) * rstd;
+                c.z = (c.z - mean) * rstd; c.w = (c.w - mean) * rstd;
+                const float4 g = grow[q];
+                aw[j].x += g.x * c.x; aw[j].y += g.y * c.y; aw[j].z += g.z * c.z; aw[j].w += g.w * c.w;
+                ab[j].x += g.x; ab[j].y += g.y; ab[j].z += g.z; ab[j].w += g.w;
+                float4 h;
+                h.x = g.x * w[j].x; h.y = g.y * w[j].y; h.z = g.z * w[j].z; h.w = g.w * w[j].w;
+                s1 += (h.x + h.y) + (h.z + h.w);
+                s2 += (h.x * c.x + h.y * c.y) + (h.z * c.z + h.w * c.w);
+                xh[j] = c;
+                gh[j] = h;
+            }
+        }
+        const float c1 = lq_wave_allsum(s1) / fE, c2 = lq_wave_allsum(s2) / fE;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int q = lane + 64 * j;
+            if (q < E4) {
+                float4 gv;
+                gv.x = rstd * (gh[j].x - c1 - xh[j].x * c2);
+                gv.y = rstd * (gh[j].y - c1 - xh[j].y * c2);
+                gv.z = rstd * (gh[j].z - c1 - xh[j].z * c2);
+                gv.w = rstd * (gh[j].w - c1 - xh[j].w * c2);
+                if (gvrow) gvrow[q] = gv;
+                ap[j].x += gv.x; ap[j].y += gv.y; ap[j].z += gv.z; ap[j].w += gv.w;
+            }
+        }
+    }
+    // one flush per WORKGROUP (every flush is 3 E atomics onto 2 E + T E addresses: with one per wave of an 8 192-wave grid the
+    // flushes cost more than the rows -- 1.15 ms for the whole launch)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        red[0][wave][lane + 64 * j] = ap[j];
+        red[1][wave][lane + 64 * j] = aw[j];
+        red[2][wave][lane + 64 * j] = ab[j];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int q = lane + 64 * j;
+        if (q < E4) {
+            float4 sp = red[0][0][q], sw = red[1][0][q], sb = red[2][0][q];
+#pragma unroll
+            for (int u = 1; u < 4; ++u) {
+                const float4 p = red[0][u][q], ww = red[1][u][q], bb = red[2][u][q];
+                sp.x += p.x; sp.y += p.y; sp.z += p.z; sp.w += p.w;
+                sw.x += ww.x; sw.y += ww.y; sw.z += ww.z; sw.w += ww.w;
+                sb.x += bb.x; sb.y += bb.y; sb.z += bb.z; sb.w += bb.w;
+            }
+            if (a.g_pos) {
+                float* d = a.g_pos + (size_t)t * a.E + 4 * q;
+                atomicAdd(d + 0, sp.x); atomicAdd(d + 1, sp.y); atomicAdd(d + 2, sp.z); atomicAdd(d + 3, sp.w);
+            }
+            if (a.g_lnw) {
+                float* d = a.g_lnw + 4 * q;
+                atomicAdd(d + 0, sw.x); atomicAdd(d + 1, sw.y); atomicAdd(d + 2, sw.z); atomicAdd(d + 3, sw.w);
+            }
+            if (a.g_lnb) {
+                float* d = a.g_lnb + 4 * q;
+                atomicAdd(d + 0, sb.x); atomicAdd(d + 1, sb.y); atomicAdd(d + 2, sb.z); atomicAdd(d + 3, sb.w);
+            }
+        }
+    }
+}
 
 template <int NJ>
 __global__ __launch_bounds__(256) void embed_rows_bwd_kernel(const EmbedBwdArgs a) {
@@ -533,7 +660,7 @@ int lipvq_embed_rows_bwd_f32(const float* gout, const float* src, const int64_t*
     if (!idx && src_rows < N) return fail(LIPVQ_EINVAL, "lipvq_embed_rows_bwd_f32: src has fewer rows than N");
     if (N == 0) return LIPVQ_OK;
     EmbedBwdArgs a{gout, src, idx, pos, stats, ln_w, g_src, g_pos, g_lnw, g_lnb, N, src_rows,
-                   out_batch_stride, out_t_stride, out_offset, T, E};
+                   out_batch_stride, out_t_stride, out_offset, T, E, nullptr, nullptr};
     int g = embed_grid(4, N);
     if (g > 512) g = 512;                 // fewer waves = fewer final flushes of the LayerNorm gradients
     const dim3 grid(g), block(256);
@@ -545,6 +672,49 @@ int lipvq_embed_rows_bwd_f32(const float* gout, const float* src, const int64_t*
         default: hipLaunchKernelGGL(embed_rows_bwd_kernel<4>, grid, block, 0, st, a); break;
     }
     return check_launch("embed_rows_bwd_kernel");
+}
+
+// Large batches of indexed rows: no atomics on the table or the time embedding (embed_rows_bwd_gv_kernel + the counting-sort
+// scatter).  workspace: gv [N][E] floats, the sanitised indices [N], then the scatter's own workspace.
+int lipvq_embed_rows_bwd_ws_supported(int64_t N, int T, int E, int64_t src_rows) {
+    return N >= 32768 && T >= 1 && T <= 1024 && E >= 4 && (E & 3) == 0 && E <= 1024 && src_rows <= 16384 &&
+           lipvq_scatter_add_sorted_supported(N, (int)src_rows, E);
+}
+
+size_t lipvq_embed_rows_bwd_workspace_bytes(int64_t N, int T, int E, int64_t src_rows) {
+    if (!lipvq_embed_rows_bwd_ws_supported(N, T, E, src_rows)) return 0;
+    const size_t gv = ((size_t)N * E * sizeof(float) + 255) & ~(size_t)255, ic = ((size_t)N * sizeof(int64_t) + 255) & ~(size_t)255;
+    return gv + ic + lipvq_scatter_add_sorted_workspace_bytes(N, (int)src_rows, E);
+}
+
+int lipvq_embed_rows_bwd_ws_f32(const float* gout, const float* src, const int64_t* idx, const float* pos, const float* stats,
+                                const float* ln_w, float* g_src, float* g_pos, float* g_lnw, float* g_lnb, void* workspace,
+                                int64_t N, int T, int E, int64_t src_rows, int64_t out_batch_stride, int64_t out_t_stride,
+                                int64_t out_offset, void* stream) {
+    if (!gout || !src || !idx || !stats || !ln_w || !workspace) return fail(LIPVQ_EINVAL, "lipvq_embed_rows_bwd_ws_f32: null pointer");
+    const int rc = embed_check("lipvq_embed_rows_bwd_ws_f32", N, T, E, src_rows, out_batch_stride, out_t_stride, out_offset);
+    if (rc) return rc;
+    if (!lipvq_embed_rows_bwd_ws_supported(N, T, E, src_rows))
+        return fail(LIPVQ_EUNSUPPORTED, "lipvq_embed_rows_bwd_ws_f32: N=%lld T=%d E=%d src_rows=%lld outside the supported range",
+                    (long long)N, T, E, (long long)src_rows);
+    const size_t gvb = ((size_t)N * E * sizeof(float) + 255) & ~(size_t)255, icb = ((size_t)N * sizeof(int64_t) + 255) & ~(size_t)255;
+    float* gv = g_src ? (float*)workspace : nullptr;
+    int64_t* idx_clean = g_src ? (int64_t*)((char*)workspace + gvb) : nullptr;
+    EmbedBwdArgs a{gout, src, idx, pos, stats, ln_w, g_src, g_pos, g_lnw, g_lnb, N, src_rows,
+                   out_batch_stride, out_t_stride, out_offset, T, E, gv, idx_clean};
+    static int grid_knob = -1;                                 // LIPVQ_EMBED_BWD_GRID: measurement knob
+    if (grid_knob < 0) { const char* e = getenv("LIPVQ_EMBED_BWD_GRID"); grid_knob = e ? atoi(e) : 1024; }
+    const dim3 grid(grid_knob < T ? T : grid_knob), block(256);   // >= one workgroup per time step (T <= 1024)
+    hipStream_t st = (hipStream_t)stream;
+    switch ((E + 255) / 256) {
+        case 1: hipLaunchKernelGGL(embed_rows_bwd_gv_kernel<1>, grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL(embed_rows_bwd_gv_kernel<2>, grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL(embed_rows_bwd_gv_kernel<3>, grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL(embed_rows_bwd_gv_kernel<4>, grid, block, 0, st, a); break;
+    }
+    if (int e = check_launch("embed_rows_bwd_gv_kernel")) return e;
+    if (!g_src) return LIPVQ_OK;
+    return lipvq_scatter_add_sorted_f32(gv, idx_clean, g_src, (char*)workspace + gvb + icb, N, (int)src_rows, E, 0, stream);
 }
 
 }  // extern "C"

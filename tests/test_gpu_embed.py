@@ -206,3 +206,53 @@ def test_full_size_gather_property():
     ops.embed_rows(table, all_idx, pos, w, b, 1e-5, combos, K * T, T, T * E, E, 0)
     t = torch.arange(N, device="cuda") % T
     assert torch.equal(out.view(N, E), combos.view(K * T, E)[idx * T + t])
+
+
+@pytest.mark.parametrize("B,T,E,K,kind", [(3300, 10, 512, 1024, "uniform"), (4100, 8, 256, 37, "collapsed"), (40000, 1, 64, 300, "bad"),
+                                          (3641, 9, 320, 2000, "uniform")])
+def test_embed_rows_bwd_large_batch_route(B, T, E, K, kind):
+    """lipvq_embed_rows_bwd_ws_f32 (N >= 32 768 indexed rows: no atomics on the table / time embedding) against the atomic kernel
+    and a float64 torch autograd reference; reproducible run after run; rows with a bad index contribute nothing."""
+    from lipvq_vae_amd import ops
+    from lipvq_vae_amd._capi import lib
+    N = B * T
+    g = torch.Generator(device="cuda").manual_seed(B + E)
+    table = torch.randn(K, E, device="cuda", generator=g)
+    pos = 0.1 * torch.randn(T, E, device="cuda", generator=g)
+    w = 1 + 0.1 * torch.randn(E, device="cuda", generator=g)
+    b = 0.1 * torch.randn(E, device="cuda", generator=g)
+    idx = torch.randint(0, K, (N,), device="cuda", generator=g)
+    if kind == "collapsed":
+        idx[torch.rand(N, device="cuda", generator=g) < 0.9] = 5
+    if kind == "bad":
+        idx[::1000] = K + 3
+        idx[7] = -1
+    out = torch.zeros(B, 3 * T, E, device="cuda")
+    gout = torch.randn(B, 3 * T, E, device="cuda", generator=g)
+    args = (N, T, 3 * T * E, 2 * E, E)
+    st = ops.embed_rows(table, idx, pos, w, b, 1e-5, out, *args, want_stats=True)
+    assert lib.lipvq_embed_rows_bwd_ws_supported(N, T, E, K)
+
+    def grads(route_ws):
+        gs = [torch.zeros_like(table), torch.zeros_like(pos), torch.zeros(E, device="cuda"), torch.zeros(E, device="cuda")]
+        if route_ws:
+            ops.embed_rows_bwd(gout, table, idx, pos, st, w, *gs, *args)
+        else:
+            from lipvq_vae_amd.ops import _ptr, _stream, check
+            check(lib.lipvq_embed_rows_bwd_f32(_ptr(gout), _ptr(table), _ptr(idx), _ptr(pos), _ptr(st), _ptr(w), *(_ptr(t) for t in gs),
+                                               N, T, E, K, 3 * T * E, 2 * E, E, _stream()), "lipvq_embed_rows_bwd_f32")
+        return gs
+    a1, a2, old = grads(True), grads(True), grads(False)
+    assert torch.equal(a1[0], a2[0])                                   # the table gradient has no atomics left
+    # float64 reference through torch autograd on the valid rows
+    ok = (idx >= 0) & (idx < K)
+    tb, ps, ww, bb = (t.double().requires_grad_(True) for t in (table, pos, w, b))
+    tt = torch.arange(N, device="cuda") % T
+    x = tb[idx.clamp(0, K - 1)] + ps[tt]
+    y = torch.nn.functional.layer_norm(x, (E,), ww, bb, 1e-5)
+    sel = gout.view(B, 3 * T, E)[:, 1:2 * T:2, :].reshape(N, E).double()
+    (y * sel * ok[:, None]).sum().backward()
+    for got, ref, o, name in zip(a1, (tb.grad, ps.grad, ww.grad, bb.grad), old, ("table", "pos", "ln_w", "ln_b")):
+        scale = float(ref.abs().max()) + 1e-30
+        assert float((got.double() - ref).abs().max()) <= 2e-4 * scale, name
+        assert float((got - o).abs().max()) <= 2e-4 * scale, name
