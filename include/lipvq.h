@@ -256,8 +256,8 @@ int lipvq_embed_rows_bwd_f32(const float* gout, const float* src, const int64_t*
 /* The same backward for a large batch of INDEXED rows without atomics on the table or the time embedding: a wave owns one time
  * step (its time-embedding gradient stays in registers), the rows' gradients are written once and summed per table row by the
  * counting-sort scatter (lipvq_scatter_add_sorted_f32): reproducible, and independent of how the indices are distributed
- * (the atomic kernel: 8.7 ms at N = 524 280, E = 512, T = 10; 55 ms when every row picks the same table row).  idx must not be
- * NULL.  workspace: lipvq_embed_rows_bwd_workspace_bytes() (0 = unsupported: N < 32768 or more than 16384 table rows). */
+ * (the atomic kernel: 8.7 ms at N = 524 280, E = 512, T = 10; 55 ms when every row picks the same table row).  idx == NULL
+ * (dense rows, N >= 32768): the row gradients are g_src itself, workspace may be NULL.  workspace: lipvq_embed_rows_bwd_workspace_bytes() (0 = unsupported: N < 32768 or more than 16384 table rows). */
 int lipvq_embed_rows_bwd_ws_supported(int64_t N, int T, int E, int64_t src_rows);
 size_t lipvq_embed_rows_bwd_workspace_bytes(int64_t N, int T, int E, int64_t src_rows);
 int lipvq_embed_rows_bwd_ws_f32(const float* gout, const float* src, const int64_t* idx, const float* pos, const float* stats,

@@ -691,15 +691,18 @@ int lipvq_embed_rows_bwd_ws_f32(const float* gout, const float* src, const int64
                                 const float* ln_w, float* g_src, float* g_pos, float* g_lnw, float* g_lnb, void* workspace,
                                 int64_t N, int T, int E, int64_t src_rows, int64_t out_batch_stride, int64_t out_t_stride,
                                 int64_t out_offset, void* stream) {
-    if (!gout || !src || !idx || !stats || !ln_w || !workspace) return fail(LIPVQ_EINVAL, "lipvq_embed_rows_bwd_ws_f32: null pointer");
+    if (!gout || !src || !stats || !ln_w || (idx && !workspace)) return fail(LIPVQ_EINVAL, "lipvq_embed_rows_bwd_ws_f32: null pointer");
     const int rc = embed_check("lipvq_embed_rows_bwd_ws_f32", N, T, E, src_rows, out_batch_stride, out_t_stride, out_offset);
     if (rc) return rc;
-    if (!lipvq_embed_rows_bwd_ws_supported(N, T, E, src_rows))
+    if (!idx && src_rows < N) return fail(LIPVQ_EINVAL, "lipvq_embed_rows_bwd_ws_f32: src has fewer rows than N");
+    const bool okay = idx ? lipvq_embed_rows_bwd_ws_supported(N, T, E, src_rows) != 0 : (N >= 32768 && T <= 1024);
+    if (!okay)
         return fail(LIPVQ_EUNSUPPORTED, "lipvq_embed_rows_bwd_ws_f32: N=%lld T=%d E=%d src_rows=%lld outside the supported range",
                     (long long)N, T, E, (long long)src_rows);
     const size_t gvb = ((size_t)N * E * sizeof(float) + 255) & ~(size_t)255, icb = ((size_t)N * sizeof(int64_t) + 255) & ~(size_t)255;
-    float* gv = g_src ? (float*)workspace : nullptr;
-    int64_t* idx_clean = g_src ? (int64_t*)((char*)workspace + gvb) : nullptr;
+    // dense rows (idx == NULL): row n of g_src has one writer -- the row gradients ARE g_src, nothing to scatter
+    float* gv = !g_src ? nullptr : (idx ? (float*)workspace : g_src);
+    int64_t* idx_clean = (g_src && idx) ? (int64_t*)((char*)workspace + gvb) : nullptr;
     EmbedBwdArgs a{gout, src, idx, pos, stats, ln_w, g_src, g_pos, g_lnw, g_lnb, N, src_rows,
                    out_batch_stride, out_t_stride, out_offset, T, E, gv, idx_clean};
     static int grid_knob = -1;                                 // LIPVQ_EMBED_BWD_GRID: measurement knob
@@ -713,7 +716,7 @@ int lipvq_embed_rows_bwd_ws_f32(const float* gout, const float* src, const int64
         default: hipLaunchKernelGGL(embed_rows_bwd_gv_kernel<4>, grid, block, 0, st, a); break;
     }
     if (int e = check_launch("embed_rows_bwd_gv_kernel")) return e;
-    if (!g_src) return LIPVQ_OK;
+    if (!g_src || !idx) return LIPVQ_OK;
     return lipvq_scatter_add_sorted_f32(gv, idx_clean, g_src, (char*)workspace + gvb + icb, N, (int)src_rows, E, 0, stream);
 }
 

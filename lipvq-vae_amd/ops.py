@@ -525,9 +525,12 @@ def embed_rows_bwd(gout, src, idx, pos, stats, ln_w, g_src, g_pos, g_lnw, g_lnb,
         if t is not None and (tuple(t.shape) != shape or not t.is_contiguous() or t.dtype != torch.float32):
             raise ValueError(f"embed_rows_bwd: {name} must be a contiguous fp32 tensor of shape {shape}")
     with _on(src.device):
-        if idx is not None and lib.lipvq_embed_rows_bwd_ws_supported(N, T, E, src.shape[0]):
-            # large indexed batches: no atomics on the table / time embedding (row gradients written once, counting-sort scatter)
-            ws = torch.empty(lib.lipvq_embed_rows_bwd_workspace_bytes(N, T, E, src.shape[0]), device=src.device, dtype=torch.uint8)
+        big_dense = idx is None and N >= 32768 and T <= 1024
+        if big_dense or (idx is not None and lib.lipvq_embed_rows_bwd_ws_supported(N, T, E, src.shape[0])):
+            # large batches: no atomics on the table / time embedding (row gradients written once, counting-sort scatter; dense
+            # rows: the row gradients are g_src)
+            ws = None if big_dense else torch.empty(lib.lipvq_embed_rows_bwd_workspace_bytes(N, T, E, src.shape[0]),
+                                                    device=src.device, dtype=torch.uint8)
             check(lib.lipvq_embed_rows_bwd_ws_f32(_ptr(gout), _ptr(src), _ptr(idx), _ptr(pos), _ptr(stats), _ptr(ln_w),
                                                   _ptr(g_src), _ptr(g_pos), _ptr(g_lnw), _ptr(g_lnb), _ptr(ws), N, T, E,
                                                   src.shape[0], bstride, tstride, offset, _stream()), "lipvq_embed_rows_bwd_ws_f32")

@@ -256,3 +256,37 @@ def test_embed_rows_bwd_large_batch_route(B, T, E, K, kind):
         scale = float(ref.abs().max()) + 1e-30
         assert float((got.double() - ref).abs().max()) <= 2e-4 * scale, name
         assert float((got - o).abs().max()) <= 2e-4 * scale, name
+
+
+def test_embed_rows_bwd_large_dense_batch_route():
+    """Dense rows (idx = None) of a large batch: the row gradients are written straight into g_src, the time-embedding gradient
+    has no per-row atomics; equals the atomic kernel to fp32 summation accuracy and float64 autograd."""
+    from lipvq_vae_amd import ops
+    from lipvq_vae_amd._capi import lib
+    from lipvq_vae_amd.ops import _ptr, _stream, check
+    B, T, E = 5000, 8, 192
+    N = B * T
+    g = torch.Generator(device="cuda").manual_seed(11)
+    src = torch.randn(N, E, device="cuda", generator=g)
+    pos = 0.1 * torch.randn(T, E, device="cuda", generator=g)
+    w = 1 + 0.1 * torch.randn(E, device="cuda", generator=g)
+    b = 0.1 * torch.randn(E, device="cuda", generator=g)
+    out = torch.zeros(B, 3 * T, E, device="cuda")
+    gout = torch.randn(B, 3 * T, E, device="cuda", generator=g)
+    args = (N, T, 3 * T * E, 2 * E, 0)
+    st = ops.embed_rows(src, None, pos, w, b, 1e-5, out, *args, want_stats=True)
+    new = [torch.zeros_like(src), torch.zeros_like(pos), torch.zeros(E, device="cuda"), torch.zeros(E, device="cuda")]
+    ops.embed_rows_bwd(gout, src, None, pos, st, w, *new, *args)
+    old = [torch.zeros_like(src), torch.zeros_like(pos), torch.zeros(E, device="cuda"), torch.zeros(E, device="cuda")]
+    check(lib.lipvq_embed_rows_bwd_f32(_ptr(gout), _ptr(src), None, _ptr(pos), _ptr(st), _ptr(w), *(_ptr(t) for t in old),
+                                       N, T, E, N, 3 * T * E, 2 * E, 0, _stream()), "lipvq_embed_rows_bwd_f32")
+    assert torch.equal(new[0], old[0])                                  # per-row arithmetic is the same code
+    sd, ps, ww, bb = (t.double().requires_grad_(True) for t in (src, pos, w, b))
+    tt = torch.arange(N, device="cuda") % T
+    y = torch.nn.functional.layer_norm(sd + ps[tt], (E,), ww, bb, 1e-5)
+    sel = gout.view(B, 3 * T, E)[:, 0:2 * T:2, :].reshape(N, E).double()
+    (y * sel).sum().backward()
+    for got, ref, o, name in zip(new, (sd.grad, ps.grad, ww.grad, bb.grad), old, ("src", "pos", "ln_w", "ln_b")):
+        scale = float(ref.abs().max()) + 1e-30
+        assert float((got.double() - ref).abs().max()) <= 2e-4 * scale, name
+        assert float((got - o).abs().max()) <= 2e-4 * scale, name
