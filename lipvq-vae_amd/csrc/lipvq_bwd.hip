@@ -250,9 +250,13 @@ template <int TI, int TJ, int ROWS>
 __global__ __launch_bounds__(64 * WGW_WAVES) void wgrad_wg5_kernel(const float* __restrict__ G, const float* __restrict__ H,
                                                                    const int64_t* __restrict__ hidx, int h_act,
                                                                    float* __restrict__ partW, float* __restrict__ partB,
-                                                                   int64_t N, int J, int Kd, int chunk_rows) {
+                                                                   int64_t N, int J, int Kd, int chunk_rows, int ldG) {
     extern __shared__ __attribute__((aligned(16))) float wg_lds[];
     constexpr int Jp = 32 * TI, Kp = 32 * TJ, Jp4 = Jp / 4, Kp4 = Kp / 4;
+    // a G wider than 224 columns is processed in column blocks of Jp (grid y): ldG = G's row stride = the slabs' row count
+    const int Jall = J, c0 = (int)blockIdx.y * Jp;
+    G += c0;
+    J = Jall - c0 < Jp ? Jall - c0 : Jp;
     constexpr int T = TI * TJ, TPW = (T + WGW_WAVES - 1) / WGW_WAVES;
     constexpr int BUF = ROWS * (Jp + Kp);                     // floats per LDS buffer: [ROWS][Jp] of G, then [ROWS][Kp] of act(H)
     constexpr int NG = (ROWS * Jp4 + 511) / 512, NH = (ROWS * Kp4 + 511) / 512;      // float4 slots per thread and block
@@ -287,14 +291,14 @@ __global__ __launch_bounds__(64 * WGW_WAVES) void wgrad_wg5_kernel(const float* 
         const int64_t rr = rb + row;
         const int64_t rc = rr < r1 ? rr : r1 - 1;
         if (vecG) {
-            const f32x4 v = reinterpret_cast<const f32x4*>(G + (size_t)rc * J)[col < J4 ? col : J4 - 1];
+            const f32x4 v = reinterpret_cast<const f32x4*>(G + (size_t)rc * ldG)[col < J4 ? col : J4 - 1];
             return wg5_sel(rr < r1 && col < J4, v);
         }
         f32x4 v;                                                       // rows that are not whole float4s (fan-in 7): element loads
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int c = 4 * col + e;
-            const float t = G[(size_t)rc * J + (c < J ? c : J - 1)];
+            const float t = G[(size_t)rc * ldG + (c < J ? c : J - 1)];
             v[e] = (rr < r1 && c < J) ? t : 0.0f;
         }
         return v;
@@ -381,7 +385,7 @@ __global__ __launch_bounds__(64 * WGW_WAVES) void wgrad_wg5_kernel(const float* 
             lq_wg_barrier();
         }
     }
-    float* pw = partW + (size_t)blockIdx.x * J * Kd;
+    float* pw = partW + (size_t)blockIdx.x * Jall * Kd + (size_t)c0 * Kd;
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
         const int t = wave + q * WGW_WAVES;
@@ -396,7 +400,7 @@ __global__ __launch_bounds__(64 * WGW_WAVES) void wgrad_wg5_kernel(const float* 
         if (tj == 0) {
             const float tot = bsum[q] + __shfl_xor(bsum[q], 32, 64);
             const int fi = 32 * ti + li;
-            if (kh == 0 && fi < J) partB[(size_t)blockIdx.x * J + fi] = tot;
+            if (kh == 0 && fi < J) partB[(size_t)blockIdx.x * Jall + c0 + fi] = tot;
         }
     }
 }
@@ -464,12 +468,15 @@ extern "C" int lipvq_wgrad_f32(const float* G, const float* H, const int64_t* hi
     const bool direct = nch == 1;
     if (direct) { partW = gW; if (gb) partB = gb; }
     auto tcode = [](int t) { return t == 1 ? 0 : t == 2 ? 1 : t == 4 ? 2 : t == 7 ? 3 : -1; };     // tile counts with an instance: 32, 64, 128, 208+ wide
-    const int ci = tcode(TI), cj = tcode(TJ);
+    // G wider than 224 columns (the embedding Linear's 512): column blocks of 128 through the four-tile instance
+    // (1.32 ms -> see DESIGN.md for N = 524 280, J = 512, Kd = 64; the per-tile kernel below read G at 0.9 TB/s)
+    const bool wide = TI > 7 && J % 128 == 0;
+    const int TIk = wide ? 4 : TI, ycount = wide ? J / 128 : 1;
+    const int ci = tcode(TIk), cj = tcode(TJ);
     if (use_wg && use_wg5 && ci >= 0 && cj >= 0 && ((J & 3) == 0 || TI == 1) && ((Kd & 3) == 0 || TJ == 1) &&
         (((uintptr_t)G | (uintptr_t)H) & 15) == 0) {
-        typedef void (*wg5_fn)(const float*, const float*, const int64_t*, int, float*, float*, int64_t, int, int, int);
+        typedef void (*wg5_fn)(const float*, const float*, const int64_t*, int, float*, float*, int64_t, int, int, int, int);
         wg5_fn kfn = nullptr;
-        // 64-row blocks while two buffers fit LDS (TI + TJ <= 10), 32-row blocks for the 208-wide pairs
         // 64-row blocks for the narrow pairs; 32-row blocks from 192 columns on (TI + TJ >= 6): two 64-row buffers of those are
         // 98 KB and more -- one workgroup per CU, every barrier and staging phase exposed -- while at 32 rows two or three
         // workgroups share a CU and fill each other's gaps: 128x64 178 -> 146 us, 64x128 217 -> 174 us at N = 524 288 (the narrow
@@ -477,18 +484,18 @@ extern "C" int lipvq_wgrad_f32(const float* G, const float* H, const int64_t* hi
         // LIPVQ_WGRAD_ROWS=32|64 forces one size (measurement knob).
         static int rows_knob = -1;
         if (rows_knob < 0) { const char* e = getenv("LIPVQ_WGRAD_ROWS"); rows_knob = e ? atoi(e) : 0; }
-        const bool r64 = TI + TJ <= 10 && (rows_knob == 64 || (rows_knob != 32 && TI + TJ < 6));
-#define LQ_W5(TI_, TJ_) if (TI == TI_ && TJ == TJ_) kfn = r64 ? (wg5_fn)wgrad_wg5_kernel<TI_, TJ_, (TI_ + TJ_ <= 10 ? 64 : 32)> : (wg5_fn)wgrad_wg5_kernel<TI_, TJ_, 32>;
+        const bool r64 = TIk + TJ <= 10 && (rows_knob == 64 || (rows_knob != 32 && TIk + TJ < 6));
+#define LQ_W5(TI_, TJ_) if (TIk == TI_ && TJ == TJ_) kfn = r64 ? (wg5_fn)wgrad_wg5_kernel<TI_, TJ_, (TI_ + TJ_ <= 10 ? 64 : 32)> : (wg5_fn)wgrad_wg5_kernel<TI_, TJ_, 32>;
         LQ_W5(1, 1) LQ_W5(1, 2) LQ_W5(1, 4) LQ_W5(1, 7) LQ_W5(2, 1) LQ_W5(2, 2) LQ_W5(2, 4) LQ_W5(2, 7)
         LQ_W5(4, 1) LQ_W5(4, 2) LQ_W5(4, 4) LQ_W5(4, 7) LQ_W5(7, 1) LQ_W5(7, 2) LQ_W5(7, 4) LQ_W5(7, 7)
 #undef LQ_W5
         const int rows5 = r64 ? 64 : 32;
-        const size_t lds5 = (size_t)2 * rows5 * 32 * (TI + TJ) * sizeof(float);
+        const size_t lds5 = (size_t)2 * rows5 * 32 * (TIk + TJ) * sizeof(float);
         static LqLdsReserve reserved5[32];          // per instantiation: per-device, thread-safe (lipvq_common.h)
         if (lds5 > 64 * 1024)
             if (int rc = lipvq_reserve_lds(reserved5[(r64 ? 16 : 0) + ci * 4 + cj], (const void*)kfn, lds5, "wgrad")) return rc;
-        hipLaunchKernelGGL(kfn, dim3(nch), dim3(64 * WGW_WAVES), lds5, st, G, H, hidx, h_act, partW, partB, N, J, Kd,
-                           wgrad_chunk_rows(N));
+        hipLaunchKernelGGL(kfn, dim3(nch, ycount), dim3(64 * WGW_WAVES), lds5, st, G, H, hidx, h_act, partW, partB, N, J, Kd,
+                           wgrad_chunk_rows(N), J);
     } else if (use_wg && TI * TJ <= WGW_WAVES * WGW_MAXT && TI <= 8 && TJ <= 8 && lds <= 64 * 1024) {
         const int wide = 32 * (TI > TJ ? TI : TJ);
         const int tpw = (TI * TJ + WGW_WAVES - 1) / WGW_WAVES;

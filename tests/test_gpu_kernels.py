@@ -78,6 +78,35 @@ def test_mlp3_gather(ops, oracle):
     assert np.array_equal(y.cpu().numpy(), y_ref)
 
 
+@pytest.mark.parametrize("N,J,Kd,act,gather", [
+    (5000, 128, 64, O.ACT_GELU, False), (70000, 64, 128, O.ACT_GELU, False), (33000, 64, 7, O.ACT_NONE, False),
+    (4097, 7, 128, O.ACT_GELU, False), (20000, 64, 64, O.ACT_NONE, True), (80, 208, 128, O.ACT_GELU, False),
+    # a gradient operand wider than 224 columns: column blocks of 128 through the four-tile kernel (the embedding Linear's 512)
+    (9000, 512, 64, O.ACT_NONE, False), (40000, 256, 64, O.ACT_RELU, False), (3000, 384, 32, O.ACT_NONE, False),
+    (2500, 320, 64, O.ACT_NONE, False),                            # 320 % 128 != 0: the per-tile kernel
+])
+def test_wgrad_against_float64(ops, N, J, Kd, act, gather):
+    """gW = G^T act(H), gb = column sums of G, for every kernel family behind lipvq_wgrad_f32, against float64 torch."""
+    g = torch.Generator(device="cuda").manual_seed(N + J)
+    G = torch.randn(N, J, device="cuda", generator=g)
+    if gather:
+        table = torch.randn(300, Kd, device="cuda", generator=g)
+        hidx = torch.randint(0, 300, (N,), device="cuda", generator=g)
+        gW, gb = ops.wgrad(G, table, h_act=act, hidx=hidx)
+        Hd = table[hidx].double()
+    else:
+        H = torch.randn(N, Kd, device="cuda", generator=g)
+        gW, gb = ops.wgrad(G, H, h_act=act)
+        Hd = H.double()
+    if act == O.ACT_GELU:
+        Hd = torch.nn.functional.gelu(Hd)
+    elif act == O.ACT_RELU:
+        Hd = torch.relu(Hd)
+    refW, refb = G.double().t() @ Hd, G.double().sum(0)
+    assert float((gW.double() - refW).abs().max()) <= 2e-5 * float(refW.abs().max())
+    assert float((gb.double() - refb).abs().max()) <= 2e-5 * max(float(refb.abs().max()), N ** 0.5)
+
+
 LDS_ROWS = 65536          # csrc/lipvq_mlp.hip: from this many rows on the LDS-resident persistent kernel runs the stack
 
 
