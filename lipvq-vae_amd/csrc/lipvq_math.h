@@ -18,9 +18,10 @@
  * the 1e-5 budget of the north star.  The distance reduction, in contrast, is
  * reproduced EXACTLY: torch's vectorised L2-norm reduction on x86 (AVX2 and
  * AVX512 builds alike) keeps 8 partial sums acc[j] += d[8i+j]^2 with fused
- * multiply-add, then adds the 8 lanes left to right and takes the square root
- * (established empirically: oracle/probe_torch_norm.py, 0 mismatches in 3e5
- * distances for D in {32,64,128,208}).  Coefficients: oracle/fit_coeffs.py.
+ * multiply-add, then adds the 8 lanes left to right, folds the elements past
+ * the last whole 8-vector (lq_sqdist8 says how) and takes the square root
+ * (established empirically: oracle/probe_torch_norm.py, 0 mismatches for every
+ * D in 1..263).  Coefficients: oracle/fit_coeffs.py.
  */
 #ifndef LIPVQ_MATH_H_
 #define LIPVQ_MATH_H_
@@ -309,10 +310,14 @@ LQ_HD float lq_softplus(float x) {
     return lq_logf_ge1(u) + (t - (u - 1.0f)) / u;    /* log1p correction term */
 }
 
-/* Squared L2 distance in torch's CPU reduction order (see header comment).
- * z, c: D contiguous floats.  D % 8 != 0: the tail is folded left to right
- * with fmaf (torch's scalar tail is build dependent; every BASELINE shape and
- * the real D = 208 are multiples of 8, so that branch is never taken there). */
+/* Squared L2 distance in torch's CPU reduction order (see header comment), any D >= 1.
+ * z, c: D contiguous floats.  The 8-lane part is torch's vectorised loop; what follows the lane fold is the
+ * kernel's scalar remainder loop AS THE SHIPPED BINARY EXECUTES IT (torch 2.10.0 CPU, the AVX2 kernel -- also
+ * what an AVX512 host dispatches for this op): while at least four elements remain, four are squared (rounded
+ * products) and added in index order -- the compiler turned the remainder loop into a 4-wide multiply followed
+ * by an in-order add --, and the last one to three elements are folded with fused multiply-add.  Established by
+ * oracle/probe_torch_norm.py for every D in 1..263 (0 mismatches) and pinned by the reference-decided near-tie
+ * fixtures tests/golden/llfq_nearties_d{7,20,37,100,203}.npz. */
 LQ_HD float lq_sqdist8(const float* z, const float* c, int D) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
     int i = 0;
@@ -327,38 +332,75 @@ LQ_HD float lq_sqdist8(const float* z, const float* c, int D) {
         a6 = lq_fma(d6, d6, a6); a7 = lq_fma(d7, d7, a7);
     }
     float s = ((((((a0 + a1) + a2) + a3) + a4) + a5) + a6) + a7;
+    if (i + 4 <= D) {
+        const float d0 = z[i + 0] - c[i + 0], d1 = z[i + 1] - c[i + 1];
+        const float d2 = z[i + 2] - c[i + 2], d3 = z[i + 3] - c[i + 3];
+        const float p0 = d0 * d0, p1 = d1 * d1, p2 = d2 * d2, p3 = d3 * d3;
+        s = (((s + p0) + p1) + p2) + p3;
+        i += 4;
+    }
     for (; i < D; ++i) { float d = z[i] - c[i]; s = lq_fma(d, d, s); }
     return s;
 }
 
 /* Squared L2 distance of the plain VQVAE variant,
  * `(z_e.unsqueeze(1) - E).pow(2).sum(-1)` (reference: robomimic/models/vq_vae/
- * backbone.py:57-60): every d*d is rounded first (pow materialises a tensor),
- * then torch's CPU sum keeps 4 accumulators of 8 lanes over 32-wide chunks,
- * folds left-over 8-vectors into accumulator 0, adds the accumulators and then
- * the lanes left to right (oracle/probe_torch_norm.py; exact for D % 8 == 0). */
+ * backbone.py:57-60): every d*d is rounded first (pow materialises a tensor), then torch's CPU sum kernel
+ * (cascade sum over the contiguous inner dimension) adds them.  Restated for any D >= 1 (probe: every D in
+ * 1..139 and a spread of widths up to 4100, 0 mismatches):
+ *   D >= 8 : the row is D/8 vectors of 8 lanes; vector v goes to accumulator v mod 4 while whole groups of
+ *            four remain, left-over vectors to accumulator 0; each accumulator is a four-level cascade (16
+ *            additions per level -- it only shows from D = 512 on); accumulators 1..3 are added to 0 in that
+ *            order; the result starts from the scalar tail (elements past the last whole vector, summed in
+ *            order from 0) and then takes the 8 lanes left to right.
+ *   D <  8 : the same scheme with one-element "vectors" (torch's scalar inner-sum path) and no tail. */
 LQ_HD float lq_sqdist32(const float* z, const float* c, int D) {
-    float acc[4][8];
-    for (int a = 0; a < 4; ++a)
-        for (int j = 0; j < 8; ++j) acc[a][j] = 0.f;
+    const int W = (D >= 8) ? 8 : 1;
+    const int nvec = D / W, size_ilp = nvec / 4;
+    int lg = 1;                                        /* torch's CeilLog2(size_ilp) */
+    if (size_ilp > 2) { lg = 0; while ((1 << lg) < size_ilp) ++lg; }
+    const int level_power = (lg / 4 > 4) ? lg / 4 : 4;
+    const int level_step = 1 << level_power, level_mask = level_step - 1;
+    float acc[4][4][8];
+    for (int j = 0; j < 4; ++j)
+        for (int k = 0; k < 4; ++k)
+            for (int l = 0; l < 8; ++l) acc[j][k][l] = 0.f;
     int i = 0;
-    for (; i + 32 <= D; i += 32)
-        for (int a = 0; a < 4; ++a)
-            for (int j = 0; j < 8; ++j) {
-                float d = z[i + 8 * a + j] - c[i + 8 * a + j];
-                acc[a][j] = acc[a][j] + d * d;
-            }
-    for (; i + 8 <= D; i += 8)
-        for (int j = 0; j < 8; ++j) {
-            float d = z[i + j] - c[i + j];
-            acc[0][j] = acc[0][j] + d * d;
+    while (i + level_step <= size_ilp) {
+        for (int j = 0; j < level_step; ++j, ++i)
+            for (int k = 0; k < 4; ++k)
+                for (int l = 0; l < W; ++l) {
+                    const int e = (4 * i + k) * W + l;
+                    const float d = z[e] - c[e];
+                    acc[0][k][l] = acc[0][k][l] + d * d;
+                }
+        for (int j = 1; j < 4; ++j) {
+            for (int k = 0; k < 4; ++k)
+                for (int l = 0; l < W; ++l) { acc[j][k][l] = acc[j][k][l] + acc[j - 1][k][l]; acc[j - 1][k][l] = 0.f; }
+            if ((i & (level_mask << (j * level_power))) != 0) break;
         }
-    float s = 0.f;
-    for (int j = 0; j < 8; ++j) {
-        float v = ((acc[0][j] + acc[1][j]) + acc[2][j]) + acc[3][j];
-        s = (j == 0) ? v : s + v;
     }
-    for (; i < D; ++i) { float d = z[i] - c[i]; s = s + d * d; }
+    for (; i < size_ilp; ++i)
+        for (int k = 0; k < 4; ++k)
+            for (int l = 0; l < W; ++l) {
+                const int e = (4 * i + k) * W + l;
+                const float d = z[e] - c[e];
+                acc[0][k][l] = acc[0][k][l] + d * d;
+            }
+    for (int j = 1; j < 4; ++j)
+        for (int k = 0; k < 4; ++k)
+            for (int l = 0; l < W; ++l) acc[0][k][l] = acc[0][k][l] + acc[j][k][l];
+    for (int v = 4 * size_ilp; v < nvec; ++v)
+        for (int l = 0; l < W; ++l) {
+            const float d = z[v * W + l] - c[v * W + l];
+            acc[0][0][l] = acc[0][0][l] + d * d;
+        }
+    for (int k = 1; k < 4; ++k)
+        for (int l = 0; l < W; ++l) acc[0][0][l] = acc[0][0][l] + acc[0][k][l];
+    if (W == 1) return acc[0][0][0];
+    float s = 0.f;
+    for (int t = nvec * 8; t < D; ++t) { const float d = z[t] - c[t]; s = s + d * d; }
+    for (int l = 0; l < 8; ++l) s = s + acc[0][0][l];
     return s;
 }
 

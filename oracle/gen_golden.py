@@ -179,6 +179,47 @@ def run_nearties(ref, name, seed, N, K, D, chunk):
           f"{int(((d2 - d1) / np.maximum(d2, 1e-30) < 1e-6).sum())}")
 
 
+def run_vq_nearties(ref, name, seed, N, K, D, chunk):
+    """The plain VQVAE's quantizer (VQVAE.quantize, vq:55-63: `(z_e.unsqueeze(1) - E).pow(2).sum(-1)`, argmin) on the same
+    adversarial near-tie rows: pins the `pow(2).sum(-1)` order -- cascade sum, scalar tail first -- at widths that are not
+    multiples of 8 (and one that is)."""
+    z, cb = O.make_neartie_case(seed, N, K, D)
+    m = ref.VQVAE(3, D, num_embeddings=K)
+    idxs, d1s, d2s = [], [], []
+    with torch.no_grad():
+        m.embedding.weight.copy_(torch.from_numpy(cb))
+        for s in range(0, N, chunk):
+            zt = torch.from_numpy(z[s:s + chunk])
+            zq, _ = m.quantize(zt)
+            dist = (zt.unsqueeze(1) - m.embedding.weight).pow(2).sum(-1)
+            idx = torch.argmin(dist, dim=1)
+            # quantize() returns z_e + (z_q - z_e).detach(): its argmin is recovered through the embedding row it picked
+            assert torch.equal(zt + (m.embedding(idx) - zt), zq), name
+            a, b = top2(dist)
+            idxs.append(idx), d1s.append(a), d2s.append(b)
+    idx = torch.cat(idxs).numpy()
+    d1, d2 = np.concatenate(d1s), np.concatenate(d2s)
+    np.savez_compressed(GOLD / f"{name}.npz", meta=meta_of(name=name, seed=seed, N=N, K=K, D=D, variant="vq-nearties"),
+                        seed=seed, N=N, K=K, D=D, indices=idx.astype(np.uint16), d_best=d1, d_second=d2)
+    print(f"{name}: N={N} K={K} D={D} exact fp32 ties: {int((d1 == d2).sum())}")
+
+
+def run_odd_width_all(v5, vq):
+    """Latent widths that are NOT multiples of 8 (the reference takes latent_dim from the observation encoder's width,
+    obs_nets.py:1193,1225-1227, which is arbitrary in low-dim mode): tails of 7, 4, 5, 4 and 3 elements after 0, 2, 4, 12 and 25
+    whole 8-vectors -- every branch of torch.norm's remainder handling (oracle/probe_torch_norm.py)."""
+    for i, D in enumerate((7, 20, 37, 100, 203)):
+        run_nearties(v5, f"llfq_nearties_d{D}_k512", 610 + i, 4096, 512, D, chunk=256)
+    for i, D in enumerate((7, 20, 64, 100, 203)):
+        run_vq_nearties(vq, f"vq_nearties_d{D}_k512", 620 + i, 2048, 512, D, chunk=256)
+    # whole modules at such widths (forward + backward + AdamW by the reference)
+    torch.set_num_threads(1)
+    orc = O.CanonicalOracle()
+    run_llfq(v5, "llfq_odd_d37", 631, 300, 7, 37, 256, full=True, oracle=orc)
+    run_llfq(v5, "llfq_odd_d203", 632, 96, 12, 203, 128, oracle=orc)
+    run_vq(vq, "vq_odd_d20", 633, 200, 7, 20, 64, oracle=orc)
+
+
 def run_llfq_train_compact(ref, name, seed, N, A, D, K, steps=3, oracle=None):
     """BASELINE config 5's tokenizer step at the REAL shape (obs_nets.py:2411 A = 12, latent = 208, K = 1024, N = 8 x 10 prompt
     actions): `steps` iterations of the reference's choreography (icl.py:913-914 zero_grad, forward, :968-970 backward + AdamW).
@@ -494,6 +535,7 @@ def main():
     ap.add_argument("--only-embed", action="store_true")
     ap.add_argument("--only-bin", action="store_true")
     ap.add_argument("--only-big", action="store_true")
+    ap.add_argument("--only-odd", action="store_true", help="only the near-tie fixtures at latent widths that are not multiples of 8")
     args = ap.parse_args()
     if args.only_embed:
         GOLD.mkdir(parents=True, exist_ok=True)
@@ -515,6 +557,8 @@ def main():
         return run_nearest_edge(v5, "llfq_nearest_edge")
     if args.only_big:
         return run_big_all(v5, O.CanonicalOracle())
+    if args.only_odd:
+        return run_odd_width_all(v5, vq)
     torch.set_num_threads(1)       # what the reference's train() sets (scripts/train.py:57)
     orc = O.CanonicalOracle()
     # BASELINE config 1 (CPU plumbing case), full fwd + bwd + AdamW
@@ -543,6 +587,7 @@ def main():
     run_default_all()
     run_bin_all(ref_root)
     run_big_all(v5, orc)
+    run_odd_width_all(v5, vq)
 
 
 def run_init(v5, vq):

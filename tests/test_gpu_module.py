@@ -40,7 +40,8 @@ def _grad_close(got, ref, name):
 
 
 LLFQ_CASES = ["llfq_cfg1_trained", "llfq_v5main_trained", "llfq_real_k1024", "llfq_default_init",
-              "llfq_cfg1_clamped", "llfq_cfg2_slice", "llfq_cfg3_slice", "llfq_ragged_n77", "llfq_n1"]
+              "llfq_cfg1_clamped", "llfq_cfg2_slice", "llfq_cfg3_slice", "llfq_ragged_n77", "llfq_n1",
+              "llfq_odd_d37", "llfq_odd_d203"]        # latent widths that are not multiples of 8
 
 
 @pytest.mark.parametrize("name", LLFQ_CASES)
@@ -78,7 +79,7 @@ def test_llfq_forward_vs_oracle_and_golden(name, oracle, golden_dir):
         assert np.abs(xr - g["x_recon"]).max() <= FLOAT_TOL
 
 
-@pytest.mark.parametrize("name", ["llfq_cfg1_trained", "llfq_v5main_trained"])
+@pytest.mark.parametrize("name", ["llfq_cfg1_trained", "llfq_v5main_trained", "llfq_odd_d37"])
 def test_llfq_training_step_vs_reference(name, oracle, golden_dir):
     from lipvq_vae_amd.tokenizer import LLFQVAE_V4
     g = np.load(golden_dir / f"{name}.npz")
@@ -123,7 +124,7 @@ def test_llfq_second_backward_and_grad_scale(oracle):
         _grad_close(v.grad.cpu().numpy() / 3.0, og[k], k)
 
 
-@pytest.mark.parametrize("name", ["vq_small_trained", "vq_main_trained", "vq_default_init"])
+@pytest.mark.parametrize("name", ["vq_small_trained", "vq_main_trained", "vq_default_init", "vq_odd_d20"])
 def test_vq_forward_backward(name, oracle, golden_dir):
     from lipvq_vae_amd.tokenizer import VQVAE
     g = np.load(golden_dir / f"{name}.npz")

@@ -119,6 +119,40 @@ def test_adversarial_near_ties_match_the_reference(ops, oracle, name, golden_dir
     assert np.array_equal(idx3.cpu().numpy(), ref)
 
 
+ODD_LLFQ = [f"llfq_nearties_d{d}_k512" for d in (7, 20, 37, 100, 203)]
+ODD_VQ = [f"vq_nearties_d{d}_k512" for d in (7, 20, 64, 100, 203)]
+
+
+@pytest.mark.parametrize("name", ODD_LLFQ)
+def test_adversarial_near_ties_odd_widths_match_the_reference(ops, name, golden_dir):
+    """Latent widths that are NOT multiples of 8 (the reference takes latent_dim from the observation encoder's width,
+    obs_nets.py:1193,1225-1227): tails of 7 / 4 / 5 / 4 / 3 elements after the 8-lane part.  torch.norm folds them as
+    "four rounded products in order, then the last one to three by fma" (oracle/probe_torch_norm.py); every row is a bisector
+    row, so a wrong order flips indices (round 2's did: 13-61 of 4096).  Indices AND the winning distance are the REFERENCE's."""
+    g = np.load(golden_dir / f"{name}.npz")
+    N, K, D = int(g["N"]), int(g["K"]), int(g["D"])
+    z, cb = O.make_neartie_case(int(g["seed"]), N, K, D)
+    ref = g["indices"].astype(np.int64)
+    idx, zq, best = ops.nearest(dev(z), dev(cb), want_best=True)
+    assert np.array_equal(idx.cpu().numpy(), ref)
+    assert np.array_equal(zq.cpu().numpy(), cb[ref])
+    assert np.array_equal(best.cpu().numpy(), g["d_best"])
+
+
+@pytest.mark.parametrize("name", ODD_VQ)
+def test_vq_adversarial_near_ties_match_the_reference(ops, name, golden_dir):
+    """The plain VQVAE's `pow(2).sum(-1)` rule (vq:57-63) on bisector rows decided by the REFERENCE's quantize(), at
+    D = 7 / 20 / 100 / 203 (scalar tail added before the lanes; below 8 columns torch's scalar path) and D = 64."""
+    g = np.load(golden_dir / f"{name}.npz")
+    N, K, D = int(g["N"]), int(g["K"]), int(g["D"])
+    z, cb = O.make_neartie_case(int(g["seed"]), N, K, D)
+    ref = g["indices"].astype(np.int64)
+    idx, zq, best = ops.nearest(dev(z), dev(cb), dist=O.DIST_SQSUM, want_best=True)
+    assert np.array_equal(idx.cpu().numpy(), ref)
+    assert np.array_equal(zq.cpu().numpy(), cb[ref])
+    assert np.array_equal(best.cpu().numpy(), g["d_best"])
+
+
 def test_small_but_nonzero_gaps_at_the_widest_latent(ops, oracle):
     """D = 208 (26 fma roundings per accumulator in the reference's own sum): rows with relative top-2 gaps from ~1e-6 to a
     few 1e-5 -- above exact ties, around the margin -- are decided exactly, and most of them by the exact kernel."""

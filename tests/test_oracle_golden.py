@@ -19,9 +19,10 @@ TOL = 1e-5
 LLFQ = sorted(Path(p).stem for p in glob.glob(str(GOLD / "llfq_*.npz"))
               if "nearest_edge" not in p and "nearties" not in p and "_train_" not in p and not p.endswith("_big.npz"))
 NEARTIES = sorted(Path(p).stem for p in glob.glob(str(GOLD / "llfq_nearties_*.npz")))
+VQ_NEARTIES = sorted(Path(p).stem for p in glob.glob(str(GOLD / "vq_nearties_*.npz")))
 BIG = sorted(Path(p).stem for p in glob.glob(str(GOLD / "llfq_*_big.npz")))
 NEAR_TIE = 1e-6      # relative top-2 distance gap (in the reference's own fp32 distances) below which an index may differ
-VQ = sorted(Path(p).stem for p in glob.glob(str(GOLD / "vq_*.npz")))
+VQ = sorted(Path(p).stem for p in glob.glob(str(GOLD / "vq_*.npz")) if "nearties" not in p)
 
 
 def _meta(g):
@@ -166,7 +167,25 @@ def test_adversarial_near_ties_exact(name, oracle):
     z, cb = O.make_neartie_case(int(g["seed"]), int(g["N"]), int(g["K"]), int(g["D"]))
     idx, _, _ = oracle.nearest(z, cb)
     assert np.array_equal(idx, g["indices"].astype(np.int64))
-    assert len(NEARTIES) >= 3
+    # ... and its two smallest distances are the reference's, bit for bit (a wrong summation order shows here first)
+    d = np.sort(oracle.distances(z, cb), axis=1)[:, :2]
+    assert np.array_equal(d[:, 0], g["d_best"]) and np.array_equal(d[:, 1], g["d_second"])
+    assert len(NEARTIES) >= 8 and {"llfq_nearties_d7_k512", "llfq_nearties_d20_k512", "llfq_nearties_d37_k512",
+                                   "llfq_nearties_d100_k512", "llfq_nearties_d203_k512"} <= set(NEARTIES)
+
+
+@pytest.mark.parametrize("name", VQ_NEARTIES)
+def test_vq_adversarial_near_ties_exact(name, oracle):
+    """The plain VQVAE's rule -- `(z_e.unsqueeze(1) - E).pow(2).sum(-1)` then argmin, vq:57-63 -- on bisector rows at
+    D = 7 / 20 / 64 / 100 / 203, decided by the REFERENCE's quantize(): torch's cascade sum adds the scalar tail BEFORE the
+    eight lanes, and below eight columns takes its scalar path; lq_sqdist32 restates both."""
+    g = np.load(GOLD / f"{name}.npz")
+    z, cb = O.make_neartie_case(int(g["seed"]), int(g["N"]), int(g["K"]), int(g["D"]))
+    idx, _, _ = oracle.nearest(z, cb, dist=O.DIST_SQSUM)
+    assert np.array_equal(idx, g["indices"].astype(np.int64))
+    d = np.sort(oracle.distances(z, cb, dist=O.DIST_SQSUM), axis=1)[:, :2]
+    assert np.array_equal(d[:, 0], g["d_best"]) and np.array_equal(d[:, 1], g["d_second"])
+    assert len(VQ_NEARTIES) >= 5
 
 
 def test_icrt_training_steps_k1024_restatement_vs_reference(oracle):
