@@ -5,9 +5,10 @@ A "step" is one pass of the tokenizer hot path (LLFQVAE_V4.tokenize: encoder MLP
 latent layer -> nearest code -> z_latent gather + code-usage histogram) over one synthetic
 batch that is already resident in HBM.  Workload (BASELINE.json configs[1]): B=4096, T=128,
 A=7, codebook K=1024 x D=64, fp32 everywhere (the parity mode: indices are bit-identical to
-the CPU oracle).  With N GPUs every rank tokenizes its own B x T batch (weak scaling, rows are
-independent) and the per-step code-usage histogram [K] int64 is all-reduced over RCCL -- the
-path's only cross-GPU dependency.
+the CPU oracle).  With N GPUs (BASELINE config 4) the GLOBAL batch stays B x T and is sharded
+B/N sequences per rank (`--scaling strong`, the default: value = global rows / max-over-ranks time); `--scaling weak`
+keeps the per-GPU batch at B x T instead.  Rows are independent: no data-path collective; the per-step code-usage
+histogram [K] int64 is all-reduced over RCCL -- the path's only cross-GPU dependency.
 
 Launching: `python bench.py --gpus N` from a plain shell starts the N ranks itself (the parent makes no
 GPU call; it runs `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process, relays
@@ -160,10 +161,22 @@ def measure_traffic_live(workload, kernels, timeout_s=150):
     try:
         for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
             d = os.path.join(tmp, kind)
-            r = subprocess.run([rp, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
-                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
-            if r.returncode != 0:
-                raise RuntimeError(f"rocprofv3 --pmc {counter} exited {r.returncode}: {r.stdout.decode(errors='replace')[-300:]}")
+            # the profiler and the bench child it starts run in a process group of their own: on a timeout the whole
+            # group is killed and reaped, so no orphan keeps the GPU busy after this function returns
+            pr = subprocess.Popen([rp, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
+            try:
+                out_b, _ = pr.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                pr.communicate()
+                raise RuntimeError(f"rocprofv3 --pmc {counter} timed out after {timeout_s} s (process group killed)")
+            if pr.returncode != 0:
+                raise RuntimeError(f"rocprofv3 --pmc {counter} exited {pr.returncode}: {out_b.decode(errors='replace')[-300:]}")
             acc = collections.defaultdict(list)
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
@@ -211,7 +224,11 @@ def rehearse(args, rank, world, backend):
     "rehearsal": true and no metric/value, so it can never be read as a bench result."""
     import torch.distributed as dist
     dist.init_process_group(backend)
-    K = WORKLOADS[args.workload][4]
+    from lipvq_vae_amd.sharded import shard_bounds       # host logic only (the rehearsal makes no GPU call)
+    B, K = WORKLOADS[args.workload][0], WORKLOADS[args.workload][4]
+    # the sharding of the real run: strong = this rank's share of the workload's B sequences, weak = B sequences per rank
+    b_lo, b_hi = shard_bounds(B, rank, world) if args.scaling == "strong" else (0, B)
+    seqs = torch.zeros(1, dtype=torch.int64)
     ubuf = [torch.zeros(K, dtype=torch.int64), torch.zeros(K, dtype=torch.int64)]
     pending = [None, None]
     total = torch.zeros(K, dtype=torch.int64)
@@ -224,6 +241,7 @@ def rehearse(args, rank, world, backend):
             total += ubuf[b]
         ubuf[b].zero_()
         ubuf[b][(rank + s) % K] += 1 + rank           # stand-in for the kernel's histogram of this rank's rows
+        seqs += b_hi - b_lo
         pending[b] = dist.all_reduce(ubuf[b], async_op=True)
     for b in (0, 1):
         if pending[b] is not None:
@@ -232,8 +250,10 @@ def rehearse(args, rank, world, backend):
     dist.barrier()
     tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(seqs)
     if rank == 0:
-        print(json.dumps({"rehearsal": True, "n_gpus": world, "world_size": dist.get_world_size(), "backend": dist.get_backend(),
+        print(json.dumps({"rehearsal": True, "scaling": args.scaling, "sequences_per_step_all_ranks": int(seqs.item()) // (args.warmup + args.steps),
+                          "n_gpus": world, "world_size": dist.get_world_size(), "backend": dist.get_backend(),
                           "steps": args.steps, "warmup": args.warmup, "usage_sum": int(total.sum()),
                           "expected_usage_sum": (args.warmup + args.steps) * world * (world + 1) // 2,
                           "elapsed_max_s": float(tmax.item())}), flush=True)
@@ -246,6 +266,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="strong", choices=("strong", "weak"),
+                    help="N > 1: strong = the workload's global batch sharded B/N per rank (BASELINE config 4 as SURVEY 8d defines "
+                         "it); weak = every rank tokenizes a full B x T batch of its own")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sustained", type=int, default=1000, help="back-to-back launches of the sustained reading (0 = skip)")
     ap.add_argument("--traffic", default="live", choices=("live", "file", "off"),
@@ -284,13 +307,28 @@ def main():
     from lipvq_vae_amd import ops
     from lipvq_vae_amd.tokenizer import LLFQVAE_V4
 
+    from lipvq_vae_amd.sharded import shard_batch, shard_bounds
+
     B, T, A, D, K = WORKLOADS[args.workload]
-    N = B * T
+    strong = args.scaling == "strong"
+    if strong and B < world:
+        raise SystemExit(f"--scaling strong: {B} sequences cannot be split over {world} ranks")
     torch.manual_seed(0)
     model = LLFQVAE_V4(A, D, num_codes=K).to(dev)
     trained_like_(model, A, seed=0)
-    gx = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    x = torch.randn(B, T, A, generator=gx).to(dev).reshape(N, A)     # flattened as tensor_utils.py:1066-1067 does
+    if strong:
+        # every rank draws the SAME global [B, T, A] batch and keeps its own B/world sequences (sharded.shard_bounds):
+        # the union over the ranks is the 1-GPU workload, row for row
+        xg = torch.randn(B, T, A, generator=torch.Generator(device="cpu").manual_seed(1234))
+        x = shard_batch(xg, rank, world).to(dev).contiguous()        # [B_local * T, A], flattened as tensor_utils.py:1066-1067 does
+        del xg
+        N_global = B * T
+    else:
+        gx = torch.Generator(device="cpu").manual_seed(1234 + rank)
+        x = torch.randn(B, T, A, generator=gx).to(dev).reshape(B * T, A)
+        N_global = world * B * T
+    N = x.shape[0]                                                   # rows THIS rank tokenizes per step
+    b_lo, b_hi = shard_bounds(B, rank, world) if strong else (0, B)
 
     # Per-step code-usage histograms, all-reduced in BUCKETS of M steps: two sets of M rows [M][K] int64; every step counts into
     # its own row, after M steps ONE asynchronous all-reduce covers the set (32 KiB for M = 4, K = 1024) while the next M steps
@@ -300,7 +338,9 @@ def main():
     # for its end: ~25-30 us of a 440 us step).  xGMI rings are per-link bound: fewer, larger messages.
     # LIPVQ_BENCH_COLLECTIVE=capi routes it through the library's own RCCL binding (lipvq_allreduce_counts, include/lipvq.h)
     # instead of torch.distributed's process group (the default: the same RCCL underneath).
-    M = max(1, int(os.environ.get("LIPVQ_BENCH_USAGE_BUCKET", "4")))
+    # Strong scaling shortens the step with the shard (65 536 rows per rank at N = 8), so the bucket grows with the world size:
+    # the collective's share of the wall clock stays what it is at one GPU's step length.
+    M = max(1, int(os.environ.get("LIPVQ_BENCH_USAGE_BUCKET", str(min(16, 4 * world) if strong else 4))))
     ubuf = [torch.zeros((M,) + tuple(model.code_usage.shape), dtype=model.code_usage.dtype, device=dev) for _ in range(2)]
     pending = [None, None]
     capi_comm = None
@@ -390,7 +430,7 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             el = float(tmax.item())
         sustained = {"launches": args.sustained, "seconds": el, "ms_per_step": 1e3 * el / args.sustained,
-                     "value": world * N * args.sustained / el, "unit": "actions/s",
+                     "value": N_global * args.sustained / el, "unit": "actions/s",
                      "order": "measured before the warm-up + timed steps of `value` (it also serves as their clock warm-up)"}
 
     for _ in range(args.warmup):
@@ -407,14 +447,14 @@ def main():
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        # every rank's last histogram is the GLOBAL one: world x N rows
+        # every rank's last histogram is the GLOBAL one: N_global rows
         usage_rows = int(last_row[0].sum().item())
     else:
         usage_rows = int(last_row[0].sum().item())
     idx_timed = idx.clone()
 
     tok_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / max(1, len(ev_pairs))
-    value = world * N * args.steps / elapsed
+    value = N_global * args.steps / elapsed
 
     # algorithmic work per launch: encoder 2*(A*64+64*128+128*D) + distance 2*K*D flop per row
     enc_flop = 2.0 * N * (A * 64 + 64 * 128 + 128 * D)
@@ -428,19 +468,6 @@ def main():
     peak_blend = algo_flop / t_floor / 1e12
     achieved = algo_flop / (tok_ms * 1e-3) / 1e12 if tok_ms > 0 else 0.0
     exact_rows = int(model.last_exact_rows[0]) if model.last_exact_rows is not None else None
-    traffic, traffic_src, traffic_detail = None, None, None
-    if args.traffic == "live" and world == 1 and not args.metric_only:
-        try:
-            traffic, traffic_src, traffic_detail = measure_traffic_live(
-                args.workload, ("tokenize_kernel", "nearest_rows") if ops.tokenize_supported(A, 64, model.hidden_dim, D, K)
-                else ("mlp3_wg_kernel", "screen_kernel", "nearest_rows"))
-        except Exception as e:  # noqa: BLE001 -- the profiler is optional equipment; the committed measurement stands in
-            traffic_src = f"live measurement failed ({type(e).__name__}: {str(e)[:200]}); "
-    tfile = ROOT / "profiles" / "hbm_traffic.json"           # PMC-derived bytes per launch (separate rocprofv3 --pmc runs)
-    if traffic is None and args.traffic != "off" and tfile.exists():
-        t = json.loads(tfile.read_text())
-        if t.get("workload") == args.workload:
-            traffic, traffic_src = t.get("bytes_per_launch"), (traffic_src or "") + "committed: " + str(t.get("source"))
     fused = ops.tokenize_supported(A, 64, model.hidden_dim, D, K)
     be = (f"{dist.get_backend()} world_size={dist.get_world_size()}, collective via "
           f"{'lipvq_allreduce_counts (C ABI -> RCCL)' if capi_comm is not None else 'torch.distributed'}"
@@ -448,11 +475,13 @@ def main():
     out = {
         "metric": "actions tokenized/sec (encode+quantize) at B=4096 T=128 K=1024, 1/2/4/8 GPU",
         "value": value, "unit": "actions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: B={B} T={T} action_dim={A} codebook K={K} d={D}, "
-                               f"fp32 encoder + fp32 argmin (parity mode), per-GPU batch fixed",
-                   "rows_per_gpu": N,
+                               f"fp32 encoder + fp32 argmin (parity mode), "
+                               + (f"global batch fixed: {B} sequences sharded {b_hi - b_lo} per GPU" if strong else
+                                  f"per-GPU batch fixed at {B} sequences (global {world * B})"),
+                   "rows_per_gpu": N, "global_rows": N_global,
                    "parallelism": f"batch-sharded x{world} ({be}), per-step code usage [K] int64 all-reduced in "
                                   f"buckets of {M} steps, overlapped with the following steps",
                    "global_usage_rows_last_step": usage_rows},
@@ -461,7 +490,7 @@ def main():
                                 "mlp3_wg_kernel + screen_kernel (+ nearest_rows_kernel for uncertified rows)"),
                      "achieved": achieved, "peak": peak_blend, "unit": "TFLOP/s", "frac": achieved / peak_blend,
                      "frac_algorithmic_floor": (t_floor_alg * 1e3) / tok_ms if tok_ms > 0 else 0.0,
-                     "traffic": traffic, "traffic_source": traffic_src, "traffic_detail": traffic_detail,
+                     "traffic": None, "traffic_source": None, "traffic_detail": None,
                      "ms_per_launch": tok_ms, "algorithmic_flop_per_launch": algo_flop,
                      "floor_ms": t_floor * 1e3, "floor_algorithmic_ms": t_floor_alg * 1e3,
                      "peak_note": "frac: algorithmic flop / (encoder flop / 157.3 TF/s fp32 MFMA + 3 x distance flop / 2500 TF/s "
@@ -525,6 +554,22 @@ def main():
                                         "what": "forward(x) without autograd: encode + quantize + decode + three losses"},
                        "train_step": {"value": N / (ts_ms * 1e-3), "unit": "actions/s", "ms_per_step": ts_ms,
                                       "what": "zero_grad + forward + loss.backward() + AdamW.step() (icl.py:913-914, 968-970)"}}
+    # HBM traffic LAST among the GPU readings: the profiler children run after every timed side reading (and are reaped before
+    # this process goes on), so nothing of them can overlap a measurement
+    traffic, traffic_src, traffic_detail = None, None, None
+    if args.traffic == "live" and world == 1 and not args.metric_only:
+        try:
+            traffic, traffic_src, traffic_detail = measure_traffic_live(
+                args.workload, ("tokenize_kernel", "nearest_rows") if ops.tokenize_supported(A, 64, model.hidden_dim, D, K)
+                else ("mlp3_wg_kernel", "screen_kernel", "nearest_rows"))
+        except Exception as e:  # noqa: BLE001 -- the profiler is optional equipment; the committed measurement stands in
+            traffic_src = f"live measurement failed ({type(e).__name__}: {str(e)[:200]}); "
+    tfile = ROOT / "profiles" / "hbm_traffic.json"           # PMC-derived bytes per launch (separate rocprofv3 --pmc runs)
+    if traffic is None and args.traffic != "off" and tfile.exists():
+        t = json.loads(tfile.read_text())
+        if t.get("workload") == args.workload:
+            traffic, traffic_src = t.get("bytes_per_launch"), (traffic_src or "") + "committed: " + str(t.get("source"))
+    out["roofline"].update({"traffic": traffic, "traffic_source": traffic_src, "traffic_detail": traffic_detail})
     failed = False
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], gate = cpu_baseline(model, x, idx_timed)

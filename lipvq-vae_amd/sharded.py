@@ -46,7 +46,13 @@ def all_reduce_usage(usage: torch.Tensor, group=None) -> torch.Tensor:
     if usage.dtype != torch.int64:
         raise TypeError("usage histogram must be int64")
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(usage, op=dist.ReduceOp.SUM, group=group)
+        if usage.is_cuda and dist.get_backend(group) == "gloo":
+            # rehearsal transport (ranks sharing one GPU): gloo moves host memory; 8 KiB through the host and back
+            host = usage.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            usage.copy_(host)
+        else:
+            dist.all_reduce(usage, op=dist.ReduceOp.SUM, group=group)
     return usage
 
 

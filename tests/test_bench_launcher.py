@@ -33,6 +33,15 @@ def test_plain_invocation_spawns_ranks_and_relays_one_line(world):
     assert out["steps"] == 4 and out["warmup"] == 1
     # every step's histogram was reduced over ALL ranks exactly once (rank r contributes r + 1 per step)
     assert out["usage_sum"] == out["expected_usage_sum"] == 5 * world * (world + 1) // 2
+    # default = strong scaling (BASELINE config 4 as SURVEY 8d defines it): the ranks' shards add up to the workload's B sequences
+    assert out["scaling"] == "strong" and out["sequences_per_step_all_ranks"] == 4096
+
+
+def test_weak_scaling_keeps_the_per_gpu_batch():
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--rehearse-launcher", "--scaling", "weak"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["scaling"] == "weak" and out["sequences_per_step_all_ranks"] == 2 * 4096
 
 
 def test_child_failure_is_relayed_as_exit_status():
