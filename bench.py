@@ -505,19 +505,24 @@ def main():
     if world == 1 and not args.metric_only and ops.tokenize_fast_supported(A, 64, model.hidden_dim, D, K):
         # reported beside the metric, never as `value`: the opt-in fast mode (fp16 encoder GEMMs, fp32 accumulation and
         # quantizer) on the same batch, with the fraction of indices that differ from the parity run above
-        for _ in range(3):
+        # Same discipline as the metric: a clock warm-up of the kernel being timed, then a loop long enough not to be a burst
+        # reading (round 2 timed 20 launches right behind three warm-ups: 0.381 ms, while 200-launch loops of the same build on
+        # the same box read 0.330 -- profiles/r03_a_fast_mode_bisect.txt).
+        nf = max(args.steps, 200)
+        for _ in range(100):
             model.tokenize(x, count_usage=False, mode="fast")
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(args.steps):
+        for _ in range(nf):
             idx_fast, _ = model.tokenize(x, count_usage=False, mode="fast")
         e1.record()
         torch.cuda.synchronize()
-        fast_ms = e0.elapsed_time(e1) / args.steps
+        fast_ms = e0.elapsed_time(e1) / nf
         out["fast_mode"] = {"value": N / (fast_ms * 1e-3), "unit": "actions/s", "ms_per_step": fast_ms,
                             "dtype": "f16 encoder operands, f32 accumulation, f32 quantizer",
                             "index_flip_rate_vs_parity": float((idx_fast != idx_timed).float().mean().item()),
+                            "launches_timed": nf,
                             "note": "opt-in (tokenize(mode='fast')); not bit-identical, hence not the reported value"}
     if world == 1 and not args.metric_only:
         # "report also full fwd (+decode+loss) and fwd+bwd+AdamW step" -- same batch, a few steps each,
