@@ -114,6 +114,14 @@ int lipvq_nearest_screened_f32(const float* z, const float* codebook, const void
  * changes every step).  D in {32, 64, 128, 208}. */
 int lipvq_nearest_rows_f32(const float* z, const float* codebook, int64_t* idx, float* zq, int64_t* usage, int64_t N,
                            int K, int D, void* stream);
+/* The plain VQVAE's quantizer (reference robomimic/models/vq_vae/backbone.py:55-63: `(z_e.unsqueeze(1) - E).pow(2).sum(-1)`,
+ * argmin) through the same two routes: idx / zq / usage exactly as lipvq_nearest_f32(.., LIPVQ_DIST_SQSUM).  The screen is the
+ * same certified MFMA screen (its margin covers the sum rule's rounding too); uncertified rows are decided by the exact kernel in
+ * torch's cascade-sum order, first minimum.  prep / workspace as for lipvq_nearest_screened_f32.  D in {32, 64, 128, 208}. */
+int lipvq_vq_nearest_screened_f32(const float* z, const float* codebook, const void* prep, int64_t* idx, float* zq,
+                                  int64_t* usage, void* workspace, int64_t N, int K, int D, void* stream);
+int lipvq_vq_nearest_rows_f32(const float* z, const float* codebook, int64_t* idx, float* zq, int64_t* usage, int64_t N,
+                              int K, int D, void* stream);
 /* Test hook: also dumps the approximate distances d~ [N][Kpad] (Kpad = K rounded up to 32) and takes
  * the error-bound factor gamma from the caller. */
 int lipvq_screen_debug_f32(const float* z, const float* codebook, const void* prep, int64_t* idx, float* zq,

@@ -47,6 +47,8 @@ SIGNATURES = {
     "lipvq_nearest_workspace_bytes": (_sz, [_i64]),
     "lipvq_nearest_screened_f32": (_i, [_vp] * 7 + [_i64, _i, _i, _vp]),
     "lipvq_nearest_rows_f32": (_i, [_vp] * 5 + [_i64, _i, _i, _vp]),
+    "lipvq_vq_nearest_screened_f32": (_i, [_vp] * 7 + [_i64, _i, _i, _vp]),
+    "lipvq_vq_nearest_rows_f32": (_i, [_vp] * 5 + [_i64, _i, _i, _vp]),
     "lipvq_screen_debug_f32": (_i, [_vp] * 8 + [C.c_float, _i64, _i, _i, _vp]),
     "lipvq_tokenize_supported": (_i, [_i] * 5),
     "lipvq_tokenize_fast_supported": (_i, [_i] * 5),

@@ -120,7 +120,7 @@ class _VQFn(torch.autograd.Function):
             z_e, pre_e = ops.mlp3(x, enc_packed, _RELU3, save_pre=True)
         else:
             z_e, pre_e = ops.mlp3(x, enc_packed, _RELU3), None
-        idx, z_q, _ = ops.nearest(z_e, E, DIST_SQSUM, usage=module.code_usage)
+        idx, z_q = module._quantize(z_e, module.code_usage)       # vq:57-66 (screened / exact rows / all-pairs: same results)
         z_st = ops.ste(z_e, z_q)                                   # vq:74
         if need_grad:
             x_rec, pre_d = ops.mlp3(z_st, dec_packed, _RELU3, save_pre=True)

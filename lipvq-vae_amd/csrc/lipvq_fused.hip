@@ -37,12 +37,24 @@
 #endif
 // stage ring of the fused kernel (LDS left beside the encoder weights): S <= 4: four buffers of two/four tiles; S = 8: the
 // weights take 98 KB, three buffers of one tile
+// The Lipschitz layer's weights are STREAMED through the stage ring (instead of living in LDS) from this many k-steps on:
+// 13 (D = 208) has no choice -- 112 KB of A operands; for 8 (D = 128) it is a trade measured in round 3: 64 KB of LDS go from
+// a phase that is a twentieth of the work at K = 8192 to the codebook ring of the phase that is the rest.
+#ifndef LQ_STREAM2_MIN_S
+#define LQ_STREAM2_MIN_S 9
+#endif
+#ifndef LQ_RING8_TC
+#define LQ_RING8_TC 1
+#endif
+#ifndef LQ_RING8_NB
+#define LQ_RING8_NB 3
+#endif
 #ifdef LQ_EXP_RING_TC             /* experiment builds: the S = 4 instance's ring shape from the command line */
-constexpr int fused_ring_tc(int S) { return S == 4 ? LQ_EXP_RING_TC : (S <= 2) ? 4 : (S <= 4) ? 2 : 1; }
-constexpr int fused_ring_nb(int S) { return S == 4 ? LQ_EXP_RING_NB : (S <= 4) ? 4 : 3; }
+constexpr int fused_ring_tc(int S) { return S == 4 ? LQ_EXP_RING_TC : (S <= 2) ? 4 : (S <= 4) ? 2 : (S == 8) ? LQ_RING8_TC : 1; }
+constexpr int fused_ring_nb(int S) { return S == 4 ? LQ_EXP_RING_NB : (S <= 4) ? 4 : (S == 8) ? LQ_RING8_NB : 3; }
 #else
-constexpr int fused_ring_tc(int S) { return (S <= 2) ? 4 : (S <= 4) ? 2 : 1; }
-constexpr int fused_ring_nb(int S) { return (S <= 4) ? 4 : 3; }
+constexpr int fused_ring_tc(int S) { return (S <= 2) ? 4 : (S <= 4) ? 2 : (S == 8) ? LQ_RING8_TC : 1; }
+constexpr int fused_ring_nb(int S) { return (S <= 4) ? 4 : (S == 8) ? LQ_RING8_NB : 3; }
 #endif
 #ifndef LQ_EXP_WGS_PER_CU
 #define LQ_EXP_WGS_PER_CU 1
@@ -115,7 +127,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
     // STREAM2: the Lipschitz layer's weights (T2 x 16 KB of fp32 MFMA A operands: 112 KB at D = 208) do not fit beside the stage
     // ring, so they are streamed, one 16 KB output-tile slab at a time, through that ring -- which is idle during the encoder
     // phase -- by the same LDS-DMA + counted-vmcnt mechanism as the codebook (all eight waves work on the same tile).
-    constexpr bool STREAM2 = !FAST && S > 8;
+    constexpr bool STREAM2 = !FAST && S >= LQ_STREAM2_MIN_S;
     static_assert(!FAST || (S % 2 == 0 && S <= 8), "fast mode: D in {32, 64, 128}");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
@@ -680,7 +692,7 @@ static size_t fused_lds_bytes(int A, int K) {
     const int S0q = ((A + 1) / 2 + 3) / 4;
     const int S0h = (A + 15) / 16;
     size_t fl = FAST ? (size_t)T0 * S0h * 256 + (size_t)T1 * (2 * T0) * 256 + (size_t)T2 * (2 * T1) * 256
-                     : (size_t)T0 * S0q * 256 + (size_t)T1 * 8 * 256 + (S > 8 ? (size_t)0 : (size_t)T2 * 16 * 256);
+                     : (size_t)T0 * S0q * 256 + (size_t)T1 * 8 * 256 + (S >= LQ_STREAM2_MIN_S ? (size_t)0 : (size_t)T2 * 16 * 256);
     fl += 32 * T0 + 32 * T1 + 32 * T2 + 16 * S;
     const size_t ring = (lq_ring_bytes<S, fused_ring_tc(S), fused_ring_nb(S)>() + 63) & ~(size_t)63;
     return fl * sizeof(float) + ring + (K <= FUSED_HIST_MAX ? (size_t)K * 4 : 0);
@@ -750,7 +762,7 @@ extern "C" int lipvq_tokenize_fast_supported(int A, int J0, int J1, int D, int K
 
 // layer-2 weights of the streamed instance (D = 208): [t][16 groups][64 lanes][4 k-steps], i.e. the LDS image of one output
 // tile's A operands as contiguous 16 KB slabs, so that the kernel can copy them with the LDS-DMA
-static size_t w2q_floats(int D) { return D > 128 ? (size_t)((D + 31) / 32) * 16 * 256 : 0; }
+static size_t w2q_floats(int D) { return (D + 15) / 16 >= LQ_STREAM2_MIN_S ? (size_t)((D + 31) / 32) * 16 * 256 : 0; }
 
 __global__ void w2q_pack_kernel(const float* __restrict__ P2, float* __restrict__ out, int T2, int S2) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

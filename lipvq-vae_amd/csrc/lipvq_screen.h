@@ -91,6 +91,13 @@ struct StandaloneScreen {
 // smallest value carries its own code and no index array is kept: med3 + min on the packed floats (3 instructions + the fma
 // instead of 4 + the fma, and 16 registers less).  The perturbation, below 2^(TB-23) of the value's own magnitude, is part of
 // the certification margin (lq_screen_decide, pack_eps).  id = the code (unpacked) or the tile index (packed).
+// LQ_ABL_NOE2 (ablation build, wrong results): the |e'|^2 f term is dropped -- what a bookkeeping of 3 instead of 4 vector
+// instructions per element (the term folded into the chain's C operand at no cost) could gain AT MOST
+#ifdef LQ_ABL_NOE2
+#define LQ_E2_TERM(e2, f, a) (a)
+#else
+#define LQ_E2_TERM(e2, f, a) lq_fma(e2, f, a)
+#endif
 template <bool PACK>
 __device__ __forceinline__ void lq_track_one(float v, int id, unsigned keep_mask, float& m1, float& m2, int& k1) {
     if constexpr (PACK) {
@@ -119,7 +126,7 @@ __device__ __forceinline__ void lq_track_part(const f32x16& acc, float e2, const
     return;
 #endif
 #pragma unroll
-    for (int r = LO; r < HI; ++r) lq_track_one<PACK>(lq_fma(e2, frow[r], acc[r]), id, keep_mask, m1[r], m2[r], k1[r]);
+    for (int r = LO; r < HI; ++r) lq_track_one<PACK>(LQ_E2_TERM(e2, frow[r], acc[r]), id, keep_mask, m1[r], m2[r], k1[r]);
 }
 
 // the pending tile's registers that are booked behind MFMA j of the 3 S MFMAs of the running tile: [16 j / 3S, 16 (j + 1) / 3S)
@@ -134,7 +141,7 @@ __device__ __forceinline__ void lq_track_after_mfma(int j, const f32x16& acc, fl
     const int lo = (16 * j) / (3 * S), hi = (16 * (j + 1)) / (3 * S);
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-        if (r >= lo && r < hi) lq_track_one<PACK>(lq_fma(e2, frow[r], acc[r]), id, keep_mask, m1[r], m2[r], k1[r]);
+        if (r >= lo && r < hi) lq_track_one<PACK>(LQ_E2_TERM(e2, frow[r], acc[r]), id, keep_mask, m1[r], m2[r], k1[r]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -619,8 +626,10 @@ __host__ __device__ static inline size_t lq_list_ints(int64_t N) { return ((size
 __host__ __device__ static inline size_t lq_lists_bytes(int64_t N) { return sizeof(int) * (2 * lq_list_ints(N) + 16 * lq_cand_cap(N)); }
 
 // exact decision for listed rows (lipvq_screen.hip); z_by_slot: z is a compact [count][D] buffer
+// dist: LIPVQ_DIST_NORM (v5:43-46: torch.norm's order, roots compared) or LIPVQ_DIST_SQSUM (vq:57-63: pow(2).sum's order)
 int lipvq_launch_rows(const float* z, int z_by_slot, const float* cb, int64_t* idx, float* zq, int64_t* usage,
-                      const int* amb_list, const int* amb_count, int64_t N, int K, int D, hipStream_t st);
+                      const int* amb_list, const int* amb_count, int64_t N, int K, int D, hipStream_t st,
+                      int dist = LIPVQ_DIST_NORM);
 // the same for rows whose z_e was never stored: recomputed from x with the raw (unpacked) encoder weights
 // raw6 = {W0, b0, W1, b1, W2 (Lipschitz-normalised), b2}
 int lipvq_launch_rows_encode(const float* x, const float* const* raw6, int A, const float* cb, int64_t* idx, float* zq,

@@ -251,10 +251,51 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
 // already reaches the best square so far proves the full square does too, and the rest of that code's row is not
 // fetched.  Same results bit for bit; the scan is bound by re-reading the codebook (1.15 ms for 3 317 rows at K = 8192,
 // D = 128 without the early exit).
-template <int DCH, bool SEEDED = false>
+// The plain VQVAE's distance (vq:57-60, `(z_e.unsqueeze(1) - E).pow(2).sum(-1)`) of one row in registers against one code:
+// lq_sqdist32's order for D = 8 DCH < 512 (rounded squares; 8-vector i -> accumulator i mod 4 while whole groups of four remain,
+// left-overs -> accumulator 0; accumulators 1..3 added to 0; lanes left to right) -- the same code as nearest_direct_kernel.
+template <int DCH>
+__device__ __forceinline__ float lq_sq32_row(const float (&zr)[DCH * 8], const float4* __restrict__ c4) {
+    static_assert(DCH < 64, "the cascade of torch's sum starts at D = 512");
+    float acc[4][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int l = 0; l < 8; ++l) acc[q][l] = 0.f;
+#pragma unroll
+    for (int i = 0; i < DCH; ++i) {
+        const int q = (i < (DCH / 4) * 4) ? (i & 3) : 0;
+        const float4 lo = c4[2 * i], hi = c4[2 * i + 1];
+        const float d0 = zr[8 * i + 0] - lo.x, d1 = zr[8 * i + 1] - lo.y;
+        const float d2 = zr[8 * i + 2] - lo.z, d3 = zr[8 * i + 3] - lo.w;
+        const float d4 = zr[8 * i + 4] - hi.x, d5 = zr[8 * i + 5] - hi.y;
+        const float d6 = zr[8 * i + 6] - hi.z, d7 = zr[8 * i + 7] - hi.w;
+        acc[q][0] = acc[q][0] + d0 * d0; acc[q][1] = acc[q][1] + d1 * d1;
+        acc[q][2] = acc[q][2] + d2 * d2; acc[q][3] = acc[q][3] + d3 * d3;
+        acc[q][4] = acc[q][4] + d4 * d4; acc[q][5] = acc[q][5] + d5 * d5;
+        acc[q][6] = acc[q][6] + d6 * d6; acc[q][7] = acc[q][7] + d7 * d7;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+        const float v = ((acc[0][l] + acc[1][l]) + acc[2][l]) + acc[3][l];
+        s = (l == 0) ? v : s + v;
+    }
+    return s;
+}
+
+template <int DCH, bool SEEDED = false, int DIST = LIPVQ_DIST_NORM>
 __device__ __forceinline__ void lq_exact_scan(const float (&zr)[DCH * 8], const float* __restrict__ cb, int kb, int ke,
                                               float& best_v, float& best_s, int& best_k, float s_prune = INFINITY) {
     constexpr int D = DCH * 8;
+    if constexpr (DIST == LIPVQ_DIST_SQSUM) {
+        // the compared value IS the sum (no root, so no two sums share a value they do not have): first minimum over ascending k
+        for (int k = kb; k < ke; ++k) {
+            const float v = lq_sq32_row<DCH>(zr, reinterpret_cast<const float4*>(cb + (size_t)k * D));
+            if (v < best_v) { best_v = v; best_s = v; best_k = k; }
+        }
+        return;
+    }
 #ifdef LQ_SCAN_G
     constexpr int G = LQ_SCAN_G;
 #else
@@ -332,7 +373,7 @@ __device__ __forceinline__ float lq_seed_bound(const float (&zr)[DCH * 8], const
 //  * nothing: codes [sl per, (sl+1) per) are scanned; the screen's best candidate, when there is one, bounds both kinds of scan.
 // Returns the slice's (root, code); the caller takes the smallest root, the LOWER CODE among equal roots (torch.argmin's
 // first-minimum rule, v5:46).
-template <int DCH, int SL>
+template <int DCH, int SL, int DIST = LIPVQ_DIST_NORM>
 __device__ __forceinline__ void lq_rows_search(const float (&zr)[DCH * 8], const float* __restrict__ cb, int K, int sl, int cslot,
                                                const int* __restrict__ seed_list, const int* __restrict__ cand_list,
                                                size_t cand_cap, float& best_v, int& best_k) {
@@ -354,6 +395,12 @@ __device__ __forceinline__ void lq_rows_search(const float (&zr)[DCH * 8], const
         const int code = j < n0 ? cl[2 + j] : cl[10 + (j - n0)];
         if (code >= 0 && code < K) {                              // (lq_screen_emit lists valid codes only)
             const float4* c4 = reinterpret_cast<const float4*>(cb + (size_t)code * D);
+            if constexpr (DIST == LIPVQ_DIST_SQSUM) {
+                const float v = lq_sq32_row<DCH>(zr, c4);
+                best_k = code;
+                best_v = (v == v) ? v : INFINITY;
+                return;
+            }
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
 #pragma unroll
             for (int i = 0; i < DCH; ++i) {
@@ -377,7 +424,7 @@ __device__ __forceinline__ void lq_rows_search(const float (&zr)[DCH * 8], const
     if (seed_list) {                         // rows listed by the screen come with its best candidate
         int seed = seed_list[cslot];
         seed = (seed >= 0 && seed < K) ? seed : 0;
-        prune = lq_seed_bound<DCH>(zr, cb, seed);
+        if constexpr (DIST == LIPVQ_DIST_NORM) prune = lq_seed_bound<DCH>(zr, cb, seed);      // (the sum rule scans without early exits)
     }
     if (n0 != -1 && n1 != -1 && cl) {
         // lane masks (at least one part said -2; a part with a short list contributes the lanes of its mask all the same)
@@ -389,13 +436,13 @@ __device__ __forceinline__ void lq_rows_search(const float (&zr)[DCH * 8], const
                 const int l = __builtin_ctz(m);
                 m &= m - 1;
                 const int k = 32 * t + l;
-                if (k < K) lq_exact_scan<DCH, true>(zr, cb, k, k + 1, best_v, best_s, best_k, prune);
+                if (k < K) lq_exact_scan<DCH, true, DIST>(zr, cb, k, k + 1, best_v, best_s, best_k, prune);
             }
         }
         return;
     }
-    if (seed_list) lq_exact_scan<DCH, true>(zr, cb, kb, ke, best_v, best_s, best_k, prune);
-    else lq_exact_scan<DCH>(zr, cb, kb, ke, best_v, best_s, best_k);
+    if (seed_list) lq_exact_scan<DCH, true, DIST>(zr, cb, kb, ke, best_v, best_s, best_k, prune);
+    else lq_exact_scan<DCH, false, DIST>(zr, cb, kb, ke, best_v, best_s, best_k);
 }
 
 // (root, code) of a row over its SL slices: smallest root, among equal roots the lower code (first-minimum rule).  Thread
@@ -424,7 +471,7 @@ __device__ __forceinline__ void lq_rows_reduce(float& bv, int& bk, float (*s_v)[
 // ------------------------------------------------------------------------------------------
 // exact decision for the listed rows: 4 rows x 64 code slices per workgroup
 // ------------------------------------------------------------------------------------------
-template <int DCH>
+template <int DCH, int DIST = LIPVQ_DIST_NORM>
 __global__ __launch_bounds__(256) void nearest_rows_kernel(
     const float* __restrict__ z, const float* __restrict__ cb, int64_t* __restrict__ idx, float* __restrict__ zq,
     unsigned long long* __restrict__ usage, const int* __restrict__ row_list, const int* __restrict__ row_count,
@@ -451,7 +498,7 @@ __global__ __launch_bounds__(256) void nearest_rows_kernel(
     }
     float best_v;
     int best_k;
-    lq_rows_search<DCH, SL>(zr, cb, K, sl, cslot, seed_list, cand_list, cand_cap, best_v, best_k);
+    lq_rows_search<DCH, SL, DIST>(zr, cb, K, sl, cslot, seed_list, cand_list, cand_cap, best_v, best_k);
     lq_rows_reduce(best_v, best_k, s_v, s_k, r, threadIdx.x);
     if (sl == 0) {
         if (valid) idx[row] = (int64_t)best_k;
@@ -472,7 +519,7 @@ __global__ __launch_bounds__(256) void nearest_rows_kernel(
 // One row per workgroup, 256 code slices: the training-step route (every row of a batch of a few hundred rows is decided
 // exactly, lipvq_nearest_rows_f32).  With 4 rows x 64 slices a thread walked K/64 codes one after the other -- 16 dependent
 // row fetches at K = 1024: 45 us for 80 rows, as long as both MLP launches of the step together; here it walks K/256.
-template <int DCH>
+template <int DCH, int DIST = LIPVQ_DIST_NORM>
 __global__ __launch_bounds__(256) void nearest_rows1_kernel(const float* __restrict__ z, const float* __restrict__ cb,
                                                             int64_t* __restrict__ idx, float* __restrict__ zq,
                                                             unsigned long long* __restrict__ usage, int count, int K) {
@@ -493,7 +540,7 @@ __global__ __launch_bounds__(256) void nearest_rows1_kernel(const float* __restr
         const int kb = tid * per, ke = (kb + per < K) ? kb + per : K;
         float bv = INFINITY, bs = INFINITY;
         int bk = kb < K ? kb : K - 1;
-        lq_exact_scan<DCH>(zr, cb, kb, ke, bv, bs, bk);
+        lq_exact_scan<DCH, false, DIST>(zr, cb, kb, ke, bv, bs, bk);
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const float ov = __shfl_xor(bv, off, 64);
@@ -721,18 +768,18 @@ static int launch_screen(const float* z, const unsigned char* prep, const float*
     return check_launch("screen");
 }
 
-template <int DCH>
+template <int DCH, int DIST = LIPVQ_DIST_NORM>
 static int launch_rows_t(const float* z, int z_by_slot, const float* cb, int64_t* idx, float* zq, int64_t* usage,
                          const int* amb_list, const int* amb_count, int64_t N, int K, hipStream_t st) {
     if (!amb_list && N <= 4096 && K >= 512) {                // every row of a small batch: one row per workgroup
-        hipLaunchKernelGGL((nearest_rows1_kernel<DCH>), dim3((unsigned)N), dim3(256), 0, st, z, cb, idx, zq,
+        hipLaunchKernelGGL((nearest_rows1_kernel<DCH, DIST>), dim3((unsigned)N), dim3(256), 0, st, z, cb, idx, zq,
                            (unsigned long long*)usage, (int)N, K);
         return check_launch("nearest_rows1");
     }
     // the count lives on the device: a bounded grid strides over however many rows were listed
     int64_t blocks = (N + 3) / 4;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL((nearest_rows_kernel<DCH>), dim3((unsigned)blocks), dim3(256), 0, st, z, cb, idx, zq,
+    hipLaunchKernelGGL((nearest_rows_kernel<DCH, DIST>), dim3((unsigned)blocks), dim3(256), 0, st, z, cb, idx, zq,
                        (unsigned long long*)usage, amb_list, amb_count, K, z_by_slot, amb_list ? 0 : (int)N,
                        amb_list ? amb_list + lq_list_ints(N) : nullptr, amb_list ? amb_list + 2 * lq_list_ints(N) : nullptr,
                        amb_list ? lq_cand_cap(N) : (size_t)0);
@@ -740,7 +787,16 @@ static int launch_rows_t(const float* z, int z_by_slot, const float* cb, int64_t
 }
 
 int lipvq_launch_rows(const float* z, int z_by_slot, const float* cb, int64_t* idx, float* zq, int64_t* usage,
-                      const int* amb_list, const int* amb_count, int64_t N, int K, int D, hipStream_t st) {
+                      const int* amb_list, const int* amb_count, int64_t N, int K, int D, hipStream_t st, int dist) {
+    if (dist == LIPVQ_DIST_SQSUM) {
+        switch (D) {
+            case 32: return launch_rows_t<4, LIPVQ_DIST_SQSUM>(z, z_by_slot, cb, idx, zq, usage, amb_list, amb_count, N, K, st);
+            case 64: return launch_rows_t<8, LIPVQ_DIST_SQSUM>(z, z_by_slot, cb, idx, zq, usage, amb_list, amb_count, N, K, st);
+            case 128: return launch_rows_t<16, LIPVQ_DIST_SQSUM>(z, z_by_slot, cb, idx, zq, usage, amb_list, amb_count, N, K, st);
+            case 208: return launch_rows_t<26, LIPVQ_DIST_SQSUM>(z, z_by_slot, cb, idx, zq, usage, amb_list, amb_count, N, K, st);
+            default: return fail(LIPVQ_EUNSUPPORTED, "nearest_rows: D=%d has no instance", D);
+        }
+    }
     switch (D) {
         case 32: return launch_rows_t<4>(z, z_by_slot, cb, idx, zq, usage, amb_list, amb_count, N, K, st);
         case 64: return launch_rows_t<8>(z, z_by_slot, cb, idx, zq, usage, amb_list, amb_count, N, K, st);
@@ -752,7 +808,7 @@ int lipvq_launch_rows(const float* z, int z_by_slot, const float* cb, int64_t* i
 
 static int screened_impl(const float* z, const float* cb, const void* prep, int64_t* idx, float* zq,
                          int64_t* usage, void* workspace, float* dbg, int64_t N, int K, int D, float gamma,
-                         hipStream_t st) {
+                         hipStream_t st, int dist = LIPVQ_DIST_NORM) {
     int* amb_count = (int*)workspace;
     int* amb_list = (int*)((unsigned char*)workspace + 64);
     hipError_t e = hipMemsetAsync(amb_count, 0, 64, st);
@@ -767,7 +823,7 @@ static int screened_impl(const float* z, const float* cb, const void* prep, int6
         default: return fail(LIPVQ_EUNSUPPORTED, "nearest_screened: D=%d has no screening instance (32, 64, 128, 208)", D);
     }
     if (rc) return rc;
-    return lipvq_launch_rows(z, 0, cb, idx, zq, usage, amb_list, amb_count, N, K, D, st);
+    return lipvq_launch_rows(z, 0, cb, idx, zq, usage, amb_list, amb_count, N, K, D, st, dist);
 }
 
 extern "C" int lipvq_nearest_screened_supported(int K, int D) {
@@ -801,6 +857,29 @@ extern "C" int lipvq_nearest_screened_f32(const float* z, const float* codebook,
         return fail(LIPVQ_EINVAL, "nearest_screened: z, codebook and zq must be 16-byte aligned");
     return screened_impl(z, codebook, prep, idx, zq, usage, workspace, nullptr, N, K, D, LIPVQ_SCREEN_GAMMA,
                          (hipStream_t)stream);
+}
+
+// The plain VQVAE's rule (vq:57-63) through the same two routes (include/lipvq.h).
+extern "C" int lipvq_vq_nearest_screened_f32(const float* z, const float* codebook, const void* prep, int64_t* idx,
+                                             float* zq, int64_t* usage, void* workspace, int64_t N, int K, int D,
+                                             void* stream) {
+    if (N < 0 || K <= 0 || D <= 0) return fail(LIPVQ_EINVAL, "vq_nearest_screened: bad sizes");
+    if (N == 0) return LIPVQ_OK;
+    if (!z || !codebook || !prep || !idx || !workspace) return fail(LIPVQ_EINVAL, "vq_nearest_screened: null pointer");
+    if (N > 2147483647LL) return fail(LIPVQ_EUNSUPPORTED, "vq_nearest_screened: N too large");
+    if ((((uintptr_t)z | (uintptr_t)codebook | (uintptr_t)zq) & 15) != 0)
+        return fail(LIPVQ_EINVAL, "vq_nearest_screened: z, codebook and zq must be 16-byte aligned");
+    return screened_impl(z, codebook, prep, idx, zq, usage, workspace, nullptr, N, K, D, LIPVQ_SCREEN_GAMMA,
+                         (hipStream_t)stream, LIPVQ_DIST_SQSUM);
+}
+
+extern "C" int lipvq_vq_nearest_rows_f32(const float* z, const float* codebook, int64_t* idx, float* zq, int64_t* usage,
+                                         int64_t N, int K, int D, void* stream) {
+    if (N < 0 || K <= 0) return fail(LIPVQ_EINVAL, "vq_nearest_rows: bad sizes");
+    if (N == 0) return LIPVQ_OK;
+    if (!z || !codebook || !idx) return fail(LIPVQ_EINVAL, "vq_nearest_rows: null pointer");
+    if (N > 0x7fffffffLL) return fail(LIPVQ_EUNSUPPORTED, "vq_nearest_rows: N too large");
+    return lipvq_launch_rows(z, 0, codebook, idx, zq, usage, nullptr, nullptr, N, K, D, (hipStream_t)stream, LIPVQ_DIST_SQSUM);
 }
 
 // Test hook: also writes the approximate distances d~ [N][Kpad] and uses the caller's gamma

@@ -331,8 +331,8 @@ def nearest_prepare(codebook: torch.Tensor) -> PreparedCodebook:
     return PreparedCodebook(buf, K, D)
 
 
-def nearest_rows(z, codebook, usage=None, want_zq=True):
-    """(idx, zq) exactly as nearest(z, codebook, DIST_NORM), every row decided by the exact re-scoring kernel (no
+def nearest_rows(z, codebook, usage=None, want_zq=True, dist: int = DIST_NORM):
+    """(idx, zq) exactly as nearest(z, codebook, dist), every row decided by the exact re-scoring kernel (no
     prepared codebook): the route for small batches."""
     z, codebook = _chk(z, "z"), _chk(codebook, "codebook")
     N, D = z.shape
@@ -343,15 +343,18 @@ def nearest_rows(z, codebook, usage=None, want_zq=True):
         usage = _chk(usage, "usage", torch.int64)
     idx = torch.empty(N, device=z.device, dtype=torch.int64)
     zq = torch.empty_like(z) if want_zq else None
+    fn, name = ((lib.lipvq_nearest_rows_f32, "lipvq_nearest_rows_f32") if dist == DIST_NORM else
+                (lib.lipvq_vq_nearest_rows_f32, "lipvq_vq_nearest_rows_f32"))
+    if dist not in (DIST_NORM, DIST_SQSUM):
+        raise ValueError(f"nearest_rows: unknown distance rule {dist}")
     with _on(z.device):
-        check(lib.lipvq_nearest_rows_f32(_ptr(z), _ptr(codebook), _ptr(idx), _ptr(zq), _ptr(usage), N, K, D, _stream()),
-              "lipvq_nearest_rows_f32")
+        check(fn(_ptr(z), _ptr(codebook), _ptr(idx), _ptr(zq), _ptr(usage), N, K, D, _stream()), name)
     return idx, zq
 
 
 def nearest_screened(z, codebook, prep: PreparedCodebook, usage=None, want_zq=True, return_workspace=False,
-                     debug_gamma=None):
-    """Same results as nearest(z, codebook, DIST_NORM), via MFMA screening + exact re-scoring of the
+                     debug_gamma=None, dist: int = DIST_NORM):
+    """Same results as nearest(z, codebook, dist), via MFMA screening + exact re-scoring of the
     rows the screen cannot certify.  With return_workspace the int32 workspace is returned too
     (element 0 = number of rows decided by the exact kernel).  debug_gamma: test hook, returns the
     approximate distance matrix as well."""
@@ -367,8 +370,14 @@ def nearest_screened(z, codebook, prep: PreparedCodebook, usage=None, want_zq=Tr
     zq = torch.empty_like(z) if want_zq else None
     ws = torch.empty(max(16, lib.lipvq_nearest_workspace_bytes(N) // 4), device=dev, dtype=torch.int32)
     dt = None
+    if dist not in (DIST_NORM, DIST_SQSUM) or (dist != DIST_NORM and debug_gamma is not None):
+        raise ValueError("nearest_screened: unknown distance rule (the debug hook runs the norm rule only)")
     with _on(dev):
-        if debug_gamma is None:
+        if debug_gamma is None and dist == DIST_SQSUM:        # the plain VQVAE's rule (vq:57-63)
+            check(lib.lipvq_vq_nearest_screened_f32(_ptr(z), _ptr(codebook), _ptr(prep.buf), _ptr(idx), _ptr(zq),
+                                                    _ptr(usage), _ptr(ws), N, K, D, _stream()),
+                  "lipvq_vq_nearest_screened_f32")
+        elif debug_gamma is None:
             check(lib.lipvq_nearest_screened_f32(_ptr(z), _ptr(codebook), _ptr(prep.buf), _ptr(idx), _ptr(zq),
                                                  _ptr(usage), _ptr(ws), N, K, D, _stream()),
                   "lipvq_nearest_screened_f32")

@@ -295,11 +295,35 @@ class VQVAE(_TokenizerBase):
     def encode(self, x):
         return ops.mlp3(self._as_rows(x), self._packed_encoder(), (ACT_RELU, ACT_RELU, ACT_RELU))
 
+    # rows up to which the exact re-scoring kernel decides every row (no codebook preparation), as in LLFQVAE_V4._quantize
+    EXACT_ROWS_MAX = 2048
+    # the all-pairs kernel stays the route for small codebooks: at K = 128 (the reference's default, vq:7) it runs at its VALU
+    # bound in 0.4 ms per 524 288 rows, where a screen launch + its uncertified rows would gain nothing
+    SCREEN_MIN_CODES = 256
+
+    def _quantize(self, z_e, usage):
+        """(idx, z_q) of vq:57-66 (`pow(2).sum(-1)`, argmin, embedding lookup): MFMA screen + exact re-scoring where the latent
+        width has a screening instance and the codebook is large enough to pay for it, the all-pairs exact kernel otherwise.
+        Identical results on every route."""
+        cb = self.embedding.weight.detach()
+        K, D = cb.shape
+        n = z_e.shape[0]
+        if ops.nearest_screen_supported(K, D) and K >= self.SCREEN_MIN_CODES and n > 0:
+            if n <= self.EXACT_ROWS_MAX:
+                self.last_exact_rows = None
+                return ops.nearest_rows(z_e, cb, usage=usage, dist=DIST_SQSUM)
+            prep = self._cb_cache.get((self.embedding.weight,), lambda: ops.nearest_prepare(cb))
+            idx, zq, ws = ops.nearest_screened(z_e, cb, prep, usage=usage, return_workspace=True, dist=DIST_SQSUM)
+            self.last_exact_rows = ws
+            return idx, zq
+        self.last_exact_rows = None
+        idx, zq, _ = ops.nearest(z_e, cb, DIST_SQSUM, usage=usage)
+        return idx, zq
+
     @torch.no_grad()
     def tokenize(self, x, count_usage=True):
         z_e = self.encode(x)
-        idx, zq, _ = ops.nearest(z_e, self.embedding.weight.detach(), DIST_SQSUM,
-                                 usage=self.code_usage if count_usage else None)
+        idx, zq = self._quantize(z_e, self.code_usage if count_usage else None)
         self.last_indices = idx
         return idx, ops.ste(z_e, zq)
 

@@ -35,5 +35,7 @@ for K in (128, 1024):
         opt.step()
 
     t_tok, t_fwd, t_step = timed(lambda: m.tokenize(x)), timed(fwd), timed(step, 5)
+    m.tokenize(x)
+    ex = int(m.last_exact_rows[0]) if m.last_exact_rows is not None else None
     print(f"VQVAE N={N} A={A} D={D} K={K}: tokenize {t_tok:.3f} ms ({N / t_tok / 1e3:.0f} M actions/s), full forward {t_fwd:.3f} ms, "
-          f"training step {t_step:.3f} ms")
+          f"training step {t_step:.3f} ms; rows decided by the exact kernel after the screen: {ex}")

@@ -152,6 +152,29 @@ def test_vq_forward_backward(name, oracle, golden_dir):
         _grad_close(got, g["grad/" + k], f"{k} vs reference")
 
 
+@pytest.mark.parametrize("K,N", [(1024, 5000), (1024, 300), (128, 5000)])
+def test_vq_module_routes(oracle, K, N):
+    """VQVAE.tokenize / forward pick the screened quantizer (large codebook, large batch), the exact-rows kernel (large
+    codebook, small batch) or the all-pairs kernel (small codebook): the same indices, straight-through values and loss as the
+    oracle on every route."""
+    from lipvq_vae_amd.tokenizer import VQVAE
+    A, D = 7, 64
+    p = O.make_params(700 + K, A, D, K, variant="vq", oracle=oracle)
+    x = O.make_inputs(701 + N, N, A)
+    model = _model(VQVAE, p, A, D, num_embeddings=K)
+    f = oracle.vq_forward(p, x)
+    model.code_usage.zero_()
+    idx, z_st = model.tokenize(torch.from_numpy(x).cuda())
+    assert np.array_equal(idx.cpu().numpy(), f["indices"])
+    assert np.array_equal(z_st.cpu().numpy(), f["z_latent"])
+    assert int(model.code_usage.sum()) == N
+    z_latent, loss = model(torch.from_numpy(x).cuda())
+    assert np.array_equal(z_latent.detach().cpu().numpy(), f["z_latent"])
+    assert abs(loss.item() - f["loss"]) <= FLOAT_TOL * abs(f["loss"])
+    if K >= 256 and N > 2048:
+        assert model.last_exact_rows is not None and int(model.last_exact_rows[0]) < N // 2
+
+
 def test_constructor_rng_matches_reference(golden_dir):
     """Same torch seed -> same initial weights as the reference constructors (drop-in property)."""
     from lipvq_vae_amd.tokenizer import LLFQVAE_V4, VQVAE

@@ -153,6 +153,60 @@ def test_vq_adversarial_near_ties_match_the_reference(ops, name, golden_dir):
     assert np.array_equal(best.cpu().numpy(), g["d_best"])
 
 
+@pytest.mark.parametrize("N,K,D", [(4096, 1024, 64), (1000, 256, 32), (700, 1000, 128), (80, 1024, 208), (33, 37, 64),
+                                   (3000, 8192, 128)])
+def test_vq_screened_routes_equal_oracle(ops, oracle, N, K, D):
+    """The plain VQVAE's rule (vq:57-63: pow(2).sum(-1), argmin) through the screened route and the exact-rows route equals the
+    oracle's lq_sqdist32 argmin -- on ReLU-like latents (a third of the elements exactly zero), with an exact duplicate code
+    (a tie only the first-minimum rule decides) -- and the all-pairs kernel."""
+    z, cb = _case(N + K + D + 1, N, K, D)
+    rng = np.random.default_rng(N + D)
+    z = np.where(rng.uniform(size=z.shape) < 0.33, 0.0, z).astype(np.float32)
+    if K > 3:
+        cb[K - 1] = cb[1]
+    idx_ref, zq_ref, usage_ref = oracle.nearest(z, cb, dist=O.DIST_SQSUM)
+    cbd, zd = dev(cb), dev(z)
+    usage = torch.zeros(K, dtype=torch.int64, device="cuda")
+    idx, zq, ws = ops.nearest_screened(zd, cbd, ops.nearest_prepare(cbd), usage=usage, return_workspace=True, dist=O.DIST_SQSUM)
+    assert np.array_equal(idx.cpu().numpy(), idx_ref) and np.array_equal(zq.cpu().numpy(), zq_ref)
+    assert np.array_equal(usage.cpu().numpy(), usage_ref)
+    assert int(ws[0]) < N, "nothing was certified"
+    usage.zero_()
+    idx2, zq2 = ops.nearest_rows(zd, cbd, usage=usage, dist=O.DIST_SQSUM)
+    assert np.array_equal(idx2.cpu().numpy(), idx_ref) and np.array_equal(zq2.cpu().numpy(), zq_ref)
+    assert np.array_equal(usage.cpu().numpy(), usage_ref)
+    idx3, _, _ = ops.nearest(zd, cbd, dist=O.DIST_SQSUM)
+    assert np.array_equal(idx3.cpu().numpy(), idx_ref)
+
+
+def test_vq_near_ties_through_the_screened_route(ops, golden_dir):
+    """Bisector rows decided by the REFERENCE's VQVAE.quantize() (D = 64, K = 512): the screen certifies (next to) none of them
+    and the exact kernel's cascade-sum order gives the reference's indices -- through both routes."""
+    g = np.load(golden_dir / "vq_nearties_d64_k512.npz")
+    N, K, D = int(g["N"]), int(g["K"]), int(g["D"])
+    z, cb = O.make_neartie_case(int(g["seed"]), N, K, D)
+    ref = g["indices"].astype(np.int64)
+    cbd, zd = dev(cb), dev(z)
+    idx, zq, ws = ops.nearest_screened(zd, cbd, ops.nearest_prepare(cbd), return_workspace=True, dist=O.DIST_SQSUM)
+    assert np.array_equal(idx.cpu().numpy(), ref) and np.array_equal(zq.cpu().numpy(), cb[ref])
+    assert int(ws[0]) >= (99 * N) // 100
+    idx2, _ = ops.nearest_rows(zd, cbd, dist=O.DIST_SQSUM)
+    assert np.array_equal(idx2.cpu().numpy(), ref)
+
+
+def test_vq_default_init_codebook_is_still_exact(ops, oracle):
+    """The reference initialises the VQVAE codebook U(-1/K, 1/K) (vq:36): every code is nearly equidistant from a latent of
+    ordinary magnitude, the screen certifies little -- whatever it leaves is decided exactly."""
+    rng = np.random.default_rng(5)
+    N, K, D = 3000, 512, 64
+    cb = rng.uniform(-1.0 / K, 1.0 / K, (K, D)).astype(np.float32)
+    z = np.maximum(rng.standard_normal((N, D)), 0).astype(np.float32)
+    idx_ref, _, _ = oracle.nearest(z, cb, dist=O.DIST_SQSUM)
+    cbd = dev(cb)
+    idx, _ = ops.nearest_screened(dev(z), cbd, ops.nearest_prepare(cbd), dist=O.DIST_SQSUM)[:2]
+    assert np.array_equal(idx.cpu().numpy(), idx_ref)
+
+
 def test_small_but_nonzero_gaps_at_the_widest_latent(ops, oracle):
     """D = 208 (26 fma roundings per accumulator in the reference's own sum): rows with relative top-2 gaps from ~1e-6 to a
     few 1e-5 -- above exact ties, around the margin -- are decided exactly, and most of them by the exact kernel."""
