@@ -646,6 +646,29 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
         LQ_STAMP(3);
         if (x_pref) load_x(blk + gridDim.x < nblk ? blk + gridDim.x : blk);      // next row block's inputs: a whole phase ahead
         constexpr bool PACKF = LQ_PACK_FOR(S) || S > 8;      // (S = 13: 104 registers of A fragments leave no room for an index array)
+#ifdef LQ_ABL_RG2
+        // ablation build (timing only): the screen loop with TWO row groups per wave -- here the same 32 rows twice, i.e. twice the
+        // MFMAs and bookkeeping over one set of LDS reads / hand-overs; half its loop time against the plain loop's is what a
+        // 64-row-per-wave kernel can gain in this phase
+        if constexpr (S <= 4) {
+            f16x8 ah2[2][S], al2[2][S];
+            float m1b[2][16], m2b[2][16];
+            int k1b[2][16];
+#pragma unroll
+            for (int g_ = 0; g_ < 2; ++g_) {
+#pragma unroll
+                for (int s_ = 0; s_ < S; ++s_) { ah2[g_][s_] = ah[s_]; al2[g_][s_] = al[s_]; }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { m1b[g_][r] = INFINITY; m2b[g_][r] = INFINITY; k1b[g_][r] = 0; }
+            }
+            asm volatile("" : "+v"(ah2[1][0]), "+v"(al2[1][0]));       // keep the second group's operands from being folded into the first's
+            lq_screen_core_rg<S, FUSED_THREADS, TCF, NBF, PACKF, 2>(ah2, al2, tiles, L.ntiles, stage0, tid, frow, m1b, m2b, k1b);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                m1[r] = fminf(m1b[0][r], m1b[1][r]); m2[r] = fminf(m2b[0][r], m2b[1][r]); k1[r] = k1b[0][r] | k1b[1][r];
+            }
+        } else
+#endif
         lq_screen_core<S, FUSED_THREADS, TCF, NBF, PACKF>(ah, al, tiles, L.ntiles, stage0, tid, frow, m1, m2, k1);
         LQ_STAMP(4);
         int my_k;

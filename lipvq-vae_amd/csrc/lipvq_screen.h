@@ -176,11 +176,14 @@ constexpr size_t lq_ring_bytes() { return (size_t)NB * ScreenCfg<S, TC_>::STAGE_
 // number of low mantissa bits that hold the tile index in PACK mode, and the relative perturbation that costs
 __host__ __device__ static inline int lq_pack_bits(int ntiles) { int b = 1; while ((1 << b) < ntiles) ++b; return b; }
 
-template <int S, int NT, int TC_ = screen_default_tc(S), int NB = 4, bool PACK = false>
-__device__ __forceinline__ void lq_screen_core(const f16x8 (&ah)[S], const f16x8 (&al)[S],
-                                               const unsigned char* __restrict__ tiles, int ntiles,
-                                               unsigned char* stage0, int tid, const float (&frow)[16],
-                                               float (&m1)[16], float (&m2)[16], int (&k1)[16]) {
+// RG row groups per wave (round 3): the wave multiplies RG x 32 rows against every tile, so that one pair of B-fragment reads,
+// one |e'|^2 read, one stage hand-over (wait, barrier, DMA issue) serve RG x 3 MFMAs per k-step instead of 3, and consecutive
+// MFMAs go to different accumulators.  ah/al/m1/m2/k1 carry the group as their leading dimension.
+template <int S, int NT, int TC_ = screen_default_tc(S), int NB = 4, bool PACK = false, int RG = 1>
+__device__ __forceinline__ void lq_screen_core_rg(const f16x8 (&ah)[RG][S], const f16x8 (&al)[RG][S],
+                                                  const unsigned char* __restrict__ tiles, int ntiles,
+                                                  unsigned char* stage0, int tid, const float (&frow)[16],
+                                                  float (&m1)[RG][16], float (&m2)[RG][16], int (&k1)[RG][16]) {
     using C = ScreenCfg<S, TC_>;
     static_assert(NB >= 2 && NB <= 4, "ring of 2..4 stage buffers");
     constexpr int NW = NT / 64;
@@ -243,10 +246,12 @@ __device__ __forceinline__ void lq_screen_core(const f16x8 (&ah)[S], const f16x8
 #endif
     lq_wg_barrier();
 
-    // two named accumulators: the chain of tile i runs into one while the other (tile i-1) is booked
-    f32x16 accA, accB;
+    // two named accumulators (per row group): the chain of tile i runs into one while the other (tile i-1) is booked
+    f32x16 accA[RG], accB[RG];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) accB[r] = INFINITY;      // "no previous tile": INFINITY never beats anything
+    for (int g_ = 0; g_ < RG; ++g_)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accB[g_][r] = INFINITY;      // "no previous tile": INFINITY never beats anything
     float e2A = 0.0f, e2B = 0.0f;
     int codeA = 0, codeB = 0;                     // the code of the lane in the tile (unpacked) or the tile index (PACK)
     const unsigned keep_mask = PACK ? ~((1u << lq_pack_bits(ntiles)) - 1u) : 0xffffffffu;
@@ -284,13 +289,15 @@ __device__ __forceinline__ void lq_screen_core(const f16x8 (&ah)[S], const f16x8
                 int b = buf + PD; b = b >= NB ? b - NB : b;
                 stage_dma(st + PD, b);
             }
-            f32x16& acc = (((c + par) & 1) == 0) ? accA : accB;
-            const f32x16& prev = (((c + par) & 1) == 0) ? accB : accA;
+            f32x16 (&acc)[RG] = (((c + par) & 1) == 0) ? accA : accB;
+            const f32x16 (&prev)[RG] = (((c + par) & 1) == 0) ? accB : accA;
             const float e2_prev = (((c + par) & 1) == 0) ? e2B : e2A;
             const int code_prev = (((c + par) & 1) == 0) ? codeB : codeA;
             if (s == 0) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                for (int g_ = 0; g_ < RG; ++g_)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[g_][r] = 0.0f;
                 const float e2c = e2q[(c + par) & 1];
                 int code = PACK ? (st * C::TC + c) : (st * C::TC + c) * 32 + ln;
                 if constexpr (PACK) asm volatile("" : "+v"(code));      // the tile index lives in a vector register (lq_track_one)
@@ -313,15 +320,24 @@ __device__ __forceinline__ void lq_screen_core(const f16x8 (&ah)[S], const f16x8
             // pinned order: reads, then (MFMA, its share of the pending tile's bookkeeping) x 3 -- left alone, hipcc lumps the
             // bookkeeping behind the chain, where nothing hides it
             __builtin_amdgcn_sched_barrier(0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh, acc, 0, 0, 0);
-            lq_track_after_mfma<S, PACK>(3 * s + 0, prev, e2_prev, frow, code_prev, keep_mask, m1, m2, k1);
-            __builtin_amdgcn_sched_barrier(0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh, acc, 0, 0, 0);
-            lq_track_after_mfma<S, PACK>(3 * s + 1, prev, e2_prev, frow, code_prev, keep_mask, m1, m2, k1);
-            __builtin_amdgcn_sched_barrier(0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl, acc, 0, 0, 0);
-            lq_track_after_mfma<S, PACK>(3 * s + 2, prev, e2_prev, frow, code_prev, keep_mask, m1, m2, k1);
-            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g_ = 0; g_ < RG; ++g_) {
+                acc[g_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g_][s], bh, acc[g_], 0, 0, 0);
+                lq_track_after_mfma<S, PACK>(3 * s + 0, prev[g_], e2_prev, frow, code_prev, keep_mask, m1[g_], m2[g_], k1[g_]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int g_ = 0; g_ < RG; ++g_) {
+                acc[g_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[g_][s], bh, acc[g_], 0, 0, 0);
+                lq_track_after_mfma<S, PACK>(3 * s + 1, prev[g_], e2_prev, frow, code_prev, keep_mask, m1[g_], m2[g_], k1[g_]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int g_ = 0; g_ < RG; ++g_) {
+                acc[g_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g_][s], bl, acc[g_], 0, 0, 0);
+                lq_track_after_mfma<S, PACK>(3 * s + 2, prev[g_], e2_prev, frow, code_prev, keep_mask, m1[g_], m2[g_], k1[g_]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         buf = nbuf;
     };
@@ -330,13 +346,25 @@ __device__ __forceinline__ void lq_screen_core(const f16x8 (&ah)[S], const f16x8
         if constexpr (PERIOD == 2) do_stage(std::integral_constant<int, 1>{}, st + 1);
     }
     // the last tile's chain: ntiles is even, so it ran into accB
-    lq_track_part<0, 16, PACK>(accB, e2B, frow, codeB, keep_mask, m1, m2, k1);
+#pragma unroll
+    for (int g_ = 0; g_ < RG; ++g_) lq_track_part<0, 16, PACK>(accB[g_], e2B, frow, codeB, keep_mask, m1[g_], m2[g_], k1[g_]);
     // the copies issued for stages past the end go to the dummy KiB, but they count: drain them, then every wave has left
     // the stage buffers (the callers reuse them as per-wave scratch: lq_screen_decide)
 #ifndef LQ_ABL_NOSTAGE
     lq_wait_vmcnt<0>();
 #endif
     lq_wg_barrier();
+}
+
+// one row group: the original interface (screen_kernel, tokenize_kernel's 32-row instances)
+template <int S, int NT, int TC_ = screen_default_tc(S), int NB = 4, bool PACK = false>
+__device__ __forceinline__ void lq_screen_core(const f16x8 (&ah)[S], const f16x8 (&al)[S],
+                                               const unsigned char* __restrict__ tiles, int ntiles,
+                                               unsigned char* stage0, int tid, const float (&frow)[16],
+                                               float (&m1)[16], float (&m2)[16], int (&k1)[16]) {
+    lq_screen_core_rg<S, NT, TC_, NB, PACK, 1>(reinterpret_cast<const f16x8 (&)[1][S]>(ah), reinterpret_cast<const f16x8 (&)[1][S]>(al),
+                                               tiles, ntiles, stage0, tid, frow, reinterpret_cast<float (&)[1][16]>(m1),
+                                               reinterpret_cast<float (&)[1][16]>(m2), reinterpret_cast<int (&)[1][16]>(k1));
 }
 
 // frow[r] = factor of row (r, h) = the row this lane's accumulator register r belongs to, fetched from the lane that

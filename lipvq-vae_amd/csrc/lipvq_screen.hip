@@ -90,6 +90,19 @@ __global__ void prep_frag_kernel(const float* __restrict__ cb, const float* __re
     }
     unsigned char* t = tiles + (size_t)(k >> 5) * L.tile_bytes;
     const int c = k & 31;
+    // Pad codes (k >= K: the tail of the last real tile and the tiles that round the count up to whole LDS stages) must lose
+    // against every real code.  prep_e2_kernel gave them |e'|^2 = +inf -- but the PACK bookkeeping writes the tile index into the
+    // low mantissa bits of every value (lq_track_one), which turns +inf into a NaN, and v_med3_f32 with a NaN operand returns the
+    // MINIMUM of the other two: the lane's second minimum became its minimum and every row whose best code sat in a lane that
+    // also holds a pad code went to the exact kernel (all rows at K = 37 or 128, three quarters at K = 1000; results were
+    // right, only slow -- found in round 3 by the first test that asserts "something was certified" at K = 37).  So pad codes get
+    // a huge FINITE |e'|^2: 2^(100 - se), i.e. 2^(100 + sz) in a row's units, above anything a real code can reach (< 2^40)
+    // and below overflow for every row scale the kernels use; a row so small that it did overflow is merely not certified.
+    if (k >= K && s == 0 && h == 0) {
+        int ex = 100 - (int)hdr[3];
+        ex = ex > 120 ? 120 : ex;
+        reinterpret_cast<float*>(t + (size_t)L.S * 2048)[c] = lq_pow2f(ex);
+    }
     *reinterpret_cast<f16x8*>(t + (((size_t)s * 2 + 0) * 64 + h * 32 + c) * 16) = hi;   // lane = h*32 + c
     *reinterpret_cast<f16x8*>(t + (((size_t)s * 2 + 1) * 64 + h * 32 + c) * 16) = lo;
 }
