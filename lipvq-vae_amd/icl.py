@@ -7,6 +7,13 @@
 * ``time_distributed``     -- the [B, T, ...] <-> [B*T, ...] reshape of
                              ``TensorUtils.icl_time_distributed`` (robomimic/utils/tensor_utils.py:1045-1090)
                              for the action leaf.
+* ``icl_time_distributed`` -- the same function in full: nested dict / list / tuple inputs, kwargs / args call forms,
+                             the ``(obs, context_obs, context_actions)`` triple (tensor_utils.py:1045-1090) -- what
+                             ``ICL_MIMO_Transformer.forward`` calls on the group encoder (obs_nets.py:2571).
+* ``ICLObservationGroupEncoder`` -- the group encoder as a whole object (obs_nets.py:1120-1383): observation encoders are
+                             handed in and passed through untouched (they are outside this path), ``prompt["action"]`` goes
+                             to ``ICLActionBranch``; ``forward(**inputs)`` returns the reference's triple and exposes
+                             ``action_network`` / ``_vq_vae_loss`` under the reference's names.
 * ``VQTokenizerTrainer``   -- the optimiser choreography of ``ICLTransformer_GMM``
                              (robomimic/algo/icl.py:885-889 AdamW(lr=1e-3, wd=1e-4); :913-914 zero_grad;
                              :968-970 loss.backward(), step()), optionally data parallel
@@ -55,6 +62,106 @@ def time_distributed(actions: torch.Tensor, op) -> torch.Tensor:
     b, t = actions.shape[:2]
     out = op(actions.reshape(b * t, *actions.shape[2:]))
     return out.reshape(b, t, *out.shape[1:])
+
+
+def _map_leaves(x, fn):
+    """New nested dict / list / tuple with fn applied to every tensor leaf (None stays None) -- the traversal
+    tensor_utils.py's join_dimensions / reshape_dimensions perform."""
+    if isinstance(x, torch.Tensor):
+        return fn(x)
+    if x is None:
+        return None
+    if isinstance(x, dict):
+        return type(x)((k, _map_leaves(v, fn)) for k, v in x.items())
+    if isinstance(x, (list, tuple)):
+        return type(x)(_map_leaves(v, fn) for v in x)
+    raise NotImplementedError(f"icl_time_distributed: cannot map a leaf of type {type(x).__name__}")
+
+
+def _first_leaf(x):
+    if isinstance(x, torch.Tensor):
+        return x
+    if isinstance(x, dict):
+        it = x.values()
+    elif isinstance(x, (list, tuple)):
+        it = x
+    else:
+        return None
+    for v in it:
+        t = _first_leaf(v)
+        if t is not None:
+            return t
+    return None
+
+
+def icl_time_distributed(inputs, op, activation=None, inputs_as_kwargs=False, inputs_as_args=False, **kwargs):
+    """``TensorUtils.icl_time_distributed`` (tensor_utils.py:1045-1090): every tensor of the nested ``inputs`` ([B, T, ...])
+    is flattened to [B*T, ...], ``op`` is called (``op(**inputs)``, ``op(*inputs)`` or ``op(inputs)``) and must return the
+    triple ``(obs, context_obs, context_actions)``, whose tensors are reshaped back to [B, T, ...].  B and T are read off
+    the first tensor leaf, as the reference does."""
+    first = _first_leaf(inputs)
+    if first is None or first.dim() < 2:
+        raise ValueError("icl_time_distributed: inputs hold no [B, T, ...] tensor")
+    batch_size, seq_len = first.shape[:2]
+    flat = _map_leaves(inputs, lambda t: t.reshape(-1, *t.shape[2:]))
+    if inputs_as_kwargs:
+        obs, context_obs, context_actions = op(**flat, **kwargs)
+    elif inputs_as_args:
+        obs, context_obs, context_actions = op(*flat, **kwargs)
+    else:
+        obs, context_obs, context_actions = op(flat, **kwargs)
+    outs = []
+    for o in (obs, context_obs, context_actions):
+        if activation is not None:
+            o = _map_leaves(o, activation)
+        outs.append(_map_leaves(o, lambda t: t.reshape(batch_size, seq_len, *t.shape[1:])))
+    return tuple(outs)
+
+
+class ICLObservationGroupEncoder(nn.Module):
+    """``ICLObservationGroupEncoder`` (obs_nets.py:1120-1383) around the MI355X action branch.
+
+    The reference builds one ``ObservationEncoder`` per observation group itself (``obs_encoder_factory``: CNNs, randomisers,
+    ... -- outside this path); here they are handed in ready-made as ``obs_encoders`` (any modules with
+    ``forward(obs_dict) -> [N, F]`` and ``output_shape() -> [F]``) and called exactly where the reference calls them.  The
+    action branch is ``ICLActionBranch`` with ``latent_dim = sum of the groups' feature widths`` (obs_nets.py:1193), selected by
+    the reference's switches; ``fast_enabled`` / ``ln_act_enabled`` need the FAST tokenizer + CLIP / Mamba packages and are
+    refused.  ``forward(**inputs)`` = obs_nets.py:1264-1345: returns ``(obs, context_obs, context_actions)`` on [B*T, ...] rows and
+    stashes the tokenizer's loss in ``_vq_vae_loss``."""
+
+    def __init__(self, obs_encoders, action_input_shape, fast_enabled=False, bin_enabled=False, vq_vae_enabled=False,
+                 ln_act_enabled=False, variant: str = "lipvq"):
+        super().__init__()
+        if fast_enabled or ln_act_enabled:
+            raise NotImplementedError("fast_enabled / ln_act_enabled need the FAST tokenizer + CLIP / Mamba packages (out of scope)")
+        self.nets = nn.ModuleDict(obs_encoders)                          # deterministic order: insertion order, as the OrderedDict
+        self.observation_group_shapes = {k: None for k in self.nets}     # the reference iterates this mapping's keys
+        self.fast_enabled, self.ln_act_enabled = False, False
+        self.bin_enabled, self.vq_vae_enabled = bool(bin_enabled), bool(vq_vae_enabled)
+        self.action_branch = ICLActionBranch(int(action_input_shape), self.output_shape()[0], vq_vae_enabled=vq_vae_enabled,
+                                             variant=variant, bin_enabled=bin_enabled)
+
+    @property
+    def action_network(self):                                            # obs_nets.py:2420-2422 aliases this attribute
+        return self.action_branch.action_network
+
+    @property
+    def _vq_vae_loss(self):                                              # obs_nets.py:2576-2577
+        return self.action_branch._vq_vae_loss
+
+    def output_shape(self):
+        return [sum(int(self.nets[g].output_shape()[0]) for g in self.nets)]      # obs_nets.py:1347-1355
+
+    def forward(self, **inputs):
+        prompt_obs = inputs["prompt"]["obs"]                             # obs_nets.py:1282-1283
+        prompt_actions = inputs["prompt"]["action"]
+        missing = set(self.nets.keys()) - set(inputs)
+        assert not missing, f"{list(inputs.keys())} does not contain all observation groups {list(self.nets.keys())}"
+        outputs = [self.nets[g](inputs[g]) for g in self.nets]           # :1293-1296
+        obs = torch.cat(outputs, dim=-1)                                 # :1302
+        context_obs = torch.cat([self.nets["obs"](prompt_obs)], dim=-1)  # :1303-1304
+        context_actions = self.action_branch(prompt_actions)             # :1335-1344 (loss stashed by the branch)
+        return obs, context_obs, context_actions
 
 
 class VQTokenizerTrainer:
