@@ -13,6 +13,8 @@
 // wave per SIMD, and both pay 268 MB of z_e traffic.  Here the weights sit in LDS (one 16-byte read feeds
 // four MFMAs), two waves share each SIMD so one wave's GELU/bookkeeping VALU work runs beside the other's
 // MFMAs, and a workgroup persists over row blocks so the weights are loaded once.
+#include <string.h>
+
 #include "lipvq_mlp.h"
 #include "lipvq_screen.h"
 
@@ -118,9 +120,15 @@ struct TokArgs {
 // percent of the indices differ, all between near-equidistant codes); everything after z_e is the parity path.
 // TRAIN: also stores the pre-activations of the three layers (16-byte stores, lq_tile_store16) -- the forward half of a training
 // step in this one launch instead of mlp3_wg_kernel (with saved pre-activations) + the stand-alone screen + its z_e round trip.
-template <int S, bool FAST, bool TRAIN = false>
-__global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
+// RG, WAVES (round 3): a wave owns RG groups of 32 rows per iteration (phase A runs once per group, phase B multiplies all of
+// them against every codebook fragment it reads: lq_screen_core_rg), WAVES waves per workgroup.  (8, RG = 1) is the round-2
+// kernel; (8, 2) halves the LDS fragment reads, |e'|^2 reads and stage hand-overs per MFMA at two waves per SIMD; (4, 2) is
+// ONE wave per SIMD with the whole 512-register file (the D = 128 instance: its A fragments alone are 64 registers per group).
+template <int S, bool FAST, bool TRAIN, int RG, int WAVES>
+__device__ __forceinline__ void tokenize_body(const TokArgs& a) {
     static_assert(!(FAST && TRAIN), "training uses the parity arithmetic");
+    static_assert(RG == 1 || RG == 2, "one or two row groups per wave");
+    constexpr int THREADS = WAVES * 64;
     constexpr int TCF = fused_ring_tc(S), NBF = fused_ring_nb(S);
     constexpr int T0 = 2, T1 = 4, T2 = (S + 1) / 2;         // S odd (D = 208): the last 32-feature tile is half used
     constexpr int S1 = 16 * T0, S2 = 16 * T1;               // k-steps (pairs) of layers 1 and 2
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
     // bin at the end of this persistent workgroup -- skewed code distributions would otherwise serialise on a
     // few global addresses (see lq_usage_add)
     constexpr size_t STAGES_BYTES = lq_ring_bytes<S, TCF, NBF>();        // the ring + its dummy KiB
-    static_assert(STAGES_BYTES >= (size_t)FUSED_WAVES * LQ_DECIDE_BYTES, "the decision's per-wave transposes live in the stage ring");
+    static_assert(STAGES_BYTES >= (size_t)WAVES * LQ_DECIDE_BYTES, "the decision's per-wave transposes live in the stage ring");
     unsigned* hist = reinterpret_cast<unsigned*>(stage0 + ((STAGES_BYTES + 63) & ~(size_t)63));
     const bool use_hist = a.usage && a.K <= FUSED_HIST_MAX;
 
@@ -165,24 +173,24 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
             // packed16 = [P0h | P1h | P2h], each already [t][s][lane][8 halfs] = 4 floats per (t, s, lane)
             const float* src = reinterpret_cast<const float*>(a.packed16);
             const int n0 = T0 * S0h * 256, n1 = T1 * (2 * T0) * 256, n2 = T2 * (2 * T1) * 256;
-            for (int i = tid; i < n0; i += FUSED_THREADS) w_P0[i] = src[i];
-            for (int i = tid; i < n1; i += FUSED_THREADS) w_P1[i] = src[n0 + i];
-            for (int i = tid; i < n2; i += FUSED_THREADS) w_P2[i] = src[n0 + n1 + i];
+            for (int i = tid; i < n0; i += THREADS) w_P0[i] = src[i];
+            for (int i = tid; i < n1; i += THREADS) w_P1[i] = src[n0 + i];
+            for (int i = tid; i < n2; i += THREADS) w_P2[i] = src[n0 + n1 + i];
         } else {
             const float* P0 = a.packed + PL.oP0;
-            for (int i = tid; i < T0 * S0q * 256; i += FUSED_THREADS) {
+            for (int i = tid; i < T0 * S0q * 256; i += THREADS) {
                 const int q = i & 3, l = (i >> 2) & 63, sq = (i >> 8) % S0q, t = (i >> 8) / S0q;
                 const int s = 4 * sq + q;
                 w_P0[i] = (s < S0) ? P0[((size_t)t * S0 + s) * 64 + l] : 0.0f;
             }
             const float* P1 = a.packed + PL.oP1;
-            for (int i = tid; i < T1 * (S1 / 4) * 256; i += FUSED_THREADS) {
+            for (int i = tid; i < T1 * (S1 / 4) * 256; i += THREADS) {
                 const int q = i & 3, l = (i >> 2) & 63, sq = (i >> 8) % (S1 / 4), t = (i >> 8) / (S1 / 4);
                 w_P1[i] = P1[((size_t)t * S1 + 4 * sq + q) * 64 + l];
             }
             if constexpr (!STREAM2) {
                 const float* P2 = a.packed + PL.oP2;
-                for (int i = tid; i < T2 * (S2 / 4) * 256; i += FUSED_THREADS) {
+                for (int i = tid; i < T2 * (S2 / 4) * 256; i += THREADS) {
                     const int q = i & 3, l = (i >> 2) & 63, sq = (i >> 8) % (S2 / 4), t = (i >> 8) / (S2 / 4);
                     w_P2[i] = P2[((size_t)t * S2 + 4 * sq + q) * 64 + l];
                 }
@@ -190,13 +198,13 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
         }
         // biases re-laid out [t][h][r] = b[32 t + 2 r + h]: the 16 values of a lane's accumulator tile are 64 contiguous bytes
         // (four 16-byte LDS reads, broadcast within the half-wave) instead of sixteen 4-byte reads
-        for (int i = tid; i < 32 * T0; i += FUSED_THREADS) w_B0[i] = a.packed[PL.oB0 + 32 * (i >> 5) + 2 * (i & 15) + ((i >> 4) & 1)];
-        for (int i = tid; i < 32 * T1; i += FUSED_THREADS) w_B1[i] = a.packed[PL.oB1 + 32 * (i >> 5) + 2 * (i & 15) + ((i >> 4) & 1)];
-        for (int i = tid; i < 32 * T2; i += FUSED_THREADS) w_B2[i] = a.packed[PL.oB2 + 32 * (i >> 5) + 2 * (i & 15) + ((i >> 4) & 1)];
+        for (int i = tid; i < 32 * T0; i += THREADS) w_B0[i] = a.packed[PL.oB0 + 32 * (i >> 5) + 2 * (i & 15) + ((i >> 4) & 1)];
+        for (int i = tid; i < 32 * T1; i += THREADS) w_B1[i] = a.packed[PL.oB1 + 32 * (i >> 5) + 2 * (i & 15) + ((i >> 4) & 1)];
+        for (int i = tid; i < 32 * T2; i += THREADS) w_B2[i] = a.packed[PL.oB2 + 32 * (i >> 5) + 2 * (i & 15) + ((i >> 4) & 1)];
         const float* mu = reinterpret_cast<const float*>(a.prep + L.o_mu);
-        for (int i = tid; i < 16 * S; i += FUSED_THREADS) w_mu[i] = mu[i];
+        for (int i = tid; i < 16 * S; i += THREADS) w_mu[i] = mu[i];
         if (use_hist)
-            for (int i = tid; i < a.K; i += FUSED_THREADS) hist[i] = 0u;
+            for (int i = tid; i < a.K; i += THREADS) hist[i] = 0u;
     }
     __syncthreads();
 
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
     const float fz = lq_pow2f(sz);
     const float fown = lq_pow2f(sz + (int)hdr[3]);
     const float tiny2 = (float)(16 * S) * lq_pow2f(-10 - 2 * sz);
-    const int64_t nblk = (a.N + FUSED_WAVES * 32 - 1) / (FUSED_WAVES * 32);
+    const int64_t nblk = (a.N + WAVES * RG * 32 - 1) / (WAVES * RG * 32);
 #ifdef LQ_EXP_STAGGER             /* experiment: the workgroup in the SIMDs' odd wave slots starts LQ_EXP_STAGGER cycles late */
     if (__builtin_amdgcn_s_getreg(6148) & 1) {
         const long long t0_ = __builtin_amdgcn_s_memtime();
@@ -234,9 +242,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
     // loaded each x value right in front of the MFMA that consumed it (four serialised HBM round trips per block)
     constexpr int XPF = 8;                                   // fan-in up to 16 is prefetched; wider inputs load at block start
     const bool x_pref = !FAST && a.A <= 2 * XPF;
-    float xq[XPF];
-    auto load_x = [&](int64_t blk_) {
-        int64_t r_ = (blk_ * FUSED_WAVES + wave) * 32 + ln;
+    float xqg[RG][XPF];
+    auto load_x = [&](int64_t blk_, const int g_, float (&xq)[XPF]) {
+        int64_t r_ = ((blk_ * WAVES + wave) * RG + g_) * 32 + ln;
         r_ = r_ < a.N ? r_ : a.N - 1;
         const int64_t last = a.N * a.A - 1;
 #pragma unroll
@@ -248,7 +256,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
             xq[q] = (k < a.A) ? v : 0.0f;
         }
     };
-    if (x_pref) load_x(blockIdx.x);
+    if (x_pref) {
+#pragma unroll
+        for (int g_ = 0; g_ < RG; ++g_) load_x(blockIdx.x, g_, xqg[g_]);
+    }
     // the z_q copy of a row block is deferred to the start of the NEXT block (parity kernel) and routed through LDS (lq_gather_dma):
     // its first round overlaps layer 0, further rounds (wider latents) follow
 #ifdef LQ_NO_DEFER_GATHER
@@ -256,19 +267,30 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
 #else
     constexpr bool DEFER_GATHER = !FAST;
 #endif
-    int pend_k = 0;
-    bool pend_ok = false;
-    int64_t pend_row0 = 0;
+    int pend_kg[RG];
+    bool pend_okg[RG];
+    int64_t pend_row0g[RG];
     bool have_pend = false;
+#pragma unroll
+    for (int g_ = 0; g_ < RG; ++g_) { pend_kg[g_] = 0; pend_okg[g_] = false; pend_row0g[g_] = 0; }
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
 #ifdef LQ_STAMPS
         st_prev = __builtin_amdgcn_s_memtime();
 #endif
-        const int64_t row0 = (blk * FUSED_WAVES + wave) * 32;
+        f16x8 ahg[RG][S], alg[RG][S];
+        float n2g[RG];
+      // ---- phase A of row group GC: the round-2 block body, on this group's rows / fragments / pending z_q copy ----
+      auto encode_group = [&](auto GC) {
+        constexpr int g = decltype(GC)::value;
+        const int64_t row0 = ((blk * WAVES + wave) * RG + g) * 32;
         const int64_t row = row0 + ln;
         const int64_t rowc = row < a.N ? row : a.N - 1;
-
-        f16x8 ah[S], al[S];
+        f16x8 (&ah)[S] = ahg[g];
+        f16x8 (&al)[S] = alg[g];
+        const float (&xq)[XPF] = xqg[g];
+        const int pend_k = pend_kg[g];
+        const bool pend_ok = pend_okg[g];
+        const int64_t pend_row0 = pend_row0g[g];
         float n2 = 0.0f;
         // sigmoid, centring, row statistics and the optional z_e store of one finished 32-feature tile
         auto finish_tile = [&](const int t, f32x16& acc) {
@@ -370,7 +392,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
             f32x16 h0[T0];
             // the previous block's z_q rows: round 0 of the copy travels codebook -> LDS staging while layer 0 runs
             constexpr int NTRIP = (16 * S + 63) / 64;                    // 64 floats of every row per gather trip
-            constexpr int GP = (STAGES_BYTES >= (size_t)FUSED_WAVES * 8192) ? 8 : 4;      // passes (KiB per wave) per round
+            constexpr int GP = (STAGES_BYTES >= (size_t)WAVES * 8192) ? 8 : 4;      // passes (KiB per wave) per round
             constexpr int NROUND = NTRIP * (8 / GP);
             unsigned char* gstage = stage0 + (size_t)wave * GP * 1024;
             const bool gnow = DEFER_GATHER && have_pend && a.zq;         // wave-uniform
@@ -470,8 +492,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
                 const unsigned char* src = reinterpret_cast<const unsigned char*>(a.w2q) + (size_t)t_ * (G2 * 1024);
                 unsigned char* dst = stage0 + (size_t)buf_ * ScreenCfg<S, TCF>::STAGE_BYTES;
 #pragma unroll
-                for (int j = 0; j < G2 * 1024 / 1024 / FUSED_WAVES; ++j) {
-                    const int off = (wave + j * FUSED_WAVES) * 1024;
+                for (int j = 0; j < G2 * 1024 / 1024 / WAVES; ++j) {
+                    const int off = (wave + j * WAVES) * 1024;
                     __builtin_amdgcn_global_load_lds((glb_ptr_e)(src + off + lane * 16), (lds_ptr_e)(dst + off), 16, 0, 0);
                 }
             };
@@ -521,8 +543,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
             LQ_STAMP(1);
             // the last tile's GELU runs inside the first layer-2 chain: steps 0 .. 47 of that chain only read h1[0..2]
             constexpr int SLAB_BYTES = G2 * 1024;                          // one output tile's A operands: 16 KB
-            constexpr int SLAB_CPW = SLAB_BYTES / 1024 / FUSED_WAVES;
-            static_assert(!STREAM2 || (SLAB_BYTES % (1024 * FUSED_WAVES) == 0 && SLAB_BYTES <= ScreenCfg<S, TCF>::STAGE_BYTES && NBF >= 3),
+            constexpr int SLAB_CPW = SLAB_BYTES / 1024 / WAVES;
+            static_assert(!STREAM2 || (SLAB_BYTES % (1024 * WAVES) == 0 && SLAB_BYTES <= ScreenCfg<S, TCF>::STAGE_BYTES && NBF >= 3),
                           "slabs ride in the stage ring");
 #pragma unroll
             for (int t = 0; t < T2; ++t) {
@@ -635,65 +657,61 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
         }
         LQ_STAMP(2);
         n2 += __shfl_xor(n2, 32, 64);
+        n2g[g] = n2;
+      };
+        encode_group(std::integral_constant<int, 0>{});
+        if constexpr (RG > 1) encode_group(std::integral_constant<int, 1>{});
         float frow[16];                                       // one scale for every row here (see fz): a single register
 #pragma unroll
         for (int r = 0; r < 16; ++r) frow[r] = fown;
-        // ================= phase B: MFMA screen (lq_screen_core, lipvq_screen.h) ==============
-        float m1[16], m2[16];
-        int k1[16];
+        // ================= phase B: MFMA screen (lq_screen_core_rg, lipvq_screen.h) ==============
+        float m1g[RG][16], m2g[RG][16];
+        int k1g[RG][16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { m1[r] = INFINITY; m2[r] = INFINITY; k1[r] = 0; }
+        for (int g_ = 0; g_ < RG; ++g_)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { m1g[g_][r] = INFINITY; m2g[g_][r] = INFINITY; k1g[g_][r] = 0; }
         LQ_STAMP(3);
-        if (x_pref) load_x(blk + gridDim.x < nblk ? blk + gridDim.x : blk);      // next row block's inputs: a whole phase ahead
+        if (x_pref) {                                         // next row block's inputs: a whole phase ahead
+#pragma unroll
+            for (int g_ = 0; g_ < RG; ++g_) load_x(blk + gridDim.x < nblk ? blk + gridDim.x : blk, g_, xqg[g_]);
+        }
         constexpr bool PACKF = LQ_PACK_FOR(S) || S > 8;      // (S = 13: 104 registers of A fragments leave no room for an index array)
-#ifdef LQ_ABL_RG2
-        // ablation build (timing only): the screen loop with TWO row groups per wave -- here the same 32 rows twice, i.e. twice the
-        // MFMAs and bookkeeping over one set of LDS reads / hand-overs; half its loop time against the plain loop's is what a
-        // 64-row-per-wave kernel can gain in this phase
-        if constexpr (S <= 4) {
-            f16x8 ah2[2][S], al2[2][S];
-            float m1b[2][16], m2b[2][16];
-            int k1b[2][16];
-#pragma unroll
-            for (int g_ = 0; g_ < 2; ++g_) {
-#pragma unroll
-                for (int s_ = 0; s_ < S; ++s_) { ah2[g_][s_] = ah[s_]; al2[g_][s_] = al[s_]; }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { m1b[g_][r] = INFINITY; m2b[g_][r] = INFINITY; k1b[g_][r] = 0; }
-            }
-            asm volatile("" : "+v"(ah2[1][0]), "+v"(al2[1][0]));       // keep the second group's operands from being folded into the first's
-            lq_screen_core_rg<S, FUSED_THREADS, TCF, NBF, PACKF, 2>(ah2, al2, tiles, L.ntiles, stage0, tid, frow, m1b, m2b, k1b);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                m1[r] = fminf(m1b[0][r], m1b[1][r]); m2[r] = fminf(m2b[0][r], m2b[1][r]); k1[r] = k1b[0][r] | k1b[1][r];
-            }
-        } else
-#endif
-        lq_screen_core<S, FUSED_THREADS, TCF, NBF, PACKF>(ah, al, tiles, L.ntiles, stage0, tid, frow, m1, m2, k1);
+        lq_screen_core_rg<S, THREADS, TCF, NBF, PACKF, RG>(ahg, alg, tiles, L.ntiles, stage0, tid, frow, m1g, m2g, k1g);
         LQ_STAMP(4);
-        int my_k;
-        LqDecision dec;
         const unsigned keep_mask = PACKF ? ~((1u << lq_pack_bits(L.ntiles)) - 1u) : 0xffffffffu;
         unsigned char* scratch = stage0 + (size_t)wave * LQ_DECIDE_BYTES;
-        bool certified = lq_screen_decide<PACKF>(m1, m2, k1, scratch, hdr, n2, fown, a.gamma, a.K, a.D, lane, my_k, dec,
-                                                 PACKF ? lq_pow2f(lq_pack_bits(L.ntiles) - 23) : 0.0f, keep_mask);
-        const bool row_sane = n2 >= tiny2;                        // (see fz above; such a row's screen values bound nothing)
-        certified = certified && row_sane;
-        lq_screen_emit<PACKF>(dec, certified, row_sane, my_k, row, row < a.N, a.amb_count, a.amb_list, a.N, a.K, lane, keep_mask, scratch);
-        if (h == 0 && row < a.N && certified) {
-            a.idx[row] = (int64_t)my_k;
-            if (use_hist) atomicAdd(&hist[my_k], 1u);              // LDS atomic
+#pragma unroll
+        for (int g_ = 0; g_ < RG; ++g_) {
+            const int64_t row0 = ((blk * WAVES + wave) * RG + g_) * 32;
+            const int64_t row = row0 + ln;
+            int my_k;
+            LqDecision dec;
+            bool certified = lq_screen_decide<PACKF>(m1g[g_], m2g[g_], k1g[g_], scratch, hdr, n2g[g_], fown, a.gamma, a.K, a.D, lane,
+                                                     my_k, dec, PACKF ? lq_pow2f(lq_pack_bits(L.ntiles) - 23) : 0.0f, keep_mask);
+            const bool row_sane = n2g[g_] >= tiny2;                   // (see fz above; such a row's screen values bound nothing)
+            certified = certified && row_sane;
+            lq_screen_emit<PACKF>(dec, certified, row_sane, my_k, row, row < a.N, a.amb_count, a.amb_list, a.N, a.K, lane, keep_mask, scratch);
+            if (h == 0 && row < a.N && certified) {
+                a.idx[row] = (int64_t)my_k;
+                if (use_hist) atomicAdd(&hist[my_k], 1u);              // LDS atomic
+            }
+            if (a.usage && !use_hist) lq_usage_add(a.usage, my_k, h == 0 && row < a.N && certified);
+            if (DEFER_GATHER) { pend_kg[g_] = my_k; pend_okg[g_] = certified; pend_row0g[g_] = row0; }
+            else if (a.zq) lq_screen_gather(a.cb, a.zq, my_k, certified, row0, a.N, a.D, lane);
+            if (RG > 1 && g_ + 1 < RG) __builtin_amdgcn_wave_barrier();     // the next group's transposes reuse this wave's scratch
         }
-        if (a.usage && !use_hist) lq_usage_add(a.usage, my_k, h == 0 && row < a.N && certified);
+        if (DEFER_GATHER) have_pend = true;
         LQ_STAMP(5);
-        if (DEFER_GATHER) { pend_k = my_k; pend_ok = certified; pend_row0 = row0; have_pend = true; }
-        else if (a.zq) lq_screen_gather(a.cb, a.zq, my_k, certified, row0, a.N, a.D, lane);
         LQ_STAMP(6);
     }
-    if (DEFER_GATHER && have_pend && a.zq) lq_screen_gather(a.cb, a.zq, pend_k, pend_ok, pend_row0, a.N, a.D, lane);   // the last block's
+    if (DEFER_GATHER && have_pend && a.zq) {                                                                          // the last block's
+#pragma unroll
+        for (int g_ = 0; g_ < RG; ++g_) lq_screen_gather(a.cb, a.zq, pend_kg[g_], pend_okg[g_], pend_row0g[g_], a.N, a.D, lane);
+    }
 #ifdef LQ_STAMPS
     if (lane == 0) {
-        long long* dbg = reinterpret_cast<long long*>(a.amb_list + (a.N / 2 & ~1)) + ((size_t)blockIdx.x * FUSED_WAVES + wave) * 16;
+        long long* dbg = reinterpret_cast<long long*>(a.amb_list + (a.N / 2 & ~1)) + ((size_t)blockIdx.x * WAVES + wave) * 16;
         for (int i = 0; i < 7; ++i) dbg[i] = st_acc[i];
         dbg[7] = 0;
         dbg[8] = __builtin_amdgcn_s_memtime() - st_begin;
@@ -702,11 +720,21 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
 #endif
     if (use_hist) {
         __syncthreads();
-        for (int i = tid; i < a.K; i += FUSED_THREADS) {
+        for (int i = tid; i < a.K; i += THREADS) {
             const unsigned c = hist[i];
             if (c) atomicAdd(&a.usage[i], (unsigned long long)c);
         }
     }
+}
+
+// two waves per SIMD (8 waves, 256 registers each) / one wave per SIMD (4 waves, the whole 512-register file each)
+template <int S, bool FAST, bool TRAIN = false, int RG = 1>
+__global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
+    tokenize_body<S, FAST, TRAIN, RG, FUSED_WAVES>(a);
+}
+template <int S, bool FAST, bool TRAIN, int RG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void tokenize_kernel_w4(TokArgs a) {
+    tokenize_body<S, FAST, TRAIN, RG, 4>(a);
 }
 
 template <int S, bool FAST>
@@ -721,17 +749,57 @@ static size_t fused_lds_bytes(int A, int K) {
     return fl * sizeof(float) + ring + (K <= FUSED_HIST_MAX ? (size_t)K * 4 : 0);
 }
 
+// Which (waves per workgroup, row groups per wave) instance runs.  Defaults from the round-3 same-box measurements
+// (profiles/r03_*): see tok_shape().  LIPVQ_TOK_SHAPE=w8rg1|w8rg2|w4rg2 overrides (measurement knob; results identical).
+struct TokShape { int waves, rg; };
+static TokShape tok_shape_env() {
+    static const TokShape v = [] {
+        const char* e = getenv("LIPVQ_TOK_SHAPE");
+        TokShape t{0, 0};
+        if (e && !strcmp(e, "w8rg1")) t = {8, 1};
+        if (e && !strcmp(e, "w8rg2")) t = {8, 2};
+        if (e && !strcmp(e, "w4rg2")) t = {4, 2};
+        if (e && !strcmp(e, "w4rg1")) t = {4, 1};
+        return t;
+    }();
+    return v;
+}
+template <int S, bool FAST, bool TRAIN>
+static TokShape tok_shape(int64_t N) {
+    constexpr bool HAS_RG2 = !FAST && !TRAIN && S <= 8;      // the instances that exist (launch_tokenize)
+    constexpr bool HAS_W4 = !FAST && !TRAIN;
+    TokShape t = tok_shape_env();
+    if (t.waves == 0) t = {8, 1};
+    if ((t.rg == 2 && !HAS_RG2) || (t.waves == 4 && !HAS_W4)) t = {8, 1};
+    // a batch that does not give every wave of the chip a 64-row unit keeps 32-row units (one block per wave: latency, not rate)
+    if (t.rg == 2 && N < (int64_t)256 * t.waves * 64) t = {8, 1};
+    return t;
+}
+
+template <typename KFN>
+static int launch_tokenize_as(KFN kfn, LqLdsReserve& reserved, const TokArgs& a, size_t lds, int waves, int rg, hipStream_t st) {
+    if (int rc = lipvq_reserve_lds(reserved, (const void*)kfn, lds, "tokenize")) return rc;
+    const int64_t unit = (int64_t)waves * rg * 32;
+    const int64_t nblk = (a.N + unit - 1) / unit;
+    const int64_t blocks = nblk < 256 * LQ_EXP_WGS_PER_CU ? nblk : 256 * LQ_EXP_WGS_PER_CU;      // one persistent workgroup per CU
+    hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(waves * 64), lds, st, a);
+    return check_launch("tokenize");
+}
+
 template <int S, bool FAST, bool TRAIN = false>
 static int launch_tokenize(const TokArgs& a, hipStream_t st) {
     const size_t lds = fused_lds_bytes<S, FAST>(a.A, a.K);
     if (lds > 160 * 1024) return fail(LIPVQ_EUNSUPPORTED, "tokenize: %zu B of LDS needed", lds);
-    auto kfn = tokenize_kernel<S, FAST, TRAIN>;
-    static LqLdsReserve reserved;               // per instantiation: per-device, thread-safe (lipvq_common.h)
-    if (int rc = lipvq_reserve_lds(reserved, (const void*)kfn, lds, "tokenize")) return rc;
-    int64_t nblk = (a.N + FUSED_WAVES * 32 - 1) / (FUSED_WAVES * 32);
-    int64_t blocks = nblk < 256 * LQ_EXP_WGS_PER_CU ? nblk : 256 * LQ_EXP_WGS_PER_CU;            // one persistent workgroup per CU
-    hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(FUSED_THREADS), lds, st, a);
-    return check_launch("tokenize");
+    const TokShape sh = tok_shape<S, FAST, TRAIN>(a.N);
+    static LqLdsReserve reserved[4];            // per instantiation and shape: per-device, thread-safe (lipvq_common.h)
+    if constexpr (!FAST && !TRAIN) {
+        if (sh.waves == 4 && sh.rg == 1) return launch_tokenize_as(tokenize_kernel_w4<S, FAST, TRAIN, 1>, reserved[3], a, lds, 4, 1, st);
+    }
+    if constexpr (!FAST && !TRAIN && S <= 8) {
+        if (sh.waves == 8 && sh.rg == 2) return launch_tokenize_as(tokenize_kernel<S, FAST, TRAIN, 2>, reserved[1], a, lds, 8, 2, st);
+        if (sh.waves == 4 && sh.rg == 2) return launch_tokenize_as(tokenize_kernel_w4<S, FAST, TRAIN, 2>, reserved[2], a, lds, 4, 2, st);
+    }
+    return launch_tokenize_as(tokenize_kernel<S, FAST, TRAIN, 1>, reserved[0], a, lds, 8, 1, st);
 }
 
 // fp16 MFMA fragments of the encoder stack for the fast mode: [layer][tile t][step s][lane][8 halfs] with

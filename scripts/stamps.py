@@ -22,11 +22,14 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record(); model.tokenize(x); e1.record(); torch.cuda.synchronize()
 ws = model._tok_ws.cpu().numpy()
 off = 16 + ((N // 2) & ~1)
-st = ws[off:off + 2048 * 32].view(np.int64).reshape(2048, 16)
+import os
+NW = 4 if os.environ.get("LIPVQ_TOK_SHAPE", "").startswith("w4") else 8      # waves per workgroup of the instance that ran
+st = ws[off:off + 256 * NW * 32].view(np.int64).reshape(256 * NW, 16)
 names = ["layer0+gelu", "layer1", "layer2+finish", "scale/split", "screen loop", "decide", "gather+idx", "-"]
 tot = st[:, 8].astype(np.float64)
 print(f"{wl}: launch {e0.elapsed_time(e1):.3f} ms; wave lifetime median {np.median(tot):.0f} ticks (s_memtime), min {tot.min():.0f} max {tot.max():.0f}")
-for half, sel in (("waves 0-3", np.arange(2048) % 8 < 4), ("waves 4-7", np.arange(2048) % 8 >= 4)):
+for half, sel in ((("waves 0-3", np.arange(2048) % 8 < 4), ("waves 4-7", np.arange(2048) % 8 >= 4)) if NW == 8 else
+                  (("waves 0-3", np.arange(1024) >= 0),)):
     m = st[sel]
     print(f" {half}: lifetime {np.median(m[:, 8]):.0f}; start skew vs wave 0 of the launch {np.median(m[:, 9] - st[:, 9].min()):.0f}")
     for i, n in enumerate(names[:7]):
