@@ -749,20 +749,21 @@ static size_t fused_lds_bytes(int A, int K) {
     return fl * sizeof(float) + ring + (K <= FUSED_HIST_MAX ? (size_t)K * 4 : 0);
 }
 
-// Which (waves per workgroup, row groups per wave) instance runs.  Defaults from the round-3 same-box measurements
-// (profiles/r03_*): see tok_shape().  LIPVQ_TOK_SHAPE=w8rg1|w8rg2|w4rg2 overrides (measurement knob; results identical).
+// Which (waves per workgroup, row groups per wave) instance runs.  Measured on one box (profiles/r03_d_tokenize_shapes_ab.txt):
+//   cfg2 (S = 4): w8rg1 0.468 ms, w8rg2 0.480 (99 spilled registers), w4rg2 0.526, w4rg1 0.549
+//   cfg3 (S = 8): w8rg1 2.98 ms,  w4rg2 3.05 (no spills, half the LDS reads per MFMA -- and nothing gained), w4rg1 3.53
+//   icrt (S = 13): w8rg1 1.19 ms, w4rg1 1.27
+// so the round-2 shape stays the default everywhere; the others remain as instances the parity tests run
+// (LIPVQ_TOK_SHAPE=w8rg1|w8rg2|w4rg2|w4rg1: measurement knob; results identical).
 struct TokShape { int waves, rg; };
-static TokShape tok_shape_env() {
-    static const TokShape v = [] {
-        const char* e = getenv("LIPVQ_TOK_SHAPE");
-        TokShape t{0, 0};
-        if (e && !strcmp(e, "w8rg1")) t = {8, 1};
-        if (e && !strcmp(e, "w8rg2")) t = {8, 2};
-        if (e && !strcmp(e, "w4rg2")) t = {4, 2};
-        if (e && !strcmp(e, "w4rg1")) t = {4, 1};
-        return t;
-    }();
-    return v;
+static TokShape tok_shape_env() {              // read per launch (a getenv: nanoseconds), so that a test can switch shapes in-process
+    const char* e = getenv("LIPVQ_TOK_SHAPE");
+    TokShape t{0, 0};
+    if (e && !strcmp(e, "w8rg1")) t = {8, 1};
+    if (e && !strcmp(e, "w8rg2")) t = {8, 2};
+    if (e && !strcmp(e, "w4rg2")) t = {4, 2};
+    if (e && !strcmp(e, "w4rg1")) t = {4, 1};
+    return t;
 }
 template <int S, bool FAST, bool TRAIN>
 static TokShape tok_shape(int64_t N) {
@@ -771,8 +772,7 @@ static TokShape tok_shape(int64_t N) {
     TokShape t = tok_shape_env();
     if (t.waves == 0) t = {8, 1};
     if ((t.rg == 2 && !HAS_RG2) || (t.waves == 4 && !HAS_W4)) t = {8, 1};
-    // a batch that does not give every wave of the chip a 64-row unit keeps 32-row units (one block per wave: latency, not rate)
-    if (t.rg == 2 && N < (int64_t)256 * t.waves * 64) t = {8, 1};
+    (void)N;        // (no size rule: the default is one shape; an explicit LIPVQ_TOK_SHAPE is honoured at any batch size)
     return t;
 }
 

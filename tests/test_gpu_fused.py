@@ -177,3 +177,20 @@ def test_training_forward_launch_equals_unfused(oracle, N, A, D, K):
     assert abs(loss.item() - loss2.item()) <= 1e-6 * abs(loss2.item())
     for k, v in model.named_parameters():
         assert torch.allclose(g_fused[k], v.grad, rtol=0, atol=1e-5 * max(1e-12, float(v.grad.abs().max()))), k
+
+
+@pytest.mark.parametrize("shape", ["w8rg2", "w4rg2", "w4rg1"])
+@pytest.mark.parametrize("N,A,D,K", [(256 * 300 + 5, 7, 64, 1024), (9000, 7, 32, 256), (4100, 7, 128, 2048), (3000, 12, 208, 1024)])
+def test_other_kernel_shapes_give_the_same_results(oracle, monkeypatch, shape, N, A, D, K):
+    """tokenize_kernel exists in four (waves per workgroup, 32-row groups per wave) shapes (lipvq_fused.hip: tok_shape); only one
+    is the default, the others stay in the library as measured alternatives -- every one of them must return the oracle's
+    indices / z_q / usage (the shape only changes which wave owns which rows).  LIPVQ_TOK_SHAPE is read per launch."""
+    p, model = _setup(N + D + 7, A, D, K, oracle)
+    x = O.make_inputs(N + 3, N, A)
+    xt = torch.from_numpy(x).cuda()
+    idx_ref, zq_ref, usage_ref = oracle.nearest(oracle.llfq_encode(p, x), p["quantizer.codebook"])
+    monkeypatch.setenv("LIPVQ_TOK_SHAPE", shape)
+    model.code_usage.zero_()
+    idx, zq = model.tokenize(xt)
+    assert np.array_equal(idx.cpu().numpy(), idx_ref) and np.array_equal(zq.cpu().numpy(), zq_ref)
+    assert np.array_equal(model.code_usage.cpu().numpy(), usage_ref)
