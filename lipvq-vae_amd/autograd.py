@@ -42,23 +42,22 @@ class _LLFQFn(torch.autograd.Function):
         dec_packed = module._packed_decoder()
         codebook = module.quantizer.codebook.detach()
         need_grad = any(ctx.needs_input_grad[2:])
-        fused_ok = x.shape[0] > module.EXACT_ROWS_MAX and ops.tokenize_supported(module.feature_dim, 64, module.hidden_dim,
-                                                                                 module.latent_dim, module.num_codes)
+        screen = module.screen_pays(x.shape[0])          # one routing decision per call (tokenizer._ScreenMonitor)
+        fused_ok = x.shape[0] > module.EXACT_ROWS_MAX and screen and module.fused_shape()
         if need_grad and fused_ok:
             # large training batches: encoder + quantizer + everything the backward needs in ONE launch (lipvq_tokenize_train_f32)
             # instead of mlp3 (saved pre-activations) + the stand-alone screen over z_e
             idx, z_q, z_e, pre_e = module._tokenize_fused(x, module.code_usage, want_pre=True)
         elif need_grad:
             z_e, pre_e = ops.mlp3(x, enc_packed, _ENC_ACTS, save_pre=True)
-            idx, z_q = module._quantize(z_e, module.code_usage)
-        elif x.shape[0] > module.EXACT_ROWS_MAX and ops.tokenize_supported(module.feature_dim, 64, module.hidden_dim,
-                                                                          module.latent_dim, module.num_codes):
+            idx, z_q = module._quantize(z_e, module.code_usage, screen=screen)
+        elif fused_ok:
             # no autograd (rollouts under no_grad, bulk evaluation): the fused encode + quantize launch, z_e written for the loss
             idx, z_q, z_e = module._tokenize_fused(x, module.code_usage, want_ze=True)
             pre_e = None
         else:
             z_e, pre_e = ops.mlp3(x, enc_packed, _ENC_ACTS), None
-            idx, z_q = module._quantize(z_e, module.code_usage)
+            idx, z_q = module._quantize(z_e, module.code_usage, screen=screen)
         if need_grad:
             x_rec, pre_d = ops.mlp3(codebook, dec_packed, _DEC_ACTS, gather_idx=idx, save_pre=True)
         else:

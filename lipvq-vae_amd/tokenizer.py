@@ -85,8 +85,54 @@ class LFQQuantizer(nn.Module):
         return zq, idx
 
 
+class _ScreenMonitor:
+    """Keeps the certified screen from being used where it does not pay, without ever synchronising.
+
+    The screen hands the rows it cannot certify to the exact kernel.  With trained parameters that is a fraction of a percent;
+    with a DEGENERATE codebook -- the reference's own default initialisation maps every row to one code, a
+    collapsed training run does the same -- it is (almost) every row, and the exact kernel, built for a few thousand rows with
+    short candidate lists, would scan the whole codebook for each of them: orders of magnitude slower than the all-pairs exact
+    kernel (results are the same on every route).  So after each screened call the uncertified-row count (workspace[0]) is
+    copied to pinned host memory asynchronously; the NEXT call looks at it only if the copy's event has already completed
+    (``event.query()``: never a wait).  A fraction above ``THRESHOLD`` routes the following ``PROBE_EVERY`` large-batch calls
+    through the all-pairs kernel, then the screen is tried again."""
+
+    THRESHOLD = 1.0 / 16.0        # beyond N/8 listed rows the exact kernel has no candidate lists left (lq_cand_cap)
+    PROBE_EVERY = 16
+
+    def __init__(self):
+        self._pending = None
+        self.bypass_calls = 0
+        self.last_fraction = None
+
+    def use_screen(self) -> bool:
+        if torch.cuda.is_current_stream_capturing():
+            return True                                  # a graph capture records one route; no host decisions inside it
+        if self._pending is not None:
+            ev, host, n = self._pending
+            if ev.query():
+                self.last_fraction = float(host[0]) / max(1, n)
+                self._pending = None
+                if self.last_fraction > self.THRESHOLD:
+                    self.bypass_calls = self.PROBE_EVERY
+        if self.bypass_calls > 0:
+            self.bypass_calls -= 1
+            return False
+        return True
+
+    def record(self, ws: torch.Tensor, n: int) -> None:
+        if torch.cuda.is_current_stream_capturing() or self._pending is not None:
+            return
+        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        host.copy_(ws[:1], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending = (ev, host, int(n))
+
+
 class _TokenizerBase(nn.Module):
     def _init_extras(self, K):
+        self._screen_monitor = _ScreenMonitor()
         self.register_buffer("code_usage", torch.zeros(K, dtype=torch.int64), persistent=False)
         self.last_indices = None
         self._enc_cache = _PackCache()
@@ -180,19 +226,28 @@ class LLFQVAE_V4(_TokenizerBase):
     # screen [+ codebook preparation]: D = 208: 36 vs 75 [+69] us at N = 80, 74 vs 122 [+69] at 2048, 143 vs 89 [+69] at 4096
     EXACT_ROWS_MAX = 2048
 
-    def _quantize(self, z_e, usage):
+    def screen_pays(self, n_rows: int) -> bool:
+        """ONE routing decision per call: small batches never consult the monitor (the exact kernel copes with all of their rows);
+        large ones ask it whether the screen has been certifying its rows (see _ScreenMonitor)."""
+        return n_rows <= self.EXACT_ROWS_MAX or self._screen_monitor.use_screen()
+
+    def _quantize(self, z_e, usage, screen=None):
         """(idx, z_q) of v5:37-48: MFMA screen + exact re-scoring where the latent width has a
         screening instance, the all-pairs exact kernel otherwise.  Identical results either way."""
         cb = self.quantizer.codebook.detach()
+        if screen is None:
+            screen = self.screen_pays(z_e.shape[0])
         if ops.nearest_screen_supported(cb.shape[0], cb.shape[1]) and 0 < z_e.shape[0] <= self.EXACT_ROWS_MAX:
             # training-step batches: the exact kernel on every row beats preparing the codebook + one screen launch
             self.last_exact_rows = None
             return ops.nearest_rows(z_e, cb, usage=usage)
-        if ops.nearest_screen_supported(cb.shape[0], cb.shape[1]) and z_e.shape[0] > 0:
+        if ops.nearest_screen_supported(cb.shape[0], cb.shape[1]) and z_e.shape[0] > 0 and screen:
             prep = self._cb_cache.get((self.quantizer.codebook,), lambda: ops.nearest_prepare(cb))
             idx, zq, ws = ops.nearest_screened(z_e, cb, prep, usage=usage, return_workspace=True)
             self.last_exact_rows = ws
+            self._screen_monitor.record(ws, z_e.shape[0])
             return idx, zq
+        self.last_exact_rows = None
         idx, zq, _ = ops.nearest(z_e, cb, DIST_NORM, usage=usage)
         return idx, zq
 
@@ -221,11 +276,16 @@ class LLFQVAE_V4(_TokenizerBase):
             idx, zq, ze, ws, pre = ops.tokenize(x, packed, (w0, b0, w1, b1, Wn, b2), cb, prep, usage=usage, workspace=self._tok_ws,
                                                 want_pre=True)
             self.last_exact_rows = ws
+            self._screen_monitor.record(ws, x.shape[0])
             return idx, zq, ze, pre
         idx, zq, ze, ws = ops.tokenize(x, packed, (w0, b0, w1, b1, Wn, b2), cb, prep, usage=usage, want_ze=want_ze,
                                        workspace=self._tok_ws, packed16=packed16)
         self.last_exact_rows = ws
+        self._screen_monitor.record(ws, x.shape[0])
         return idx, zq, ze
+
+    def fused_shape(self) -> bool:
+        return ops.tokenize_supported(self.feature_dim, 64, self.hidden_dim, self.latent_dim, self.num_codes)
 
     @torch.no_grad()
     def tokenize(self, x, count_usage=True, mode="parity"):
@@ -241,10 +301,11 @@ class LLFQVAE_V4(_TokenizerBase):
         shape = (self.feature_dim, 64, self.hidden_dim, self.latent_dim, self.num_codes)
         if mode == "fast" and not ops.tokenize_fast_supported(*shape):
             raise RuntimeError("tokenize(mode='fast') needs the fast kernel's shapes (hidden 64/128, D in {32, 64, 128})")
-        if x.shape[0] > 0 and ops.tokenize_supported(*shape):
+        screen = self.screen_pays(x.shape[0])
+        if x.shape[0] > 0 and screen and self.fused_shape():
             idx, zq, _ = self._tokenize_fused(x, usage, fast=(mode == "fast"))
         else:
-            idx, zq = self._quantize(self.encode(x), usage)
+            idx, zq = self._quantize(self.encode(x), usage, screen=screen)
         self.last_indices = idx
         return idx, zq
 
@@ -312,10 +373,12 @@ class VQVAE(_TokenizerBase):
             if n <= self.EXACT_ROWS_MAX:
                 self.last_exact_rows = None
                 return ops.nearest_rows(z_e, cb, usage=usage, dist=DIST_SQSUM)
-            prep = self._cb_cache.get((self.embedding.weight,), lambda: ops.nearest_prepare(cb))
-            idx, zq, ws = ops.nearest_screened(z_e, cb, prep, usage=usage, return_workspace=True, dist=DIST_SQSUM)
-            self.last_exact_rows = ws
-            return idx, zq
+            if self._screen_monitor.use_screen():
+                prep = self._cb_cache.get((self.embedding.weight,), lambda: ops.nearest_prepare(cb))
+                idx, zq, ws = ops.nearest_screened(z_e, cb, prep, usage=usage, return_workspace=True, dist=DIST_SQSUM)
+                self.last_exact_rows = ws
+                self._screen_monitor.record(ws, n)
+                return idx, zq
         self.last_exact_rows = None
         idx, zq, _ = ops.nearest(z_e, cb, DIST_SQSUM, usage=usage)
         return idx, zq
