@@ -103,7 +103,8 @@ int lipvq_mse_pair_loss_f32(const float* xr, const float* x, int64_t nx, const f
  * Redo it whenever the codebook changes.  prep: lipvq_nearest_prep_bytes(K, D) bytes. */
 size_t lipvq_nearest_prep_bytes(int K, int D);
 int lipvq_nearest_prepare_f32(const float* codebook, void* prep, int K, int D, void* stream);
-int lipvq_nearest_screened_supported(int K, int D);          /* 1 for D in {32, 64, 128, 208} */
+int lipvq_nearest_screened_supported(int K, int D);          /* 1 for any D in 1 ... 208 (widths other than 32 / 64 / 128 / 208 run
+                                                               * the next larger instance on zero-padded columns) */
 size_t lipvq_nearest_workspace_bytes(int64_t N);
 /* idx / zq / usage exactly as lipvq_nearest_f32.  After the call the first int of `workspace`
  * holds how many rows were decided by the exact kernel (the rest were certified by the screen). */
@@ -111,13 +112,13 @@ int lipvq_nearest_screened_f32(const float* z, const float* codebook, const void
                                int64_t* usage, void* workspace, int64_t N, int K, int D, void* stream);
 /* Same contract again (idx / zq / usage as lipvq_nearest_f32 with LIPVQ_DIST_NORM) with every row decided by the exact
  * re-scoring kernel: needs no prepared codebook.  For batches of a few thousand rows (training steps, where the codebook
- * changes every step).  D in {32, 64, 128, 208}. */
+ * changes every step).  Any D (tuned instances for 32 / 64 / 128 / 208, a generic kernel otherwise). */
 int lipvq_nearest_rows_f32(const float* z, const float* codebook, int64_t* idx, float* zq, int64_t* usage, int64_t N,
                            int K, int D, void* stream);
 /* The plain VQVAE's quantizer (reference robomimic/models/vq_vae/backbone.py:55-63: `(z_e.unsqueeze(1) - E).pow(2).sum(-1)`,
  * argmin) through the same two routes: idx / zq / usage exactly as lipvq_nearest_f32(.., LIPVQ_DIST_SQSUM).  The screen is the
  * same certified MFMA screen (its margin covers the sum rule's rounding too); uncertified rows are decided by the exact kernel in
- * torch's cascade-sum order, first minimum.  prep / workspace as for lipvq_nearest_screened_f32.  D in {32, 64, 128, 208}. */
+ * torch's cascade-sum order, first minimum.  prep / workspace as for lipvq_nearest_screened_f32.  D in 1 ... 208. */
 int lipvq_vq_nearest_screened_f32(const float* z, const float* codebook, const void* prep, int64_t* idx, float* zq,
                                   int64_t* usage, void* workspace, int64_t N, int K, int D, void* stream);
 int lipvq_vq_nearest_rows_f32(const float* z, const float* codebook, int64_t* idx, float* zq, int64_t* usage, int64_t N,

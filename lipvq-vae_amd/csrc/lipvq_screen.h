@@ -20,9 +20,17 @@ struct PrepLayout {
     size_t o_hdr, o_mu, o_tiles, tile_bytes, total;
 };
 
+// k-steps (of 16 columns) of the screening instance that serves a D-column latent: the instances are 2, 4, 8 and 13 k-steps
+// (D = 32, 64, 128, 208); any other width up to 208 runs the next larger one on zero-padded columns (zeros add nothing to a
+// dot product, so the screened values and their error bound are those of the unpadded row); 0 = no instance.
+__host__ __device__ static inline int lq_screen_S(int D) {
+    const int s = (D + 15) / 16;
+    return D <= 0 ? 0 : s <= 2 ? 2 : s <= 4 ? 4 : s <= 8 ? 8 : s <= 13 ? 13 : 0;
+}
+
 __host__ __device__ static inline PrepLayout prep_layout(int K, int D) {
     PrepLayout L;
-    L.S = (D + 15) / 16;
+    L.S = lq_screen_S(D) ? lq_screen_S(D) : (D + 15) / 16;
     L.Dpad = L.S * 16;
     L.Kpad = ((K + 31) / 32) * 32;
     L.ntiles = ((L.Kpad / 32 + 7) / 8) * 8;   // whole LDS stages: pad tiles carry e2 = +inf, zero fragments
@@ -489,7 +497,9 @@ __device__ __forceinline__ bool lq_screen_decide(const float (&m1)[16], const fl
     //  numbers: S_k1 <= best + |z'|^2 + eps_s, plus the rounding of n2 itself ((D + 2) u n2).  The bound is relative to the
     //  WINNER's distance (not to the largest distance the row can see), so it is rigorous for every D and negligible for
     //  rows close to a code.
-    const int Dpad16 = ((D + 15) / 16) * 16;
+    //  A width that is not a multiple of 8 adds the reference's remainder handling to (2): up to 7 more additions, four of them
+    //  of separately rounded products (lq_sqdist8; the sum rule adds its scalar tail likewise): 11 more roundings.
+    const int Dpad16 = ((D + 15) / 16) * 16 + ((D & 7) ? 88 : 0);             // (enters only as Dpad16 / 8 + 12 and Dpad16 + 2 below)
     const float u24 = 5.9604644775390625e-08f;                                  // 2^-24
     const float eps_s = gamma * (E2max + cross) * fown;
     const float n2s = n2 * fown;
@@ -641,6 +651,17 @@ __device__ __forceinline__ void lq_screen_gather(const float* __restrict__ cb, f
 #ifdef LQ_ABL_NOGATHER
     return;
 #endif
+    if (D & 3) {
+        // rows that are not whole 16-byte vectors (any-width route): 16 lanes copy one row element by element, 4 rows per pass
+        for (int p = 0; p < 8; ++p) {
+            const int src_lane = 4 * p + (lane >> 4);
+            const int kk = __shfl(my_k, src_lane, 64);
+            const bool ok = (__shfl((int)certified, src_lane, 64) != 0) && (row0 + src_lane < N);
+            if (ok)
+                for (int d = lane & 15; d < D; d += 16) zq[(size_t)(row0 + src_lane) * D + d] = cb[(size_t)kk * D + d];
+        }
+        return;
+    }
     for (int trip = 0; 64 * trip < D; ++trip) {
         LqGatherTrip g;
         lq_gather_load(g, cb, my_k, certified, row0, N, D, lane, trip);

@@ -529,6 +529,82 @@ __global__ __launch_bounds__(256) void nearest_rows_kernel(
   }
 }
 
+// Any latent width (no compile-time D, rows not necessarily 16-byte aligned): the same decision for a listed row -- short lists,
+// lane masks, or a full scan -- with both operands read straight from global memory (L2) through lq_sqdist8 / lq_sqdist32, i.e.
+// torch's remainder handling included (lipvq_math.h).  The route of widths outside {32, 64, 128, 208}: a few thousand rows at most.
+template <int DIST>
+__global__ __launch_bounds__(256) void nearest_rows_any_kernel(
+    const float* __restrict__ z, const float* __restrict__ cb, int64_t* __restrict__ idx, float* __restrict__ zq,
+    unsigned long long* __restrict__ usage, const int* __restrict__ row_list, const int* __restrict__ row_count,
+    int K, int D, int z_by_slot, int count_direct, const int* __restrict__ cand_list, size_t cand_cap) {
+    constexpr int RB = 4, SL = 64;
+    __shared__ float s_v[RB][SL];
+    __shared__ int s_k[RB][SL];
+    const int count = row_count ? *row_count : count_direct;
+    const int r = threadIdx.x & (RB - 1), sl = threadIdx.x / RB;
+    auto score = [&](const float* zr, int k) {
+        const float* c = cb + (size_t)k * D;
+        const float v = (DIST == LIPVQ_DIST_NORM) ? lq_sqrt(lq_sqdist8(zr, c, D)) : lq_sqdist32(zr, c, D);
+        return (v == v) ? v : INFINITY;                        // a NaN never wins; the code stays valid
+    };
+    for (int base = blockIdx.x * RB; base < count; base += gridDim.x * RB) {
+        const int slot = base + r;
+        const bool valid = slot < count;
+        const int cslot = valid ? slot : count - 1;
+        const int64_t row = row_list ? row_list[cslot] : cslot;
+        const float* zr = z + (size_t)(z_by_slot ? (int64_t)cslot : row) * D;
+        const int per = (K + SL - 1) / SL;
+        const int kb = sl * per, ke = (kb + per < K) ? kb + per : K;
+        float best_v = INFINITY;
+        int best_k = kb < K ? kb : K - 1;
+        int n0 = -1, n1 = -1;
+        const int* cl = nullptr;
+        if (cand_list && (size_t)cslot < cand_cap) {
+            cl = cand_list + (size_t)cslot * 16;
+            n0 = cl[0]; n1 = cl[8];
+        }
+        if (n0 >= 0 && n1 >= 0 && n0 + n1 >= 1 && n0 <= LQ_CAND_MAX && n1 <= LQ_CAND_MAX) {
+            const int j = sl < n0 + n1 ? sl : 0;
+            int code = j < n0 ? cl[2 + j] : cl[10 + (j - n0)];
+            code = (code >= 0 && code < K) ? code : 0;
+            best_k = code;
+            best_v = score(zr, code);
+        } else if (n0 != -1 && n1 != -1 && cl) {
+            const unsigned lanes = ((unsigned)cl[1] & 0xffffu) | (((unsigned)cl[9] & 0xffffu) << 16);
+            const int ntile = (K + 31) / 32;
+            for (int t = sl; t < ntile; t += SL) {                // ascending codes within a slice: first minimum kept
+                unsigned m = lanes;
+                while (m) {
+                    const int l = __builtin_ctz(m);
+                    m &= m - 1;
+                    const int k = 32 * t + l;
+                    if (k < K) {
+                        const float v = score(zr, k);
+                        if (v < best_v) { best_v = v; best_k = k; }
+                    }
+                }
+            }
+        } else {
+            for (int k = kb; k < ke; ++k) {
+                const float v = score(zr, k);
+                if (v < best_v) { best_v = v; best_k = k; }
+            }
+        }
+        lq_rows_reduce(best_v, best_k, s_v, s_k, r, threadIdx.x);
+        if (sl == 0) {
+            if (valid) idx[row] = (int64_t)best_k;
+            s_k[r][0] = best_k;
+        }
+        if (usage && threadIdx.x < 64) lq_usage_add(usage, (sl == 0 && valid) ? s_k[r][0] : 0, sl == 0 && valid);
+        __syncthreads();
+        if (zq && valid) {
+            const int bk = s_k[r][0];
+            for (int d = sl; d < D; d += SL) zq[(size_t)row * D + d] = cb[(size_t)bk * D + d];
+        }
+        __syncthreads();
+    }
+}
+
 // One row per workgroup, 256 code slices: the training-step route (every row of a batch of a few hundred rows is decided
 // exactly, lipvq_nearest_rows_f32).  With 4 rows x 64 slices a thread walked K/64 codes one after the other -- 16 dependent
 // row fetches at K = 1024: 45 us for 80 rows, as long as both MLP launches of the step together; here it walks K/256.
@@ -799,6 +875,18 @@ static int launch_rows_t(const float* z, int z_by_slot, const float* cb, int64_t
     return check_launch("nearest_rows");
 }
 
+template <int DIST>
+static int launch_rows_any(const float* z, int z_by_slot, const float* cb, int64_t* idx, float* zq, int64_t* usage,
+                           const int* amb_list, const int* amb_count, int64_t N, int K, int D, hipStream_t st) {
+    if (D <= 0) return fail(LIPVQ_EINVAL, "nearest_rows: D=%d", D);
+    int64_t blocks = (N + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((nearest_rows_any_kernel<DIST>), dim3((unsigned)blocks), dim3(256), 0, st, z, cb, idx, zq,
+                       (unsigned long long*)usage, amb_list, amb_count, K, D, z_by_slot, amb_list ? 0 : (int)N,
+                       amb_list ? amb_list + 2 * lq_list_ints(N) : nullptr, amb_list ? lq_cand_cap(N) : (size_t)0);
+    return check_launch("nearest_rows_any");
+}
+
 int lipvq_launch_rows(const float* z, int z_by_slot, const float* cb, int64_t* idx, float* zq, int64_t* usage,
                       const int* amb_list, const int* amb_count, int64_t N, int K, int D, hipStream_t st, int dist) {
     if (dist == LIPVQ_DIST_SQSUM) {
@@ -807,7 +895,7 @@ int lipvq_launch_rows(const float* z, int z_by_slot, const float* cb, int64_t* i
             case 64: return launch_rows_t<8, LIPVQ_DIST_SQSUM>(z, z_by_slot, cb, idx, zq, usage, amb_list, amb_count, N, K, st);
             case 128: return launch_rows_t<16, LIPVQ_DIST_SQSUM>(z, z_by_slot, cb, idx, zq, usage, amb_list, amb_count, N, K, st);
             case 208: return launch_rows_t<26, LIPVQ_DIST_SQSUM>(z, z_by_slot, cb, idx, zq, usage, amb_list, amb_count, N, K, st);
-            default: return fail(LIPVQ_EUNSUPPORTED, "nearest_rows: D=%d has no instance", D);
+            default: return launch_rows_any<LIPVQ_DIST_SQSUM>(z, z_by_slot, cb, idx, zq, usage, amb_list, amb_count, N, K, D, st);
         }
     }
     switch (D) {
@@ -815,7 +903,7 @@ int lipvq_launch_rows(const float* z, int z_by_slot, const float* cb, int64_t* i
         case 64: return launch_rows_t<8>(z, z_by_slot, cb, idx, zq, usage, amb_list, amb_count, N, K, st);
         case 128: return launch_rows_t<16>(z, z_by_slot, cb, idx, zq, usage, amb_list, amb_count, N, K, st);
         case 208: return launch_rows_t<26>(z, z_by_slot, cb, idx, zq, usage, amb_list, amb_count, N, K, st);
-        default: return fail(LIPVQ_EUNSUPPORTED, "nearest_rows: D=%d has no instance", D);
+        default: return launch_rows_any<LIPVQ_DIST_NORM>(z, z_by_slot, cb, idx, zq, usage, amb_list, amb_count, N, K, D, st);
     }
 }
 
@@ -828,19 +916,19 @@ static int screened_impl(const float* z, const float* cb, const void* prep, int6
     if (e != hipSuccess) return fail(LIPVQ_EHIP, "nearest_screened: %s", hipGetErrorString(e));
     const unsigned char* p = (const unsigned char*)prep;
     int rc;
-    switch (D) {
-        case 32: rc = launch_screen<2>(z, p, cb, idx, zq, usage, amb_list, amb_count, dbg, N, K, D, gamma, st); break;
-        case 64: rc = launch_screen<4>(z, p, cb, idx, zq, usage, amb_list, amb_count, dbg, N, K, D, gamma, st); break;
-        case 128: rc = launch_screen<8>(z, p, cb, idx, zq, usage, amb_list, amb_count, dbg, N, K, D, gamma, st); break;
-        case 208: rc = launch_screen<13>(z, p, cb, idx, zq, usage, amb_list, amb_count, dbg, N, K, D, gamma, st); break;
-        default: return fail(LIPVQ_EUNSUPPORTED, "nearest_screened: D=%d has no screening instance (32, 64, 128, 208)", D);
+    switch (lq_screen_S(D)) {                   // widths between the instances run the next larger one on zero-padded columns
+        case 2: rc = launch_screen<2>(z, p, cb, idx, zq, usage, amb_list, amb_count, dbg, N, K, D, gamma, st); break;
+        case 4: rc = launch_screen<4>(z, p, cb, idx, zq, usage, amb_list, amb_count, dbg, N, K, D, gamma, st); break;
+        case 8: rc = launch_screen<8>(z, p, cb, idx, zq, usage, amb_list, amb_count, dbg, N, K, D, gamma, st); break;
+        case 13: rc = launch_screen<13>(z, p, cb, idx, zq, usage, amb_list, amb_count, dbg, N, K, D, gamma, st); break;
+        default: return fail(LIPVQ_EUNSUPPORTED, "nearest_screened: D=%d has no screening instance (1 ... 208)", D);
     }
     if (rc) return rc;
     return lipvq_launch_rows(z, 0, cb, idx, zq, usage, amb_list, amb_count, N, K, D, st, dist);
 }
 
 extern "C" int lipvq_nearest_screened_supported(int K, int D) {
-    return (K > 0 && (D == 32 || D == 64 || D == 128 || D == 208)) ? 1 : 0;
+    return (K > 0 && lq_screen_S(D) != 0) ? 1 : 0;            // any width 1 ... 208
 }
 
 // Exact decision of EVERY row by the re-scoring kernel (4 rows x 64 code slices per workgroup): no codebook
@@ -866,7 +954,7 @@ extern "C" int lipvq_nearest_screened_f32(const float* z, const float* codebook,
     if (N == 0) return LIPVQ_OK;
     if (!z || !codebook || !prep || !idx || !workspace) return fail(LIPVQ_EINVAL, "nearest_screened: null pointer");
     if (N > 2147483647LL) return fail(LIPVQ_EUNSUPPORTED, "nearest_screened: N too large");
-    if ((((uintptr_t)z | (uintptr_t)codebook | (uintptr_t)zq) & 15) != 0)
+    if (!(D & 7) && (((uintptr_t)z | (uintptr_t)codebook | (uintptr_t)zq) & 15) != 0)
         return fail(LIPVQ_EINVAL, "nearest_screened: z, codebook and zq must be 16-byte aligned");
     return screened_impl(z, codebook, prep, idx, zq, usage, workspace, nullptr, N, K, D, LIPVQ_SCREEN_GAMMA,
                          (hipStream_t)stream);
@@ -880,7 +968,7 @@ extern "C" int lipvq_vq_nearest_screened_f32(const float* z, const float* codebo
     if (N == 0) return LIPVQ_OK;
     if (!z || !codebook || !prep || !idx || !workspace) return fail(LIPVQ_EINVAL, "vq_nearest_screened: null pointer");
     if (N > 2147483647LL) return fail(LIPVQ_EUNSUPPORTED, "vq_nearest_screened: N too large");
-    if ((((uintptr_t)z | (uintptr_t)codebook | (uintptr_t)zq) & 15) != 0)
+    if (!(D & 7) && (((uintptr_t)z | (uintptr_t)codebook | (uintptr_t)zq) & 15) != 0)
         return fail(LIPVQ_EINVAL, "vq_nearest_screened: z, codebook and zq must be 16-byte aligned");
     return screened_impl(z, codebook, prep, idx, zq, usage, workspace, nullptr, N, K, D, LIPVQ_SCREEN_GAMMA,
                          (hipStream_t)stream, LIPVQ_DIST_SQSUM);

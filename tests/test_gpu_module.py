@@ -240,17 +240,22 @@ def test_full_size_properties(oracle):
 
 
 def test_degenerate_codebook_is_routed_around_the_screen(oracle):
-    """The reference's DEFAULT initialisation maps every row to one code: the certified screen then certifies
-    nothing and the exact kernel would have to scan the whole codebook for every row.  The tokenizer notices (the uncertified
-    count of a call is read back without synchronising) and routes the following large batches through the all-pairs kernel;
-    results are the oracle's on every call, whichever route ran -- and a trained-like model stays on the fused launch."""
+    """A codebook in which every code exists twice (dead-code resets that copy live codes, a collapsed run): every row is an exact
+    tie, the certified screen certifies nothing and the exact kernel -- built for a fraction of a percent of the rows, with
+    candidate lists for at most N/8 of them -- would scan the whole codebook for the rest.  The tokenizer notices (the
+    uncertified count of a call is read back without synchronising) and routes the following large batches through the
+    all-pairs kernel; results are the oracle's on every call, whichever route ran -- and an ordinary model stays on the fused
+    launch.  (The reference's default initialisation, although it maps every row to ONE code, is no such case: its rows are
+    certified.)"""
     from lipvq_vae_amd.tokenizer import LLFQVAE_V4
     A, D, K, N = 7, 64, 1024, 12000
-    p = O.make_params(41, A, D, K, regime="default", oracle=oracle)
+    p = O.make_params(41, A, D, K, oracle=oracle)
+    p["quantizer.codebook"][K // 2:] = p["quantizer.codebook"][:K // 2]
     model = _model(LLFQVAE_V4, p, A, D, num_codes=K)
     x = O.make_inputs(42, N, A)
     xt = torch.from_numpy(x).cuda()
     idx_ref, zq_ref, _ = oracle.nearest(oracle.llfq_encode(p, x), p["quantizer.codebook"])
+    assert idx_ref.max() < K // 2                      # first-minimum rule: the lower copy wins every tie
     routes = []
     for _ in range(4):
         idx, zq = model.tokenize(xt, count_usage=False)

@@ -137,6 +137,35 @@ def test_adversarial_near_ties_odd_widths_match_the_reference(ops, name, golden_
     assert np.array_equal(idx.cpu().numpy(), ref)
     assert np.array_equal(zq.cpu().numpy(), cb[ref])
     assert np.array_equal(best.cpu().numpy(), g["d_best"])
+    # ... and through the screened route (the next larger screening instance on zero-padded columns, then the any-width exact
+    # kernel for the rows it cannot certify -- here (nearly) all of them) and the exact-rows route
+    cbd, zd = dev(cb), dev(z)
+    assert ops.nearest_screen_supported(K, D)
+    idx2, zq2, ws = ops.nearest_screened(zd, cbd, ops.nearest_prepare(cbd), return_workspace=True)
+    assert np.array_equal(idx2.cpu().numpy(), ref) and np.array_equal(zq2.cpu().numpy(), cb[ref])
+    assert int(ws[0]) >= (99 * N) // 100, "near-ties were certified by the approximate screen"
+    idx3, zq3 = ops.nearest_rows(zd, cbd)
+    assert np.array_equal(idx3.cpu().numpy(), ref) and np.array_equal(zq3.cpu().numpy(), cb[ref])
+
+
+@pytest.mark.parametrize("D", [1, 5, 9, 20, 37, 48, 100, 150, 203])
+@pytest.mark.parametrize("dist", [0, 1])
+def test_any_width_screened_equals_oracle(ops, oracle, D, dist):
+    """Ordinary (not adversarial) rows at widths between the screening instances: most rows must be CERTIFIED by the screen --
+    the zero-padded columns change neither the screened values nor their bound -- and every index is the oracle's, for the
+    norm rule and the sum rule alike."""
+    N, K = 3000, 700
+    z, cb = _case(D + 11, N, K, D)
+    idx_ref, zq_ref, usage_ref = oracle.nearest(z, cb, dist=dist)
+    cbd, zd = dev(cb), dev(z)
+    usage = torch.zeros(K, dtype=torch.int64, device="cuda")
+    idx, zq, ws = ops.nearest_screened(zd, cbd, ops.nearest_prepare(cbd), usage=usage, return_workspace=True, dist=dist)
+    assert np.array_equal(idx.cpu().numpy(), idx_ref) and np.array_equal(zq.cpu().numpy(), zq_ref)
+    assert np.array_equal(usage.cpu().numpy(), usage_ref)
+    if D >= 5:
+        assert int(ws[0]) < N // 4, f"the screen certified too little at D = {D}: {int(ws[0])} of {N} rows left"
+    idx2, _ = ops.nearest_rows(zd[:500].contiguous(), cbd, dist=dist)
+    assert np.array_equal(idx2.cpu().numpy(), idx_ref[:500])
 
 
 @pytest.mark.parametrize("name", ODD_VQ)
@@ -151,6 +180,11 @@ def test_vq_adversarial_near_ties_match_the_reference(ops, name, golden_dir):
     assert np.array_equal(idx.cpu().numpy(), ref)
     assert np.array_equal(zq.cpu().numpy(), cb[ref])
     assert np.array_equal(best.cpu().numpy(), g["d_best"])
+    cbd, zd = dev(cb), dev(z)
+    idx2, zq2 = ops.nearest_screened(zd, cbd, ops.nearest_prepare(cbd), dist=O.DIST_SQSUM)[:2]
+    assert np.array_equal(idx2.cpu().numpy(), ref) and np.array_equal(zq2.cpu().numpy(), cb[ref])
+    idx3, _ = ops.nearest_rows(zd, cbd, dist=O.DIST_SQSUM)
+    assert np.array_equal(idx3.cpu().numpy(), ref)
 
 
 @pytest.mark.parametrize("N,K,D", [(4096, 1024, 64), (1000, 256, 32), (700, 1000, 128), (80, 1024, 208), (33, 37, 64),
