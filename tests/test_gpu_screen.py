@@ -143,7 +143,10 @@ def test_adversarial_near_ties_odd_widths_match_the_reference(ops, name, golden_
     assert ops.nearest_screen_supported(K, D)
     idx2, zq2, ws = ops.nearest_screened(zd, cbd, ops.nearest_prepare(cbd), return_workspace=True)
     assert np.array_equal(idx2.cpu().numpy(), ref) and np.array_equal(zq2.cpu().numpy(), cb[ref])
-    assert int(ws[0]) >= (99 * N) // 100, "near-ties were certified by the approximate screen"
+    # (in few dimensions the midpoint of two random codes usually has a THIRD code much closer: only the rows whose two smallest
+    # reference distances nearly coincide are near-ties -- 314 of 4096 at D = 7, all of them from D = 100 on)
+    near = int(((g["d_second"] - g["d_best"]) <= 1e-6 * np.maximum(g["d_second"], 1e-30)).sum())
+    assert int(ws[0]) >= near, "near-ties were certified by the approximate screen"
     idx3, zq3 = ops.nearest_rows(zd, cbd)
     assert np.array_equal(idx3.cpu().numpy(), ref) and np.array_equal(zq3.cpu().numpy(), cb[ref])
 
