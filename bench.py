@@ -555,10 +555,21 @@ def main():
         ff_ms = timed_ms(full_forward, 5)
         ts_ms = timed_ms(train_step, 5)
         model.load_state_dict(saved)                 # the cpu_baseline below compares against the untrained parameters
+        # denominators for the two side readings (the same pricing as `roofline`: fp32 work at the fp32 MFMA peak, the distance
+        # screen's three split products at the fp16 MFMA peak; HBM is not the binding roof for either)
+        dec_flop = 2.0 * N * (D * 64 + 64 * 128 + 128 * A)
+        ff_floor = (enc_flop + dec_flop) / (PEAK_FP32_TFLOPS * 1e12) + 3.0 * dist_flop / (PEAK_F16_MFMA_TFLOPS * 1e12)
+        # training: forward + backward-data (the encoder's input gradient is not needed: its first layer drops out) + weight
+        # gradients = 3x the two stacks' forward flops minus that one layer
+        ts_floor = (3.0 * (enc_flop + dec_flop) - 2.0 * N * A * 64) / (PEAK_FP32_TFLOPS * 1e12) + 3.0 * dist_flop / (PEAK_F16_MFMA_TFLOPS * 1e12)
         out["also"] = {"full_forward": {"value": N / (ff_ms * 1e-3), "unit": "actions/s", "ms_per_step": ff_ms,
+                                        "floor_ms": ff_floor * 1e3, "frac": ff_floor * 1e3 / ff_ms,
                                         "what": "forward(x) without autograd: encode + quantize + decode + three losses"},
                        "train_step": {"value": N / (ts_ms * 1e-3), "unit": "actions/s", "ms_per_step": ts_ms,
-                                      "what": "zero_grad + forward + loss.backward() + AdamW.step() (icl.py:913-914, 968-970)"}}
+                                      "floor_ms": ts_floor * 1e3, "frac": ts_floor * 1e3 / ts_ms,
+                                      "what": "zero_grad + forward + loss.backward() + AdamW.step() (icl.py:913-914, 968-970); floor = "
+                                              "forward + backward-data + weight-gradient flops of both stacks at 157.3 TF/s fp32 MFMA "
+                                              "+ the screen's 3 split products at 2500 TF/s"}}
     # HBM traffic LAST among the GPU readings: the profiler children run after every timed side reading (and are reaped before
     # this process goes on), so nothing of them can overlap a measurement
     traffic, traffic_src, traffic_detail = None, None, None
