@@ -38,7 +38,7 @@ __host__ __device__ static inline PrepLayout prep_layout(int K, int D) {
     L.o_mu = 64;
     L.o_tiles = L.o_mu + sizeof(float) * (size_t)L.Dpad;
     L.o_tiles = (L.o_tiles + 255) & ~(size_t)255;
-    L.tile_bytes = (size_t)L.S * 2048 + 128;    // S steps x {hi,lo} x 32 codes x 2 halves x 16 B, then 32 x e2
+    L.tile_bytes = (size_t)L.S * 2048 + 256;    // S steps x {hi,lo} x 32 codes x 2 halves x 16 B, then 32 x |e'|^2, then 32 x |e'| (rounded up)
     L.total = L.o_tiles + (size_t)L.ntiles * L.tile_bytes;
     return L;
 }
@@ -70,7 +70,7 @@ constexpr int screen_default_tc(int S) { return (S <= 2) ? 8 : (S <= 4) ? 4 : (S
 
 template <int S, int TC_ = screen_default_tc(S)>
 struct ScreenCfg {
-    static constexpr int TILE_BYTES = S * 2048 + 128;
+    static constexpr int TILE_BYTES = S * 2048 + 256;
     static constexpr int TC = TC_;                                              // tiles per stage (divides 8)
     static constexpr int STAGE_BYTES = TC * TILE_BYTES;
     static constexpr int STAGE_VEC = STAGE_BYTES / 16;
@@ -126,30 +126,45 @@ __device__ __forceinline__ void lq_track_one(float v, int id, unsigned keep_mask
 // Bookkeeping of registers [LO, HI) of a finished 32 x 32 tile of d~ - |e'|^2 f (the chain starts from zero; the |e'|^2
 // term of the lane's code is added here, one fma per element, off the MFMA chain's critical path): per row (register)
 // and lane (code mod 32) the smallest value, its code and the second smallest.
-template <int LO, int HI, bool PACK = false>
-__device__ __forceinline__ void lq_track_part(const f32x16& acc, float e2, const float (&frow)[16], int id, unsigned keep_mask,
-                                              float (&m1)[16], float (&m2)[16], int (&k1)[16]) {
+// COARSE (round 3): the chain holds ONE product per k-step, hi x hi -- a third of the matrix work -- and the value that is booked is
+// a LOWER BOUND of the code's distance: the hi-only product is off by at most w(n, k) = (2^-9 + 2^-21) |z'_n| |e'_k| (each operand
+// rounded to 11 significant bits; Cauchy-Schwarz over the row), so  L = d~ - w <= d  for every code, and  L + 2 w >= d  for the
+// winner (lq_screen_decide).  en = |e'_k| of the lane's code (rounded up, from the tile), znr[r] = (2^-9 + 2^-21)(1 + 2^-10) |z'_n| f
+// of the register's row: one more fma per element.
+template <int LO, int HI, bool PACK = false, bool COARSE = false>
+__device__ __forceinline__ void lq_track_part(const f32x16& acc, float e2, float en, const float (&frow)[16], const float (&znr)[16],
+                                              int id, unsigned keep_mask, float (&m1)[16], float (&m2)[16], int (&k1)[16]) {
 #ifdef LQ_ABL_NOTRACK
     if (LO == 0) m1[0] = fminf(m1[0], acc[0] + acc[5] + acc[10] + acc[15]);   // keeps the MFMAs alive
     return;
 #endif
 #pragma unroll
-    for (int r = LO; r < HI; ++r) lq_track_one<PACK>(LQ_E2_TERM(e2, frow[r], acc[r]), id, keep_mask, m1[r], m2[r], k1[r]);
+    for (int r = LO; r < HI; ++r) {
+        float v = LQ_E2_TERM(e2, frow[r], acc[r]);
+        if constexpr (COARSE) v = lq_fma(-znr[r], en, v);
+        lq_track_one<PACK>(v, id, keep_mask, m1[r], m2[r], k1[r]);
+    }
 }
 
-// the pending tile's registers that are booked behind MFMA j of the 3 S MFMAs of the running tile: [16 j / 3S, 16 (j + 1) / 3S)
-// (j a compile-time constant after unrolling)
-template <int S, bool PACK>
-__device__ __forceinline__ void lq_track_after_mfma(int j, const f32x16& acc, float e2, const float (&frow)[16], int id,
-                                                    unsigned keep_mask, float (&m1)[16], float (&m2)[16], int (&k1)[16]) {
+// the pending tile's registers that are booked behind MFMA j of the NM MFMAs of the running tile (NM = 3 S, or S for the
+// one-product chain): [16 j / NM, 16 (j + 1) / NM)   (j a compile-time constant after unrolling)
+template <int S, bool PACK, bool COARSE = false>
+__device__ __forceinline__ void lq_track_after_mfma(int j, const f32x16& acc, float e2, float en, const float (&frow)[16],
+                                                    const float (&znr)[16], int id, unsigned keep_mask, float (&m1)[16],
+                                                    float (&m2)[16], int (&k1)[16]) {
 #ifdef LQ_ABL_NOTRACK
     if (j == 0) m1[0] = fminf(m1[0], acc[0] + acc[5] + acc[10] + acc[15]);
     return;
 #endif
-    const int lo = (16 * j) / (3 * S), hi = (16 * (j + 1)) / (3 * S);
+    constexpr int NM = COARSE ? S : 3 * S;
+    const int lo = (16 * j) / NM, hi = (16 * (j + 1)) / NM;
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-        if (r >= lo && r < hi) lq_track_one<PACK>(LQ_E2_TERM(e2, frow[r], acc[r]), id, keep_mask, m1[r], m2[r], k1[r]);
+        if (r >= lo && r < hi) {
+            float v = LQ_E2_TERM(e2, frow[r], acc[r]);
+            if constexpr (COARSE) v = lq_fma(-znr[r], en, v);
+            lq_track_one<PACK>(v, id, keep_mask, m1[r], m2[r], k1[r]);
+        }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -187,10 +202,11 @@ __host__ __device__ static inline int lq_pack_bits(int ntiles) { int b = 1; whil
 // RG row groups per wave (round 3): the wave multiplies RG x 32 rows against every tile, so that one pair of B-fragment reads,
 // one |e'|^2 read, one stage hand-over (wait, barrier, DMA issue) serve RG x 3 MFMAs per k-step instead of 3, and consecutive
 // MFMAs go to different accumulators.  ah/al/m1/m2/k1 carry the group as their leading dimension.
-template <int S, int NT, int TC_ = screen_default_tc(S), int NB = 4, bool PACK = false, int RG = 1>
+template <int S, int NT, int TC_ = screen_default_tc(S), int NB = 4, bool PACK = false, int RG = 1, bool COARSE = false>
 __device__ __forceinline__ void lq_screen_core_rg(const f16x8 (&ah)[RG][S], const f16x8 (&al)[RG][S],
                                                   const unsigned char* __restrict__ tiles, int ntiles,
                                                   unsigned char* stage0, int tid, const float (&frow)[16],
+                                                  const float (&znr)[RG][16],
                                                   float (&m1)[RG][16], float (&m2)[RG][16], int (&k1)[RG][16]) {
     using C = ScreenCfg<S, TC_>;
     static_assert(NB >= 2 && NB <= 4, "ring of 2..4 stage buffers");
@@ -267,12 +283,16 @@ __device__ __forceinline__ void lq_screen_core_rg(const f16x8 (&ah)[RG][S], cons
     // or the stage's position in the loop trip when NSTEP is odd
     f16x8 fh[FR], fl[FR];
     float e2q[2] = {0.0f, 0.0f};                  // |e'|^2 of the tile in accumulator A / B
+    float enq[2] = {0.0f, 0.0f};                  // COARSE: |e'| of the same tiles
+    float enA = 0.0f, enB = 0.0f;
 #ifndef LQ_ABL_NOLDSB
 #pragma unroll
     for (int g = 0; g < FD; ++g) {                // k-steps 0 .. FD-1 of stage 0 (FD <= S: all in tile 0)
-        fh[g] = frag(stage0, g, 0); fl[g] = frag(stage0, g, 1);
+        fh[g] = frag(stage0, g, 0);
+        if constexpr (!COARSE) fl[g] = frag(stage0, g, 1);
     }
     e2q[0] = reinterpret_cast<const float*>(stage0 + S * 2048)[ln];
+    if constexpr (COARSE) enq[0] = reinterpret_cast<const float*>(stage0 + S * 2048 + 128)[ln];
     static_assert(FD <= S, "prologue reads stay in tile 0");
 #endif
     int buf = 0;                                  // ring position of stage st
@@ -300,6 +320,7 @@ __device__ __forceinline__ void lq_screen_core_rg(const f16x8 (&ah)[RG][S], cons
             f32x16 (&acc)[RG] = (((c + par) & 1) == 0) ? accA : accB;
             const f32x16 (&prev)[RG] = (((c + par) & 1) == 0) ? accB : accA;
             const float e2_prev = (((c + par) & 1) == 0) ? e2B : e2A;
+            const float en_prev = (((c + par) & 1) == 0) ? enB : enA;
             const int code_prev = (((c + par) & 1) == 0) ? codeB : codeA;
             if (s == 0) {
 #pragma unroll
@@ -307,11 +328,14 @@ __device__ __forceinline__ void lq_screen_core_rg(const f16x8 (&ah)[RG][S], cons
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[g_][r] = 0.0f;
                 const float e2c = e2q[(c + par) & 1];
+                const float enc = enq[(c + par) & 1];
                 int code = PACK ? (st * C::TC + c) : (st * C::TC + c) * 32 + ln;
                 if constexpr (PACK) asm volatile("" : "+v"(code));      // the tile index lives in a vector register (lq_track_one)
-                if (((c + par) & 1) == 0) { e2A = e2c; codeA = code; } else { e2B = e2c; codeB = code; }
+                if (((c + par) & 1) == 0) { e2A = e2c; enA = enc; codeA = code; } else { e2B = e2c; enB = enc; codeB = code; }
             }
-            const f16x8 bh = fh[(g + so) % FR], bl = fl[(g + so) % FR];
+            const f16x8 bh = fh[(g + so) % FR];
+            f16x8 bl = bh;
+            if constexpr (!COARSE) bl = fl[(g + so) % FR];
 #ifndef LQ_ABL_NOLDSB
             // k-step g + FD of this stage, or (g + FD >= NSTEP > MID: the hand-over has passed) of the next stage's first tile.
             // Unconditional: behind the last stage it reads bytes of the ring that nobody uses (no branch in the loop body).
@@ -321,8 +345,11 @@ __device__ __forceinline__ void lq_screen_core_rg(const f16x8 (&ah)[RG][S], cons
                 const int gg = (g1 < NSTEP) ? g1 : g1 - NSTEP;
                 const unsigned char* tb = base + (size_t)(gg / S) * C::TILE_BYTES;
                 fh[(g1 + so) % FR] = frag(tb, gg % S, 0);
-                fl[(g1 + so) % FR] = frag(tb, gg % S, 1);
-                if (gg % S == 0) e2q[(g1 / S + par) & 1] = reinterpret_cast<const float*>(tb + S * 2048)[ln];   // g1 / S >= TC: next stage
+                if constexpr (!COARSE) fl[(g1 + so) % FR] = frag(tb, gg % S, 1);
+                if (gg % S == 0) {
+                    e2q[(g1 / S + par) & 1] = reinterpret_cast<const float*>(tb + S * 2048)[ln];   // g1 / S >= TC: next stage
+                    if constexpr (COARSE) enq[(g1 / S + par) & 1] = reinterpret_cast<const float*>(tb + S * 2048 + 128)[ln];
+                }
             }
 #endif
             // pinned order: reads, then (MFMA, its share of the pending tile's bookkeeping) x 3 -- left alone, hipcc lumps the
@@ -331,20 +358,25 @@ __device__ __forceinline__ void lq_screen_core_rg(const f16x8 (&ah)[RG][S], cons
 #pragma unroll
             for (int g_ = 0; g_ < RG; ++g_) {
                 acc[g_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g_][s], bh, acc[g_], 0, 0, 0);
-                lq_track_after_mfma<S, PACK>(3 * s + 0, prev[g_], e2_prev, frow, code_prev, keep_mask, m1[g_], m2[g_], k1[g_]);
+                lq_track_after_mfma<S, PACK, COARSE>(COARSE ? s : 3 * s + 0, prev[g_], e2_prev, en_prev, frow, znr[g_], code_prev, keep_mask,
+                                                     m1[g_], m2[g_], k1[g_]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (!COARSE) {
 #pragma unroll
-            for (int g_ = 0; g_ < RG; ++g_) {
-                acc[g_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[g_][s], bh, acc[g_], 0, 0, 0);
-                lq_track_after_mfma<S, PACK>(3 * s + 1, prev[g_], e2_prev, frow, code_prev, keep_mask, m1[g_], m2[g_], k1[g_]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                for (int g_ = 0; g_ < RG; ++g_) {
+                    acc[g_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[g_][s], bh, acc[g_], 0, 0, 0);
+                    lq_track_after_mfma<S, PACK, false>(3 * s + 1, prev[g_], e2_prev, en_prev, frow, znr[g_], code_prev, keep_mask,
+                                                        m1[g_], m2[g_], k1[g_]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
-            for (int g_ = 0; g_ < RG; ++g_) {
-                acc[g_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g_][s], bl, acc[g_], 0, 0, 0);
-                lq_track_after_mfma<S, PACK>(3 * s + 2, prev[g_], e2_prev, frow, code_prev, keep_mask, m1[g_], m2[g_], k1[g_]);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int g_ = 0; g_ < RG; ++g_) {
+                    acc[g_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g_][s], bl, acc[g_], 0, 0, 0);
+                    lq_track_after_mfma<S, PACK, false>(3 * s + 2, prev[g_], e2_prev, en_prev, frow, znr[g_], code_prev, keep_mask,
+                                                        m1[g_], m2[g_], k1[g_]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         buf = nbuf;
@@ -355,7 +387,8 @@ __device__ __forceinline__ void lq_screen_core_rg(const f16x8 (&ah)[RG][S], cons
     }
     // the last tile's chain: ntiles is even, so it ran into accB
 #pragma unroll
-    for (int g_ = 0; g_ < RG; ++g_) lq_track_part<0, 16, PACK>(accB[g_], e2B, frow, codeB, keep_mask, m1[g_], m2[g_], k1[g_]);
+    for (int g_ = 0; g_ < RG; ++g_)
+        lq_track_part<0, 16, PACK, COARSE>(accB[g_], e2B, enB, frow, znr[g_], codeB, keep_mask, m1[g_], m2[g_], k1[g_]);
     // the copies issued for stages past the end go to the dummy KiB, but they count: drain them, then every wave has left
     // the stage buffers (the callers reuse them as per-wave scratch: lq_screen_decide)
 #ifndef LQ_ABL_NOSTAGE
@@ -370,9 +403,10 @@ __device__ __forceinline__ void lq_screen_core(const f16x8 (&ah)[S], const f16x8
                                                const unsigned char* __restrict__ tiles, int ntiles,
                                                unsigned char* stage0, int tid, const float (&frow)[16],
                                                float (&m1)[16], float (&m2)[16], int (&k1)[16]) {
-    lq_screen_core_rg<S, NT, TC_, NB, PACK, 1>(reinterpret_cast<const f16x8 (&)[1][S]>(ah), reinterpret_cast<const f16x8 (&)[1][S]>(al),
-                                               tiles, ntiles, stage0, tid, frow, reinterpret_cast<float (&)[1][16]>(m1),
-                                               reinterpret_cast<float (&)[1][16]>(m2), reinterpret_cast<int (&)[1][16]>(k1));
+    lq_screen_core_rg<S, NT, TC_, NB, PACK, 1, false>(reinterpret_cast<const f16x8 (&)[1][S]>(ah), reinterpret_cast<const f16x8 (&)[1][S]>(al),
+                                                      tiles, ntiles, stage0, tid, frow, reinterpret_cast<const float (&)[1][16]>(frow),
+                                                      reinterpret_cast<float (&)[1][16]>(m1), reinterpret_cast<float (&)[1][16]>(m2),
+                                                      reinterpret_cast<int (&)[1][16]>(k1));
 }
 
 // frow[r] = factor of row (r, h) = the row this lane's accumulator register r belongs to, fetched from the lane that
@@ -407,12 +441,16 @@ struct LqDecision {
     bool screen_ok;              // the screen's numbers mean something (finite codebook bound, best code in range)
 };
 
-template <bool PACK = false>
+// COARSE (one-product screen): the booked values are lower bounds L = d~ - w (lq_track_part); `zn` is this lane's row's
+// (2^-9 + 2^-21)(1 + 2^-10) |z'| f and `tiles` / `tile_bytes` / `S` locate the winner's |e'| -- its upper bound is L + 2 w.
+#define LQ_COARSE_CC 1.9550323486328125e-03f      /* (2^-9 + 2^-21)(1 + 2^-10), rounded up */
+template <bool PACK = false, bool COARSE = false>
 __device__ __forceinline__ bool lq_screen_decide(const float (&m1)[16], const float (&m2)[16], const int (&k1)[16],
                                                  unsigned char* wave_lds /* LQ_DECIDE_BYTES, this wave only */,
                                                  const unsigned* hdr, float n2, float fown, float gamma, int K, int D,
                                                  int lane, int& my_k, LqDecision& dec, float pack_eps = 0.0f,
-                                                 unsigned keep_mask = 0xffffffffu) {
+                                                 unsigned keep_mask = 0xffffffffu, float zn = 0.0f,
+                                                 const unsigned char* tiles = nullptr, size_t tile_bytes = 0, int S = 0) {
     constexpr int TS = LQ_DECIDE_STRIDE;
     const int ln = lane & 31, h = lane >> 5;
     float* tv = reinterpret_cast<float*>(wave_lds);           // [32 rows][TS], reused by the passes
@@ -503,12 +541,21 @@ __device__ __forceinline__ bool lq_screen_decide(const float (&m1)[16], const fl
     const float u24 = 5.9604644775390625e-08f;                                  // 2^-24
     const float eps_s = gamma * (E2max + cross) * fown;
     const float n2s = n2 * fown;
-    const float s1 = fmaxf(0.0f, best + n2s) + eps_s + (float)(Dpad16 + 2) * u24 * n2s;
+    //  (0) COARSE: `best` is the winner's LOWER bound; its distance is at most best + 2 w(n, k1) (lq_track_part), every other code's
+    //      at least its own booked value: the same inequality with the winner's side raised by w2 = 2 w.
+    float w2 = 0.0f;
+    if constexpr (COARSE) {
+        const int bkc = (bk >= 0 && bk < K) ? bk : 0;
+        const float en = reinterpret_cast<const float*>(tiles + (size_t)(bkc >> 5) * tile_bytes + (size_t)S * 2048 + 128)[bkc & 31];
+        w2 = 2.0f * zn * en;
+        w2 = lq_fma(w2, 9.5367431640625e-07f, w2);          // (1 + 2^-20): the product's own rounding, generously
+    }
+    const float s1 = fmaxf(0.0f, best + w2 + n2s) + eps_s + (float)(Dpad16 + 2) * u24 * n2s;
     //  (3) PACK bookkeeping (lq_track_one): best and second carry the tile index in their low bits, a perturbation below
     //      pack_eps = 2^(TB-23) of each value's own magnitude, and so does every other code's value that `second` bounds.
     //  The same inequality, applied to ANY code's value v instead of `second`, says that code loses strictly to k1 in the
     //  reference's arithmetic: thr(v) = t0 + p (|best| + |v|)  (lq_screen_emit lists the codes it does not exclude).
-    dec.t0 = 2.0f * eps_s + 2.125f * (float)(Dpad16 / 8 + 12) * u24 * s1;
+    dec.t0 = w2 + 2.0f * eps_s + 2.125f * (float)(Dpad16 / 8 + 12) * u24 * s1;
     dec.p = 2.125f * pack_eps;
     dec.best = best;
     dec.m2min = m2min;
@@ -538,7 +585,9 @@ __device__ __forceinline__ bool lq_screen_decide(const float (&m1)[16], const fl
 // `mask` is always valid unless n = -1; the exact kernels use the lane masks of both parts as soon as one part says -2.
 #define LQ_CAND_MAX 6
 __host__ __device__ static inline size_t lq_list_ints(int64_t N);
-__host__ __device__ static inline size_t lq_cand_cap(int64_t N) { return (size_t)(N / 8) + 64; }   // slots that get a list; later slots: full scan
+// slots that get a list (later slots: full scan).  Every row can have one since round 3: the one-product screen leaves 10-40 % of
+// the rows to the exact kernel -- each with its two or three candidates -- where the three-product screen left a fraction of a percent
+__host__ __device__ static inline size_t lq_cand_cap(int64_t N) { return (size_t)N + 64; }
 
 template <bool PACK>
 __device__ __forceinline__ void lq_screen_emit(const LqDecision& dec, bool certified, bool lists_ok, int my_k, int64_t row,
@@ -668,6 +717,10 @@ __device__ __forceinline__ void lq_screen_gather(const float* __restrict__ cb, f
         lq_gather_store(g, zq, certified, row0, N, D, lane, trip);
     }
 }
+
+// which screen a shape runs by default (measured, profiles/r03_*; LIPVQ_SCREEN_MODE overrides per launch: lipvq_screen.hip)
+static inline int lq_screen_coarse_default(int S) { (void)S; return 0; }
+int lq_screen_coarse(int S);
 
 // workspace of the screened routes: [64 B: counter] [row list: lq_list_ints(N) ints] [best-candidate list: the same]
 // [short lists: 16 ints x lq_cand_cap(N)]

@@ -24,6 +24,7 @@
 // (LIPVQ_SCREEN_GAMMA) is 2^-18: 5x the analytic split bound, 16x the largest error observed;
 // tests/test_gpu_screen.py (test_error_bound_holds, test_any_magnitude) assert a >= 4x margin on every run.
 #include <stdlib.h>
+#include <string.h>
 
 #include "lipvq_screen.h"
 
@@ -114,7 +115,8 @@ __global__ void prep_e2_kernel(const float* __restrict__ cb, const float* __rest
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= L.ntiles * 32) return;
     float* e2p = reinterpret_cast<float*>(tiles + (size_t)(k >> 5) * L.tile_bytes + (size_t)L.S * 2048) + (k & 31);
-    if (k >= K) { *e2p = INFINITY; return; }
+    float* enp = e2p + 32;                             // |e'| (rounded up): the one-product screen's per-code error scale
+    if (k >= K) { *e2p = INFINITY; *enp = 0.0f; return; }
     double s = 0.0;
     float mx = 0.0f;
     for (int d = 0; d < D; ++d) {
@@ -124,6 +126,7 @@ __global__ void prep_e2_kernel(const float* __restrict__ cb, const float* __rest
     }
     const float e2 = (float)s;
     *e2p = e2;
+    *enp = (float)(sqrt(s) * (1.0 + 1e-6));
     atomicMax(&hdr[0], __float_as_uint(e2));          // non-negative floats order like their bit patterns
     atomicMax(&hdr[1], __float_as_uint(e2));          // Emax^2 (same quantity; kept separate for clarity)
     atomicMax(&hdr[2], __float_as_uint(mx));
@@ -150,7 +153,7 @@ extern "C" int lipvq_nearest_prepare_f32(const float* codebook, void* prep, int 
 // ------------------------------------------------------------------------------------------
 // screening kernel: 8 waves x 32 rows per workgroup (main loop: lq_screen_core, lipvq_screen.h)
 // ------------------------------------------------------------------------------------------
-template <int S, bool DBG>
+template <int S, bool DBG, bool COARSE = false>
 __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
     const float* __restrict__ z, const unsigned char* __restrict__ prep, const float* __restrict__ cb,
     int64_t* __restrict__ idx, float* __restrict__ zq, unsigned long long* __restrict__ usage,
@@ -204,6 +207,10 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
     }
     float frow[16];
     lq_row_factors(fown, lane, frow);
+    // COARSE: the per-row scale of the one-product error bound, (2^-9 + 2^-21)(1 + 2^-10) |z'| f, in the register layout of frow
+    const float zn = COARSE ? LQ_COARSE_CC * lq_sqrt(n2) * fown : 0.0f;
+    float znr[16];
+    lq_row_factors(zn, lane, znr);
 
     float m1[16], m2[16];
     int k1[16];
@@ -223,9 +230,12 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
                 const f16x8 bh = *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 0) * 64 + lane) * 16);
                 const f16x8 bl = *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 1) * 64 + lane) * 16);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl, acc, 0, 0, 0);
+                if constexpr (!COARSE) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl, acc, 0, 0, 0);
+                }
             }
+            const float en = reinterpret_cast<const float*>(tb + S * 2048 + 128)[ln];
             const int code = ct * 32 + ln;
             if (dbg && code < L.Kpad) {
 #pragma unroll
@@ -234,10 +244,13 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
                     if (rr < N) dbg[(size_t)rr * L.Kpad + code] = lq_fma(e2, frow[r], acc[r]) / frow[r];      // back to unscaled units
                 }
             }
-            lq_track_part<0, 16>(acc, e2, frow, code, 0xffffffffu, m1, m2, k1);
+            lq_track_part<0, 16, false, COARSE>(acc, e2, en, frow, znr, code, 0xffffffffu, m1, m2, k1);
         }
     } else {
-        lq_screen_core<S, SCREEN_WAVES * 64, SC::TC, SC::NB, SC::PACK>(ah, al, tiles, L.ntiles, lds, tid, frow, m1, m2, k1);
+        lq_screen_core_rg<S, SCREEN_WAVES * 64, SC::TC, SC::NB, SC::PACK, 1, COARSE>(
+            reinterpret_cast<const f16x8 (&)[1][S]>(ah), reinterpret_cast<const f16x8 (&)[1][S]>(al), tiles, L.ntiles, lds, tid, frow,
+            reinterpret_cast<const float (&)[1][16]>(znr), reinterpret_cast<float (&)[1][16]>(m1), reinterpret_cast<float (&)[1][16]>(m2),
+            reinterpret_cast<int (&)[1][16]>(k1));
     }
     int my_k;
     const float pack_eps = (SC::PACK && !DBG) ? lq_pow2f(lq_pack_bits(L.ntiles) - 23) : 0.0f;
@@ -247,10 +260,12 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
     bool certified;
     // (the debug hook runs with the caller's gamma, which need not bound anything: its uncertified rows get no short list)
     if (SC::PACK && !DBG) {
-        certified = lq_screen_decide<true>(m1, m2, k1, scratch, hdr, n2, fown, gamma, K, D, lane, my_k, dec, pack_eps, keep_mask);
+        certified = lq_screen_decide<true, COARSE>(m1, m2, k1, scratch, hdr, n2, fown, gamma, K, D, lane, my_k, dec, pack_eps, keep_mask,
+                                                   zn, tiles, L.tile_bytes, S);
         lq_screen_emit<true>(dec, certified, true, my_k, row, row < N, amb_count, amb_list, N, K, lane, keep_mask, scratch);
     } else {
-        certified = lq_screen_decide<false>(m1, m2, k1, scratch, hdr, n2, fown, gamma, K, D, lane, my_k, dec, 0.0f);
+        certified = lq_screen_decide<false, COARSE>(m1, m2, k1, scratch, hdr, n2, fown, gamma, K, D, lane, my_k, dec, 0.0f, 0xffffffffu,
+                                                    zn, tiles, L.tile_bytes, S);
         lq_screen_emit<false>(dec, certified, !DBG, my_k, row, row < N, amb_count, amb_list, N, K, lane, keep_mask, scratch);
     }
     if (h == 0 && row < N && certified) idx[row] = (int64_t)my_k;
@@ -839,6 +854,15 @@ extern "C" size_t lipvq_nearest_workspace_bytes(int64_t N) {
     return 64 + lq_lists_bytes(N);    // [0] uncertified-row counter, then the row list, the best-candidate list and the short lists
 }
 
+// One-product ("coarse") or three-product screen.  LIPVQ_SCREEN_MODE=coarse|fine (read per launch; measurement knob --
+// identical results): the default is the shape's measured winner (lq_screen_coarse_default).
+int lq_screen_coarse(int S) {
+    const char* e = getenv("LIPVQ_SCREEN_MODE");
+    if (e && !strcmp(e, "coarse")) return 1;
+    if (e && !strcmp(e, "fine")) return 0;
+    return lq_screen_coarse_default(S);
+}
+
 template <int S>
 static int launch_screen(const float* z, const unsigned char* prep, const float* cb, int64_t* idx, float* zq,
                          int64_t* usage, int* amb_list, int* amb_count, float* dbg, int64_t N, int K, int D,
@@ -848,10 +872,14 @@ static int launch_screen(const float* z, const unsigned char* prep, const float*
     if (lds < (size_t)SCREEN_WAVES * LQ_DECIDE_BYTES) lds = (size_t)SCREEN_WAVES * LQ_DECIDE_BYTES;      // per-wave transpose slices reuse the stages
     const int64_t rows_per_block = SCREEN_WAVES * 32;
     unsigned blocks = (unsigned)((N + rows_per_block - 1) / rows_per_block);
-    auto kfn = dbg ? screen_kernel<S, true> : screen_kernel<S, false>;
-    static LqLdsReserve reserved[2];            // per instantiation and kernel flavour: per-device, thread-safe (lipvq_common.h)
+    // the debug hook takes the arithmetic from the sign of its gamma (negative: the one-product chain, bound factor |gamma|)
+    const bool coarse = dbg ? (gamma < 0.0f) : (lq_screen_coarse(S) != 0);
+    if (gamma < 0.0f) gamma = -gamma;
+    auto kfn = dbg ? (coarse ? screen_kernel<S, true, true> : screen_kernel<S, true, false>)
+                   : (coarse ? screen_kernel<S, false, true> : screen_kernel<S, false, false>);
+    static LqLdsReserve reserved[4];            // per instantiation and kernel flavour: per-device, thread-safe (lipvq_common.h)
     if (lds > 64 * 1024)
-        if (int rc = lipvq_reserve_lds(reserved[dbg ? 1 : 0], (const void*)kfn, lds, "screen")) return rc;
+        if (int rc = lipvq_reserve_lds(reserved[(dbg ? 1 : 0) + (coarse ? 2 : 0)], (const void*)kfn, lds, "screen")) return rc;
     hipLaunchKernelGGL(kfn, dim3(blocks), dim3(SCREEN_WAVES * 64), lds, st, z, prep, cb, idx, zq,
                        (unsigned long long*)usage, amb_list, amb_count, dbg, N, K, D, gamma);
     return check_launch("screen");
