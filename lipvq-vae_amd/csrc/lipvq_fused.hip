@@ -112,6 +112,7 @@ struct TokArgs {
     int64_t N;
     int A, D, K;
     float gamma;
+    int coarse;                  // host side only: the one-product screen instance runs (ze_out is then never NULL)
 };
 
 // T0 = 2 (64 features), T1 = 4 (128 features): the reference's encoder widths (v5:54-59).
@@ -124,7 +125,10 @@ struct TokArgs {
 // them against every codebook fragment it reads: lq_screen_core_rg), WAVES waves per workgroup.  (8, RG = 1) is the round-2
 // kernel; (8, 2) halves the LDS fragment reads, |e'|^2 reads and stage hand-overs per MFMA at two waves per SIMD; (4, 2) is
 // ONE wave per SIMD with the whole 512-register file (the D = 128 instance: its A fragments alone are 64 registers per group).
-template <int S, bool FAST, bool TRAIN, int RG, int WAVES>
+// COARSE (round 3): phase B runs the one-product screen (lq_screen_core_rg<.., COARSE>): a third of the matrix work, lower-bound
+// bookkeeping, 10-40 % of the rows left to the exact kernel with their two or three candidates -- which then needs z_e, so the
+// host always passes a z_e buffer in this mode (a.ze_out).
+template <int S, bool FAST, bool TRAIN, int RG, int WAVES, bool COARSE = false>
 __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
     static_assert(!(FAST && TRAIN), "training uses the parity arithmetic");
     static_assert(RG == 1 || RG == 2, "one or two row groups per wave");
@@ -677,7 +681,17 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
             for (int g_ = 0; g_ < RG; ++g_) load_x(blk + gridDim.x < nblk ? blk + gridDim.x : blk, g_, xqg[g_]);
         }
         constexpr bool PACKF = LQ_PACK_FOR(S) || S > 8;      // (S = 13: 104 registers of A fragments leave no room for an index array)
-        lq_screen_core_rg<S, THREADS, TCF, NBF, PACKF, RG>(ahg, alg, tiles, L.ntiles, stage0, tid, frow, m1g, m2g, k1g);
+        float zng[RG], znrg[RG][16];                       // COARSE: the rows' error scale (lq_track_part), in frow's register layout
+#pragma unroll
+        for (int g_ = 0; g_ < RG; ++g_) {
+            zng[g_] = COARSE ? LQ_COARSE_CC * lq_sqrt(n2g[g_]) * fown : 0.0f;
+            if constexpr (COARSE) lq_row_factors(zng[g_], lane, znrg[g_]);
+            else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) znrg[g_][r] = 0.0f;
+            }
+        }
+        lq_screen_core_rg<S, THREADS, TCF, NBF, PACKF, RG, COARSE>(ahg, alg, tiles, L.ntiles, stage0, tid, frow, znrg, m1g, m2g, k1g);
         LQ_STAMP(4);
         const unsigned keep_mask = PACKF ? ~((1u << lq_pack_bits(L.ntiles)) - 1u) : 0xffffffffu;
         unsigned char* scratch = stage0 + (size_t)wave * LQ_DECIDE_BYTES;
@@ -687,8 +701,9 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
             const int64_t row = row0 + ln;
             int my_k;
             LqDecision dec;
-            bool certified = lq_screen_decide<PACKF>(m1g[g_], m2g[g_], k1g[g_], scratch, hdr, n2g[g_], fown, a.gamma, a.K, a.D, lane,
-                                                     my_k, dec, PACKF ? lq_pow2f(lq_pack_bits(L.ntiles) - 23) : 0.0f, keep_mask);
+            bool certified = lq_screen_decide<PACKF, COARSE>(m1g[g_], m2g[g_], k1g[g_], scratch, hdr, n2g[g_], fown, a.gamma, a.K, a.D, lane,
+                                                             my_k, dec, PACKF ? lq_pow2f(lq_pack_bits(L.ntiles) - 23) : 0.0f, keep_mask,
+                                                             zng[g_], tiles, L.tile_bytes, S);
             const bool row_sane = n2g[g_] >= tiny2;                   // (see fz above; such a row's screen values bound nothing)
             certified = certified && row_sane;
             lq_screen_emit<PACKF>(dec, certified, row_sane, my_k, row, row < a.N, a.amb_count, a.amb_list, a.N, a.K, lane, keep_mask, scratch);
@@ -728,9 +743,9 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
 }
 
 // two waves per SIMD (8 waves, 256 registers each) / one wave per SIMD (4 waves, the whole 512-register file each)
-template <int S, bool FAST, bool TRAIN = false, int RG = 1>
+template <int S, bool FAST, bool TRAIN = false, int RG = 1, bool COARSE = false>
 __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
-    tokenize_body<S, FAST, TRAIN, RG, FUSED_WAVES>(a);
+    tokenize_body<S, FAST, TRAIN, RG, FUSED_WAVES, COARSE>(a);
 }
 template <int S, bool FAST, bool TRAIN, int RG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void tokenize_kernel_w4(TokArgs a) {
@@ -791,7 +806,10 @@ static int launch_tokenize(const TokArgs& a, hipStream_t st) {
     const size_t lds = fused_lds_bytes<S, FAST>(a.A, a.K);
     if (lds > 160 * 1024) return fail(LIPVQ_EUNSUPPORTED, "tokenize: %zu B of LDS needed", lds);
     const TokShape sh = tok_shape<S, FAST, TRAIN>(a.N);
-    static LqLdsReserve reserved[4];            // per instantiation and shape: per-device, thread-safe (lipvq_common.h)
+    static LqLdsReserve reserved[5];            // per instantiation and shape: per-device, thread-safe (lipvq_common.h)
+    if constexpr (!FAST && !TRAIN) {
+        if (a.coarse) return launch_tokenize_as(tokenize_kernel<S, FAST, TRAIN, 1, true>, reserved[4], a, lds, 8, 1, st);
+    }
     if constexpr (!FAST && !TRAIN) {
         if (sh.waves == 4 && sh.rg == 1) return launch_tokenize_as(tokenize_kernel_w4<S, FAST, TRAIN, 1>, reserved[3], a, lds, 4, 1, st);
     }
@@ -864,8 +882,10 @@ __global__ void w2q_pack_kernel(const float* __restrict__ P2, float* __restrict_
 
 extern "C" size_t lipvq_tokenize_workspace_bytes(int64_t N, int D) {
     if (N <= 0 || D <= 0) return 0;
-    // uncertified-row counter, row list, best-candidate list, short lists, then (D = 208) the streamed layer-2 weights
-    return 64 + lq_lists_bytes(N) + sizeof(float) * w2q_floats(D);
+    // uncertified-row counter, row list, best-candidate list, short lists, then (D = 208) the streamed layer-2 weights, then a z_e
+    // scratch [N][D] for the one-product screen's exact stage (used when the caller passes no ze_out; always part of the size, so
+    // that the mode may change between calls)
+    return 64 + lq_lists_bytes(N) + sizeof(float) * w2q_floats(D) + 256 + sizeof(float) * (size_t)N * (size_t)D;
 }
 
 // Fused encode + quantize (reference v5:71-74).  packed: lipvq_mlp3_pack_f32 of the encoder stack
@@ -895,6 +915,13 @@ static int tokenize_impl(const float* x, const float* packed, const void* packed
     // z_e is written only when the caller wants it (training); otherwise the exact kernel recomputes it for the few
     // rows it has to decide (saves a 134 MB write per 524 288-row launch at BASELINE config 2)
     float* ze_buf = ze_out;
+    // the one-product screen (parity instances only): its exact stage reads z_e rows, so one is always written
+    const int coarse = (!packed16 && !pre0) ? lq_screen_coarse(lq_screen_S(D)) : 0;
+    if (coarse && !ze_buf) {
+        size_t off = 64 + lq_lists_bytes(N) + sizeof(float) * w2q_floats(D);
+        off = (off + 255) & ~(size_t)255;
+        ze_buf = reinterpret_cast<float*>(ws + off);
+    }
     hipError_t e = hipMemsetAsync(amb_count, 0, 64, st);
     if (e != hipSuccess) return fail(LIPVQ_EHIP, "tokenize: %s", hipGetErrorString(e));
     float* w2q = nullptr;
@@ -907,7 +934,7 @@ static int tokenize_impl(const float* x, const float* packed, const void* packed
         hipLaunchKernelGGL(w2q_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, packed + PL.oP2, w2q, PL.T2, PL.S2);
     }
     TokArgs a{x, packed, (const unsigned char*)packed16, (const unsigned char*)prep, codebook, idx, zq,
-              (unsigned long long*)usage, ze_buf, amb_count, amb_list, w2q, pre0, pre1, pre2, N, A, D, K, LIPVQ_SCREEN_GAMMA};
+              (unsigned long long*)usage, ze_buf, amb_count, amb_list, w2q, pre0, pre1, pre2, N, A, D, K, LIPVQ_SCREEN_GAMMA, coarse};
     int rc;
     if (pre0) {
         if ((((uintptr_t)pre0 | (uintptr_t)pre1 | (uintptr_t)pre2) & 15) != 0)
@@ -935,7 +962,7 @@ static int tokenize_impl(const float* x, const float* packed, const void* packed
     }
     if (rc) return rc;
     // uncertified rows (count on the device): exact decision, from the stored z_e rows or from x
-    if (ze_out) return lipvq_launch_rows(ze_out, 0, codebook, idx, zq, usage, amb_list, amb_count, N, K, D, st);
+    if (ze_buf) return lipvq_launch_rows(ze_buf, 0, codebook, idx, zq, usage, amb_list, amb_count, N, K, D, st);
     return lipvq_launch_rows_encode(x, raw6, A, codebook, idx, zq, usage, amb_list, amb_count, N, K, D, st);
 }
 

@@ -70,6 +70,33 @@ def test_error_bound_holds(ops):
     assert worst < 1.0 / 4.0, f"screening error reached {worst:.3f} of its bound"
 
 
+def test_coarse_error_bound_holds(ops):
+    """The one-product (hi x hi) screen: |d~ - d| against float64 stays below the bound its certification uses,
+    w(n, k) = (2^-9 + 2^-21) |z'_n| |e'_k| (11-bit operands, Cauchy-Schwarz) + the three-product screen's gamma term -- on every
+    pair, at ordinary, small and large spreads and at every instance width; and it does use a good part of it (the bound is not
+    vacuous).  The debug hook selects the one-product chain through a negative gamma."""
+    worst, used = 0.0, 0.0
+    for seed, (N, K, D, spread) in enumerate([(512, 1024, 64, 1.0), (256, 2048, 128, 1.0), (256, 512, 32, 1.0),
+                                              (128, 1024, 208, 1.0), (512, 1024, 64, 0.2), (512, 1024, 64, 3.0), (300, 700, 100, 1.0)]):
+        z, cb = _case(300 + seed, N, K, D, spread)
+        cbd = dev(cb)
+        prep = ops.nearest_prepare(cbd)
+        idx, zq, dt = ops.nearest_screened(dev(z), cbd, prep, debug_gamma=-GAMMA)
+        dt = dt.cpu().numpy().astype(np.float64)[:, :K]
+        mu = cb.astype(np.float64).mean(0)
+        zc, ec = z.astype(np.float64) - mu, cb.astype(np.float64) - mu
+        e2 = (ec * ec).sum(1)
+        d = e2[None, :] - 2.0 * zc @ ec.T
+        zn = np.sqrt((zc * zc).sum(1))
+        w = (2.0 ** -9 + 2.0 ** -21) * zn[:, None] * np.sqrt(e2)[None, :]
+        bound = w + GAMMA * (e2.max() + 2.0 * zn * np.sqrt(e2.max()))[:, None]
+        ratio = np.abs(dt - d) / bound
+        worst = max(worst, ratio.max())
+        used = max(used, (np.abs(dt - d) / w).max())
+    assert worst < 1.0, f"one-product screening error reached {worst:.3f} of its bound"
+    assert used > 0.02, "the measured error is nowhere near the bound: is the debug hook running the three-product chain?"
+
+
 def test_gamma_extremes_still_exact(ops, oracle):
     """gamma = 0 certifies every row with a positive gap; a huge gamma certifies nothing: same answer."""
     z, cb = _case(9, 2000, 512, 64)
