@@ -21,6 +21,8 @@ only: the BASELINE metric's path) and ``perplexity()``.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -106,6 +108,8 @@ class _ScreenMonitor:
         self.last_fraction = None
 
     def use_screen(self) -> bool:
+        if os.environ.get("LIPVQ_SCREEN_MONITOR", "1") == "0":      # measurement knob: always the screen
+            return True
         if torch.cuda.is_current_stream_capturing():
             return True                                  # a graph capture records one route; no host decisions inside it
         if self._pending is not None:
