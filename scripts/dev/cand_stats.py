@@ -15,7 +15,7 @@ trained_like_(model, A)
 x = torch.randn(N, A, device="cuda")
 model.tokenize(x); torch.cuda.synchronize()
 ws = model._tok_ws.cpu().numpy()
-cnt = int(ws[0]); L = (N + 15) & ~15; cap = N // 8 + 64
+cnt = int(ws[0]); L = (N + 15) & ~15; cap = N + 64      # lq_cand_cap (round 3: every row can have a list)
 cl = ws[16 + 2 * L: 16 + 2 * L + 16 * cap].reshape(cap, 16)[:min(cnt, cap)]
 n0, n1 = cl[:, 0], cl[:, 8]
 full = (n0 == -1) | (n1 == -1)
