@@ -680,7 +680,9 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
 #pragma unroll
             for (int g_ = 0; g_ < RG; ++g_) load_x(blk + gridDim.x < nblk ? blk + gridDim.x : blk, g_, xqg[g_]);
         }
-        constexpr bool PACKF = LQ_PACK_FOR(S) || S > 8;      // (S = 13: 104 registers of A fragments leave no room for an index array)
+        // (S = 13: 104 registers of A fragments leave no room for an index array; COARSE: the packed index's perturbation is far
+        // below the one-product margin at any S)
+        constexpr bool PACKF = LQ_PACK_FOR(S) || S > 8 || COARSE;
         float zng[RG], znrg[RG][16];                       // COARSE: the rows' error scale (lq_track_part), in frow's register layout
 #pragma unroll
         for (int g_ = 0; g_ < RG; ++g_) {

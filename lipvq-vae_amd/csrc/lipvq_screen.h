@@ -130,7 +130,8 @@ __device__ __forceinline__ void lq_track_one(float v, int id, unsigned keep_mask
 // a LOWER BOUND of the code's distance: the hi-only product is off by at most w(n, k) = (2^-9 + 2^-21) |z'_n| |e'_k| (each operand
 // rounded to 11 significant bits; Cauchy-Schwarz over the row), so  L = d~ - w <= d  for every code, and  L + 2 w >= d  for the
 // winner (lq_screen_decide).  en = |e'_k| of the lane's code (rounded up, from the tile), znr[r] = (2^-9 + 2^-21)(1 + 2^-10) |z'_n| f
-// of the register's row: one more fma per element.
+// of the register's row.  The chain is SEEDED with |e'|^2 f - w (one fma per element when the tile starts) instead of starting from
+// zero and adding the terms afterwards (two): the accumulator is the booked value.
 template <int LO, int HI, bool PACK = false, bool COARSE = false>
 __device__ __forceinline__ void lq_track_part(const f32x16& acc, float e2, float en, const float (&frow)[16], const float (&znr)[16],
                                               int id, unsigned keep_mask, float (&m1)[16], float (&m2)[16], int (&k1)[16]) {
@@ -140,8 +141,8 @@ __device__ __forceinline__ void lq_track_part(const f32x16& acc, float e2, float
 #endif
 #pragma unroll
     for (int r = LO; r < HI; ++r) {
-        float v = LQ_E2_TERM(e2, frow[r], acc[r]);
-        if constexpr (COARSE) v = lq_fma(-znr[r], en, v);
+        // COARSE: the chain started from |e'|^2 f - w (lq_screen_core_rg seeds it), the accumulator IS the booked value
+        const float v = COARSE ? acc[r] : LQ_E2_TERM(e2, frow[r], acc[r]);
         lq_track_one<PACK>(v, id, keep_mask, m1[r], m2[r], k1[r]);
     }
 }
@@ -161,8 +162,7 @@ __device__ __forceinline__ void lq_track_after_mfma(int j, const f32x16& acc, fl
 #pragma unroll
     for (int r = 0; r < 16; ++r)
         if (r >= lo && r < hi) {
-            float v = LQ_E2_TERM(e2, frow[r], acc[r]);
-            if constexpr (COARSE) v = lq_fma(-znr[r], en, v);
+            const float v = COARSE ? acc[r] : LQ_E2_TERM(e2, frow[r], acc[r]);
             lq_track_one<PACK>(v, id, keep_mask, m1[r], m2[r], k1[r]);
         }
 }
@@ -323,12 +323,12 @@ __device__ __forceinline__ void lq_screen_core_rg(const f16x8 (&ah)[RG][S], cons
             const float en_prev = (((c + par) & 1) == 0) ? enB : enA;
             const int code_prev = (((c + par) & 1) == 0) ? codeB : codeA;
             if (s == 0) {
+                const float e2c = e2q[(c + par) & 1];
+                const float enc = enq[(c + par) & 1];
 #pragma unroll
                 for (int g_ = 0; g_ < RG; ++g_)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[g_][r] = 0.0f;
-                const float e2c = e2q[(c + par) & 1];
-                const float enc = enq[(c + par) & 1];
+                    for (int r = 0; r < 16; ++r) acc[g_][r] = COARSE ? lq_fma(-znr[g_][r], enc, e2c * frow[r]) : 0.0f;
                 int code = PACK ? (st * C::TC + c) : (st * C::TC + c) * 32 + ln;
                 if constexpr (PACK) asm volatile("" : "+v"(code));      // the tile index lives in a vector register (lq_track_one)
                 if (((c + par) & 1) == 0) { e2A = e2c; enA = enc; codeA = code; } else { e2B = e2c; enB = enc; codeB = code; }
@@ -725,7 +725,9 @@ int lq_screen_coarse(int S);
 // workspace of the screened routes: [64 B: counter] [row list: lq_list_ints(N) ints] [best-candidate list: the same]
 // [short lists: 16 ints x lq_cand_cap(N)]
 __host__ __device__ static inline size_t lq_list_ints(int64_t N) { return ((size_t)N + 15) & ~(size_t)15; }
-__host__ __device__ static inline size_t lq_lists_bytes(int64_t N) { return sizeof(int) * (2 * lq_list_ints(N) + 16 * lq_cand_cap(N)); }
+// ... [slots the list kernel left to the scanning kernel: lq_list_ints(N) ints; their count is the header's second int]
+__host__ __device__ static inline size_t lq_lists_bytes(int64_t N) { return sizeof(int) * (3 * lq_list_ints(N) + 16 * lq_cand_cap(N)); }
+__host__ __device__ static inline size_t lq_slot2_offset_ints(int64_t N) { return 2 * lq_list_ints(N) + 16 * lq_cand_cap(N); }
 
 // exact decision for listed rows (lipvq_screen.hip); z_by_slot: z is a compact [count][D] buffer
 // dist: LIPVQ_DIST_NORM (v5:43-46: torch.norm's order, roots compared) or LIPVQ_DIST_SQSUM (vq:57-63: pow(2).sum's order)

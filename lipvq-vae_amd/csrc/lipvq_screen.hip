@@ -161,6 +161,9 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
     float gamma) {
     using SC = StandaloneScreen<S>;
     using C = ScreenCfg<S, SC::TC>;
+    // PACK bookkeeping: where the three-product screen needs it (S <= 4), and ALWAYS for the one-product screen -- its margin
+    // (2^-9 of the cross term) dwarfs the 2^(TB-23) the packed tile index perturbs a value by
+    constexpr bool PK = SC::PACK || COARSE;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const PrepLayout L = prep_layout(K, D);
     const unsigned* hdr = reinterpret_cast<const unsigned*>(prep);
@@ -222,9 +225,10 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
         for (int ct = 0; ct < L.ntiles; ++ct) {
             const unsigned char* tb = tiles + (size_t)ct * C::TILE_BYTES;
             const float e2 = reinterpret_cast<const float*>(tb + S * 2048)[ln];
+            const float en = reinterpret_cast<const float*>(tb + S * 2048 + 128)[ln];
             f32x16 acc;                                   // same arithmetic as lq_screen_core: chain from zero, |e'|^2 f added last
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll                                            // (COARSE: chain seeded with |e'|^2 f - w, the booked lower bound)
+            for (int r = 0; r < 16; ++r) acc[r] = COARSE ? lq_fma(-znr[r], en, e2 * frow[r]) : 0.0f;
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 const f16x8 bh = *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 0) * 64 + lane) * 16);
@@ -235,31 +239,31 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl, acc, 0, 0, 0);
                 }
             }
-            const float en = reinterpret_cast<const float*>(tb + S * 2048 + 128)[ln];
             const int code = ct * 32 + ln;
             if (dbg && code < L.Kpad) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int64_t rr = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (rr < N) dbg[(size_t)rr * L.Kpad + code] = lq_fma(e2, frow[r], acc[r]) / frow[r];      // back to unscaled units
+                    // back to unscaled units; COARSE: the bound term is taken out again -- the test wants d~ itself
+                    if (rr < N) dbg[(size_t)rr * L.Kpad + code] = (COARSE ? lq_fma(znr[r], en, acc[r]) : lq_fma(e2, frow[r], acc[r])) / frow[r];
                 }
             }
             lq_track_part<0, 16, false, COARSE>(acc, e2, en, frow, znr, code, 0xffffffffu, m1, m2, k1);
         }
     } else {
-        lq_screen_core_rg<S, SCREEN_WAVES * 64, SC::TC, SC::NB, SC::PACK, 1, COARSE>(
+        lq_screen_core_rg<S, SCREEN_WAVES * 64, SC::TC, SC::NB, PK, 1, COARSE>(
             reinterpret_cast<const f16x8 (&)[1][S]>(ah), reinterpret_cast<const f16x8 (&)[1][S]>(al), tiles, L.ntiles, lds, tid, frow,
             reinterpret_cast<const float (&)[1][16]>(znr), reinterpret_cast<float (&)[1][16]>(m1), reinterpret_cast<float (&)[1][16]>(m2),
             reinterpret_cast<int (&)[1][16]>(k1));
     }
     int my_k;
-    const float pack_eps = (SC::PACK && !DBG) ? lq_pow2f(lq_pack_bits(L.ntiles) - 23) : 0.0f;
-    const unsigned keep_mask = (SC::PACK && !DBG) ? ~((1u << lq_pack_bits(L.ntiles)) - 1u) : 0xffffffffu;
+    const float pack_eps = (PK && !DBG) ? lq_pow2f(lq_pack_bits(L.ntiles) - 23) : 0.0f;
+    const unsigned keep_mask = (PK && !DBG) ? ~((1u << lq_pack_bits(L.ntiles)) - 1u) : 0xffffffffu;
     unsigned char* scratch = lds + (size_t)wave * LQ_DECIDE_BYTES;
     LqDecision dec;
     bool certified;
     // (the debug hook runs with the caller's gamma, which need not bound anything: its uncertified rows get no short list)
-    if (SC::PACK && !DBG) {
+    if (PK && !DBG) {
         certified = lq_screen_decide<true, COARSE>(m1, m2, k1, scratch, hdr, n2, fown, gamma, K, D, lane, my_k, dec, pack_eps, keep_mask,
                                                    zn, tiles, L.tile_bytes, S);
         lq_screen_emit<true>(dec, certified, true, my_k, row, row < N, amb_count, amb_list, N, K, lane, keep_mask, scratch);
@@ -503,7 +507,8 @@ template <int DCH, int DIST = LIPVQ_DIST_NORM>
 __global__ __launch_bounds__(256) void nearest_rows_kernel(
     const float* __restrict__ z, const float* __restrict__ cb, int64_t* __restrict__ idx, float* __restrict__ zq,
     unsigned long long* __restrict__ usage, const int* __restrict__ row_list, const int* __restrict__ row_count,
-    int K, int z_by_slot, int count_direct, const int* __restrict__ seed_list, const int* __restrict__ cand_list, size_t cand_cap) {
+    int K, int z_by_slot, int count_direct, const int* __restrict__ seed_list, const int* __restrict__ cand_list, size_t cand_cap,
+    const int* __restrict__ slot_list) {
     constexpr int D = DCH * 8;
     constexpr int RB = 4, SL = 64;               // rows per workgroup, code slices per row
     __shared__ float s_v[RB][SL];
@@ -513,7 +518,8 @@ __global__ __launch_bounds__(256) void nearest_rows_kernel(
   for (int base = blockIdx.x * RB; base < count; base += gridDim.x * RB) {
     const int slot = base + r;
     const bool valid = slot < count;
-    const int cslot = valid ? slot : count - 1;
+    // slot_list (round 3): the slots nearest_lists_kernel left over (lane masks, full scans); `count` is then their number
+    const int cslot = slot_list ? slot_list[valid ? slot : count - 1] : (valid ? slot : count - 1);
     const int64_t row = row_list ? row_list[cslot] : cslot;
     float zr[D];
     {
@@ -542,6 +548,90 @@ __global__ __launch_bounds__(256) void nearest_rows_kernel(
     }
     __syncthreads();
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Listed rows with SHORT candidate lists, at rate (round 3).  nearest_rows_kernel above gives a row to 64 threads that each
+// load the whole row and one candidate -- right for the fraction of a percent of rows the three-product screen leaves, 64-fold
+// redundant for the 10-40 % the one-product screen leaves (cfg3: 103 k rows, 926 us).  Here ONE WAVE owns a row per iteration and
+// its eight 8-lane groups score eight candidates at once: lane j of a group keeps torch's accumulator j (features j, j + 8, ...:
+// the k-ordered fma chain of lq_sqdist8; for the sum rule the four accumulators of lane column j, lq_sqdist32), the eight
+// partials are added in lane order, roots compared, lower code among equal values.  Rows without a short list (lane masks, no
+// list) are appended to slot2_list for the scanning kernel.
+// ------------------------------------------------------------------------------------------
+template <int DCH, int DIST>
+__global__ __launch_bounds__(256) void nearest_lists_kernel(
+    const float* __restrict__ z, const float* __restrict__ cb, int64_t* __restrict__ idx, float* __restrict__ zq,
+    unsigned long long* __restrict__ usage, const int* __restrict__ row_list, const int* __restrict__ row_count,
+    int K, int z_by_slot, const int* __restrict__ cand_list, size_t cand_cap, int* __restrict__ slot2_list,
+    int* __restrict__ slot2_count) {
+    constexpr int D = DCH * 8;
+    const int lane = threadIdx.x & 63, g = lane >> 3, j = lane & 7;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    const int count = *row_count;
+    for (int slot = wid; slot < count; slot += nw) {
+        int n0 = -1, n1 = -1;
+        const int* cl = cand_list + (size_t)((size_t)slot < cand_cap ? slot : 0) * 16;
+        if ((size_t)slot < cand_cap) { n0 = cl[0]; n1 = cl[8]; }
+        const bool shortlist = n0 >= 0 && n1 >= 0 && n0 + n1 >= 1 && n0 <= LQ_CAND_MAX && n1 <= LQ_CAND_MAX;   // wave-uniform
+        if (!shortlist) {
+            if (lane == 0) slot2_list[atomicAdd(slot2_count, 1)] = slot;
+            continue;
+        }
+        const int64_t row = row_list[slot];
+        const float* zr = z + (size_t)(z_by_slot ? (int64_t)slot : row) * D;
+        const int nc = n0 + n1;
+        float best_v = INFINITY;
+        int best_k = 0x7fffffff;
+        for (int c0 = 0; c0 < nc; c0 += 8) {
+            const int ci = c0 + g;
+            const bool live = ci < nc;
+            int code = live ? (ci < n0 ? cl[2 + ci] : cl[10 + (ci - n0)]) : cl[n0 > 0 ? 2 : 10];
+            code = (code >= 0 && code < K) ? code : 0;                       // (lq_screen_emit lists valid codes only)
+            const float* c = cb + (size_t)code * D;
+            float s;
+            if constexpr (DIST == LIPVQ_DIST_NORM) {
+                float a = 0.0f;
+#pragma unroll
+                for (int i = 0; i < DCH; ++i) { const float d = zr[8 * i + j] - c[8 * i + j]; a = lq_fma(d, d, a); }
+                s = __shfl(a, 8 * g, 64);
+#pragma unroll
+                for (int l = 1; l < 8; ++l) s = s + __shfl(a, 8 * g + l, 64);
+                s = lq_sqrt(s);
+            } else {
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < DCH; ++i) {
+                    const int q = (i < (DCH / 4) * 4) ? (i & 3) : 0;
+                    const float d = zr[8 * i + j] - c[8 * i + j];
+                    acc[q] = acc[q] + d * d;
+                }
+                const float vl = ((acc[0] + acc[1]) + acc[2]) + acc[3];
+                s = __shfl(vl, 8 * g, 64);
+#pragma unroll
+                for (int l = 1; l < 8; ++l) s = s + __shfl(vl, 8 * g + l, 64);
+            }
+            const float v = (live && s == s) ? s : INFINITY;                 // a NaN never wins
+            const int kk = live ? code : 0x7fffffff;
+            if (v < best_v || (v == best_v && kk < best_k)) { best_v = v; best_k = kk; }
+        }
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) {
+            const float ov = __shfl_xor(best_v, off, 64);
+            const int ok = __shfl_xor(best_k, off, 64);
+            if (ov < best_v || (ov == best_v && ok < best_k)) { best_v = ov; best_k = ok; }
+        }
+        if (best_k < 0 || best_k >= K) best_k = (cl[n0 > 0 ? 2 : 10] >= 0 && cl[n0 > 0 ? 2 : 10] < K) ? cl[n0 > 0 ? 2 : 10] : 0;   // every value NaN
+        if (lane == 0) {
+            idx[row] = (int64_t)best_k;
+            if (usage) atomicAdd(&usage[best_k], 1ull);
+        }
+        if (zq) {
+            const float4* src = reinterpret_cast<const float4*>(cb + (size_t)best_k * D);
+            float4* dst = reinterpret_cast<float4*>(zq + (size_t)row * D);
+            for (int v4 = lane; v4 < D / 4; v4 += 64) dst[v4] = src[v4];
+        }
+    }
 }
 
 // Any latent width (no compile-time D, rows not necessarily 16-byte aligned): the same decision for a listed row -- short lists,
@@ -896,10 +986,24 @@ static int launch_rows_t(const float* z, int z_by_slot, const float* cb, int64_t
     // the count lives on the device: a bounded grid strides over however many rows were listed
     int64_t blocks = (N + 3) / 4;
     if (blocks > 4096) blocks = 4096;
+    if (amb_list) {
+        // rows with short candidate lists (95 % and more of the listed rows): one wave per row, eight candidates at a time;
+        // what it leaves (lane masks, no list) goes through slot2 to the scanning kernel
+        int* slot2_list = const_cast<int*>(amb_list) + lq_slot2_offset_ints(N);
+        int* slot2_count = const_cast<int*>(amb_count) + 1;                 // zeroed with the header by the caller's memset
+        int64_t lb = (N + 3) / 4;
+        if (lb > 2048) lb = 2048;
+        hipLaunchKernelGGL((nearest_lists_kernel<DCH, DIST>), dim3((unsigned)lb), dim3(256), 0, st, z, cb, idx, zq,
+                           (unsigned long long*)usage, amb_list, amb_count, K, z_by_slot, amb_list + 2 * lq_list_ints(N),
+                           lq_cand_cap(N), slot2_list, slot2_count);
+        if (int rc = check_launch("nearest_lists")) return rc;
+        hipLaunchKernelGGL((nearest_rows_kernel<DCH, DIST>), dim3((unsigned)blocks), dim3(256), 0, st, z, cb, idx, zq,
+                           (unsigned long long*)usage, amb_list, slot2_count, K, z_by_slot, 0, amb_list + lq_list_ints(N),
+                           amb_list + 2 * lq_list_ints(N), lq_cand_cap(N), slot2_list);
+        return check_launch("nearest_rows");
+    }
     hipLaunchKernelGGL((nearest_rows_kernel<DCH, DIST>), dim3((unsigned)blocks), dim3(256), 0, st, z, cb, idx, zq,
-                       (unsigned long long*)usage, amb_list, amb_count, K, z_by_slot, amb_list ? 0 : (int)N,
-                       amb_list ? amb_list + lq_list_ints(N) : nullptr, amb_list ? amb_list + 2 * lq_list_ints(N) : nullptr,
-                       amb_list ? lq_cand_cap(N) : (size_t)0);
+                       (unsigned long long*)usage, nullptr, nullptr, K, z_by_slot, (int)N, nullptr, nullptr, (size_t)0, nullptr);
     return check_launch("nearest_rows");
 }
 
