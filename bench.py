@@ -462,7 +462,10 @@ def main():
     algo_flop = enc_flop + dist_flop
     # floor 1 (instruction mix): the kernel executes the encoder on the fp32 matrix pipe (157.3 TF/s) and the distance
     # screen on the fp16 matrix pipe with 3 split products per algorithmic product (2500 TF/s dense)
-    t_floor = enc_flop / (PEAK_FP32_TFLOPS * 1e12) + 3.0 * dist_flop / (PEAK_F16_MFMA_TFLOPS * 1e12)
+    # (the one-product screen -- wide latents against large codebooks, e.g. cfg3 -- executes ONE product: no credit then)
+    coarse = bool(ops.screen_is_coarse(K, D)) and ops.tokenize_supported(A, 64, model.hidden_dim, D, K)
+    split = 1.0 if coarse else 3.0
+    t_floor = enc_flop / (PEAK_FP32_TFLOPS * 1e12) + split * dist_flop / (PEAK_F16_MFMA_TFLOPS * 1e12)
     # floor 2 (strict): algorithmic distance flops at the fp16 pipe, no credit for the 3x split
     t_floor_alg = enc_flop / (PEAK_FP32_TFLOPS * 1e12) + dist_flop / (PEAK_F16_MFMA_TFLOPS * 1e12)
     peak_blend = algo_flop / t_floor / 1e12
@@ -486,15 +489,20 @@ def main():
                                   f"buckets of {M} steps, overlapped with the following steps",
                    "global_usage_rows_last_step": usage_rows},
         "roofline": {"bound": "mfma",
-                     "kernel": ("tokenize_kernel (+ nearest_rows_encode_kernel for uncertified rows)" if fused else
+                     "kernel": (("tokenize_kernel, one-product screen (+ nearest_lists_kernel / nearest_rows_kernel: the exact stage over "
+                                 "the rows it leaves)" if coarse else
+                                 "tokenize_kernel (+ nearest_rows_encode_kernel for uncertified rows)") if fused else
                                 "mlp3_wg_kernel + screen_kernel (+ nearest_rows_kernel for uncertified rows)"),
+                     "screen": "one fp16 product per algorithmic product (11-bit operands, lower-bound bookkeeping)" if coarse else
+                               "three fp16 products per algorithmic product (22-bit operands)",
                      "achieved": achieved, "peak": peak_blend, "unit": "TFLOP/s", "frac": achieved / peak_blend,
                      "frac_algorithmic_floor": (t_floor_alg * 1e3) / tok_ms if tok_ms > 0 else 0.0,
                      "traffic": None, "traffic_source": None, "traffic_detail": None,
                      "ms_per_launch": tok_ms, "algorithmic_flop_per_launch": algo_flop,
                      "floor_ms": t_floor * 1e3, "floor_algorithmic_ms": t_floor_alg * 1e3,
-                     "peak_note": "frac: algorithmic flop / (encoder flop / 157.3 TF/s fp32 MFMA + 3 x distance flop / 2500 TF/s "
-                                  "fp16 MFMA); frac_algorithmic_floor: the same without the 3x (no credit for the split)",
+                     "peak_note": f"frac: algorithmic flop / (encoder flop / 157.3 TF/s fp32 MFMA + {split:g} x distance flop / 2500 TF/s "
+                                  "fp16 MFMA: the products the screen executes); frac_algorithmic_floor: the same with 1 x (no credit "
+                                  "for a split)",
                      "algorithmic_bytes_per_launch": float(N) * (4 * A + 4 * D + 8),
                      # SURVEY 8d asks for both fractions: the same launch against the HBM roof (it is compute bound by a wide margin)
                      "hbm_frac": (float(N) * (4 * A + 4 * D + 8) / (tok_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if tok_ms > 0 else 0.0,
@@ -558,7 +566,7 @@ def main():
         # denominators for the two side readings (the same pricing as `roofline`: fp32 work at the fp32 MFMA peak, the distance
         # screen's three split products at the fp16 MFMA peak; HBM is not the binding roof for either)
         dec_flop = 2.0 * N * (D * 64 + 64 * 128 + 128 * A)
-        ff_floor = (enc_flop + dec_flop) / (PEAK_FP32_TFLOPS * 1e12) + 3.0 * dist_flop / (PEAK_F16_MFMA_TFLOPS * 1e12)
+        ff_floor = (enc_flop + dec_flop) / (PEAK_FP32_TFLOPS * 1e12) + split * dist_flop / (PEAK_F16_MFMA_TFLOPS * 1e12)
         # training: forward + backward-data (the encoder's input gradient is not needed: its first layer drops out) + weight
         # gradients = 3x the two stacks' forward flops minus that one layer
         ts_floor = (3.0 * (enc_flop + dec_flop) - 2.0 * N * A * 64) / (PEAK_FP32_TFLOPS * 1e12) + 3.0 * dist_flop / (PEAK_F16_MFMA_TFLOPS * 1e12)
@@ -576,8 +584,8 @@ def main():
     if args.traffic == "live" and world == 1 and not args.metric_only:
         try:
             traffic, traffic_src, traffic_detail = measure_traffic_live(
-                args.workload, ("tokenize_kernel", "nearest_rows") if ops.tokenize_supported(A, 64, model.hidden_dim, D, K)
-                else ("mlp3_wg_kernel", "screen_kernel", "nearest_rows"))
+                args.workload, ("tokenize_kernel", "nearest_rows", "nearest_lists") if ops.tokenize_supported(A, 64, model.hidden_dim, D, K)
+                else ("mlp3_wg_kernel", "mlp3_lds_kernel", "screen_kernel", "nearest_rows", "nearest_lists"))
         except Exception as e:  # noqa: BLE001 -- the profiler is optional equipment; the committed measurement stands in
             traffic_src = f"live measurement failed ({type(e).__name__}: {str(e)[:200]}); "
     tfile = ROOT / "profiles" / "hbm_traffic.json"           # PMC-derived bytes per launch (separate rocprofv3 --pmc runs)

@@ -106,6 +106,12 @@ int lipvq_nearest_prepare_f32(const float* codebook, void* prep, int K, int D, v
 int lipvq_nearest_screened_supported(int K, int D);          /* 1 for any D in 1 ... 208 (widths other than 32 / 64 / 128 / 208 run
                                                                * the next larger instance on zero-padded columns) */
 size_t lipvq_nearest_workspace_bytes(int64_t N);
+/* The screen comes in two strengths with identical results: three fp16 products per algorithmic product (22-bit operands; a
+ * fraction of a percent of the rows left to the exact kernel) or ONE (11-bit operands, a third of the matrix work, lower-bound
+ * bookkeeping; 10-40 % of the rows left to the exact stage with their two or three candidates each).  The library picks per
+ * shape (wide latents against large codebooks take the one-product screen: K >= 4096 and D > 64); this query tells which one
+ * a call with (K, D) would run now (environment LIPVQ_SCREEN_MODE=coarse|fine overrides: a measurement knob). */
+int lipvq_screen_is_coarse(int K, int D);
 /* idx / zq / usage exactly as lipvq_nearest_f32.  After the call the first int of `workspace`
  * holds how many rows were decided by the exact kernel (the rest were certified by the screen). */
 int lipvq_nearest_screened_f32(const float* z, const float* codebook, const void* prep, int64_t* idx, float* zq,

@@ -45,6 +45,7 @@ SIGNATURES = {
     "lipvq_nearest_prepare_f32": (_i, [_vp, _vp, _i, _i, _vp]),
     "lipvq_nearest_screened_supported": (_i, [_i, _i]),
     "lipvq_nearest_workspace_bytes": (_sz, [_i64]),
+    "lipvq_screen_is_coarse": (_i, [_i, _i]),
     "lipvq_nearest_screened_f32": (_i, [_vp] * 7 + [_i64, _i, _i, _vp]),
     "lipvq_nearest_rows_f32": (_i, [_vp] * 5 + [_i64, _i, _i, _vp]),
     "lipvq_vq_nearest_screened_f32": (_i, [_vp] * 7 + [_i64, _i, _i, _vp]),

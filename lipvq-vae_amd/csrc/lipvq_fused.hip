@@ -918,7 +918,7 @@ static int tokenize_impl(const float* x, const float* packed, const void* packed
     // rows it has to decide (saves a 134 MB write per 524 288-row launch at BASELINE config 2)
     float* ze_buf = ze_out;
     // the one-product screen (parity instances only): its exact stage reads z_e rows, so one is always written
-    const int coarse = (!packed16 && !pre0) ? lq_screen_coarse(lq_screen_S(D)) : 0;
+    const int coarse = (!packed16 && !pre0) ? lq_screen_coarse(lq_screen_S(D), K) : 0;
     if (coarse && !ze_buf) {
         size_t off = 64 + lq_lists_bytes(N) + sizeof(float) * w2q_floats(D);
         off = (off + 255) & ~(size_t)255;

@@ -718,9 +718,13 @@ __device__ __forceinline__ void lq_screen_gather(const float* __restrict__ cb, f
     }
 }
 
-// which screen a shape runs by default (measured, profiles/r03_*; LIPVQ_SCREEN_MODE overrides per launch: lipvq_screen.hip)
-static inline int lq_screen_coarse_default(int S) { (void)S; return 0; }
-int lq_screen_coarse(int S);
+// Which screen a shape runs by default (LIPVQ_SCREEN_MODE=coarse|fine overrides per launch: lipvq_screen.hip).  Measured on one box
+// (profiles/r03_j_coarse_ab.txt), whole step incl. the exact stage: K = 8192, D = 128 (BASELINE config 3): 3.01 -> 1.90 ms with the
+// one-product screen; K = 1024: D = 64 0.47 -> 0.51 ms, D = 208 1.19 -> 1.23 ms.  The one-product screen trades two thirds of the
+// matrix work for an exact stage over 10-40 % of the rows: it pays where the screen IS the launch -- wide latents against large
+// codebooks.
+static inline int lq_screen_coarse_default(int S, int K) { return (S >= 8 && K >= 4096) ? 1 : 0; }
+int lq_screen_coarse(int S, int K);
 
 // workspace of the screened routes: [64 B: counter] [row list: lq_list_ints(N) ints] [best-candidate list: the same]
 // [short lists: 16 ints x lq_cand_cap(N)]

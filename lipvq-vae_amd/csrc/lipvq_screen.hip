@@ -946,11 +946,18 @@ extern "C" size_t lipvq_nearest_workspace_bytes(int64_t N) {
 
 // One-product ("coarse") or three-product screen.  LIPVQ_SCREEN_MODE=coarse|fine (read per launch; measurement knob --
 // identical results): the default is the shape's measured winner (lq_screen_coarse_default).
-int lq_screen_coarse(int S) {
+int lq_screen_coarse(int S, int K) {
     const char* e = getenv("LIPVQ_SCREEN_MODE");
     if (e && !strcmp(e, "coarse")) return 1;
     if (e && !strcmp(e, "fine")) return 0;
-    return lq_screen_coarse_default(S);
+    return lq_screen_coarse_default(S, K);
+}
+
+// 1 if the screened routes (lipvq_nearest_screened_f32, lipvq_vq_nearest_screened_f32, lipvq_tokenize_f32) would run the
+// one-product screen for this shape right now (callers that budget the exact stage -- the host-side screen monitor, the bench's
+// roofline -- ask; results do not depend on it)
+extern "C" int lipvq_screen_is_coarse(int K, int D) {
+    return (K > 0 && lq_screen_S(D)) ? lq_screen_coarse(lq_screen_S(D), K) : 0;
 }
 
 template <int S>
@@ -963,7 +970,7 @@ static int launch_screen(const float* z, const unsigned char* prep, const float*
     const int64_t rows_per_block = SCREEN_WAVES * 32;
     unsigned blocks = (unsigned)((N + rows_per_block - 1) / rows_per_block);
     // the debug hook takes the arithmetic from the sign of its gamma (negative: the one-product chain, bound factor |gamma|)
-    const bool coarse = dbg ? (gamma < 0.0f) : (lq_screen_coarse(S) != 0);
+    const bool coarse = dbg ? (gamma < 0.0f) : (lq_screen_coarse(S, K) != 0);
     if (gamma < 0.0f) gamma = -gamma;
     auto kfn = dbg ? (coarse ? screen_kernel<S, true, true> : screen_kernel<S, true, false>)
                    : (coarse ? screen_kernel<S, false, true> : screen_kernel<S, false, false>);

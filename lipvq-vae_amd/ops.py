@@ -322,6 +322,11 @@ def nearest_screen_supported(K: int, D: int) -> bool:
     return bool(lib.lipvq_nearest_screened_supported(int(K), int(D)))
 
 
+def screen_is_coarse(K: int, D: int) -> bool:
+    """True if the screened routes would run the one-product screen for this shape now (lipvq_screen_is_coarse)."""
+    return bool(lib.lipvq_screen_is_coarse(int(K), int(D)))
+
+
 def nearest_prepare(codebook: torch.Tensor) -> PreparedCodebook:
     codebook = _chk(codebook, "codebook")
     K, D = codebook.shape

@@ -99,7 +99,8 @@ class _ScreenMonitor:
     (``event.query()``: never a wait).  A fraction above ``THRESHOLD`` routes the following ``PROBE_EVERY`` large-batch calls
     through the all-pairs kernel, then the screen is tried again."""
 
-    THRESHOLD = 1.0 / 16.0        # beyond N/8 listed rows the exact kernel has no candidate lists left (lq_cand_cap)
+    THRESHOLD = 1.0 / 16.0        # three-product screen: a fraction of a percent is normal
+    THRESHOLD_COARSE = 0.6        # one-product screen: 10-40 % of the rows go to the exact stage BY DESIGN (lipvq_screen_is_coarse)
     PROBE_EVERY = 16
 
     def __init__(self):
@@ -113,25 +114,25 @@ class _ScreenMonitor:
         if torch.cuda.is_current_stream_capturing():
             return True                                  # a graph capture records one route; no host decisions inside it
         if self._pending is not None:
-            ev, host, n = self._pending
+            ev, host, n, coarse = self._pending
             if ev.query():
                 self.last_fraction = float(host[0]) / max(1, n)
                 self._pending = None
-                if self.last_fraction > self.THRESHOLD:
+                if self.last_fraction > (self.THRESHOLD_COARSE if coarse else self.THRESHOLD):
                     self.bypass_calls = self.PROBE_EVERY
         if self.bypass_calls > 0:
             self.bypass_calls -= 1
             return False
         return True
 
-    def record(self, ws: torch.Tensor, n: int) -> None:
+    def record(self, ws: torch.Tensor, n: int, coarse: bool = False) -> None:
         if torch.cuda.is_current_stream_capturing() or self._pending is not None:
             return
         host = torch.empty(1, dtype=torch.int32, pin_memory=True)
         host.copy_(ws[:1], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self._pending = (ev, host, int(n))
+        self._pending = (ev, host, int(n), bool(coarse))
 
 
 class _TokenizerBase(nn.Module):
@@ -249,7 +250,7 @@ class LLFQVAE_V4(_TokenizerBase):
             prep = self._cb_cache.get((self.quantizer.codebook,), lambda: ops.nearest_prepare(cb))
             idx, zq, ws = ops.nearest_screened(z_e, cb, prep, usage=usage, return_workspace=True)
             self.last_exact_rows = ws
-            self._screen_monitor.record(ws, z_e.shape[0])
+            self._screen_monitor.record(ws, z_e.shape[0], ops.screen_is_coarse(cb.shape[0], cb.shape[1]))
             return idx, zq
         self.last_exact_rows = None
         idx, zq, _ = ops.nearest(z_e, cb, DIST_NORM, usage=usage)
@@ -280,12 +281,12 @@ class LLFQVAE_V4(_TokenizerBase):
             idx, zq, ze, ws, pre = ops.tokenize(x, packed, (w0, b0, w1, b1, Wn, b2), cb, prep, usage=usage, workspace=self._tok_ws,
                                                 want_pre=True)
             self.last_exact_rows = ws
-            self._screen_monitor.record(ws, x.shape[0])
+            self._screen_monitor.record(ws, x.shape[0])          # (training instances run the three-product screen)
             return idx, zq, ze, pre
         idx, zq, ze, ws = ops.tokenize(x, packed, (w0, b0, w1, b1, Wn, b2), cb, prep, usage=usage, want_ze=want_ze,
                                        workspace=self._tok_ws, packed16=packed16)
         self.last_exact_rows = ws
-        self._screen_monitor.record(ws, x.shape[0])
+        self._screen_monitor.record(ws, x.shape[0], (not fast) and ops.screen_is_coarse(self.num_codes, self.latent_dim))
         return idx, zq, ze
 
     def fused_shape(self) -> bool:
@@ -381,7 +382,7 @@ class VQVAE(_TokenizerBase):
                 prep = self._cb_cache.get((self.embedding.weight,), lambda: ops.nearest_prepare(cb))
                 idx, zq, ws = ops.nearest_screened(z_e, cb, prep, usage=usage, return_workspace=True, dist=DIST_SQSUM)
                 self.last_exact_rows = ws
-                self._screen_monitor.record(ws, n)
+                self._screen_monitor.record(ws, n, ops.screen_is_coarse(K, D))
                 return idx, zq
         self.last_exact_rows = None
         idx, zq, _ = ops.nearest(z_e, cb, DIST_SQSUM, usage=usage)
