@@ -597,8 +597,17 @@ __device__ __forceinline__ void lq_screen_emit(const LqDecision& dec, bool certi
     if (__builtin_amdgcn_ballot_w64(need) == 0ull) return;              // wave-uniform: most waves have nothing to list
     const int ln = lane & 31, h = lane >> 5;
     int slot = 0;
+    {
+        // ONE atomic per wave for all its listed rows (the one-product screen lists several rows per wave and block; a slot per
+        // row by its own atomicAdd serialised them on one address): the first listed lane reserves popcount slots
+        const unsigned long long lm = __builtin_amdgcn_ballot_w64(h == 0 && need);        // (bits 0 .. 31 only)
+        const int leader = __builtin_ctzll(lm);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(amb_count, __builtin_popcountll(lm));
+        base = __shfl(base, leader, 64);
+        slot = base + __builtin_popcountll(lm & ((1ull << lane) - 1ull));
+    }
     if (h == 0 && need) {
-        slot = atomicAdd(amb_count, 1);
         amb_list[slot] = (int)row;
         amb_list[lq_list_ints(N) + slot] = my_k;                        // the screen's best candidate: bounds the exact scan
     }
@@ -719,11 +728,12 @@ __device__ __forceinline__ void lq_screen_gather(const float* __restrict__ cb, f
 }
 
 // Which screen a shape runs by default (LIPVQ_SCREEN_MODE=coarse|fine overrides per launch: lipvq_screen.hip).  Measured on one box
-// (profiles/r03_j_coarse_ab.txt), whole step incl. the exact stage: K = 8192, D = 128 (BASELINE config 3): 3.01 -> 1.90 ms with the
-// one-product screen; K = 1024: D = 64 0.47 -> 0.51 ms, D = 208 1.19 -> 1.23 ms.  The one-product screen trades two thirds of the
-// matrix work for an exact stage over 10-40 % of the rows: it pays where the screen IS the launch -- wide latents against large
-// codebooks.
-static inline int lq_screen_coarse_default(int S, int K) { return (S >= 8 && K >= 4096) ? 1 : 0; }
+// (profiles/r03_k_coarse_sweep.txt: 524 288 rows, whole call incl. the exact stage, one-product / three-product time):
+//   D =  64: K = 1024 1.07, 4096 0.83, 8192 0.72      D = 128: K = 1024 0.97, 2048 0.84, 4096 0.71, 8192 0.63 (BASELINE config 3)
+//   D = 208: K = 1024 0.98, 4096 0.69, 8192 0.60
+// The one-product screen trades two thirds of the matrix work for an exact stage over 10-20 % of the rows: it pays where the
+// screen IS the launch -- large codebooks, the more so the wider the latent.
+static inline int lq_screen_coarse_default(int S, int K) { return (K >= 4096 || (S >= 8 && K >= 2048)) ? 1 : 0; }
 int lq_screen_coarse(int S, int K);
 
 // workspace of the screened routes: [64 B: counter] [row list: lq_list_ints(N) ints] [best-candidate list: the same]
