@@ -228,12 +228,32 @@ class GraphedTokenizerStep:
                     if st and "step" in st:
                         st["step"] = torch.as_tensor(float(st["step"]), dtype=torch.float32, device=prm.device)
         self.warmup_steps = int(warmup)
+        # The warm-up steps are REAL training steps (they have to be: they make the one-time work happen); construction must not
+        # train the model, though (round 2's did: two extra updates on the example batch).  Parameters and optimizer state are
+        # snapshotted here and put back IN PLACE after the warm-up -- in place, because the capture below records the state
+        # tensors' addresses and must find them allocated: state created by the warm-up is zeroed (= a fresh AdamW), state that
+        # came with `optimizer_state` gets its values back.  Replay k then equals eager step k.
+        params = list(vq_vae_model.parameters())
+        saved_params = [p.detach().clone() for p in params]
+        saved_state = {id(p): {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in self.vq_optimizer.state.get(p, {}).items()}
+                       for p in params}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(self.warmup_steps):
                 self._eager_step()
         torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for p, sp in zip(params, saved_params):
+                p.copy_(sp)
+                for k, v in self.vq_optimizer.state.get(p, {}).items():
+                    if torch.is_tensor(v):
+                        old = saved_state[id(p)].get(k)
+                        if old is not None:
+                            v.copy_(old)
+                        else:
+                            v.zero_()
         torch.cuda.synchronize()
         self.model.invalidate_caches()
         self.graph = torch.cuda.CUDAGraph()

@@ -1,7 +1,8 @@
 """Dev tool (GPU): randomized soak of the quantizer routes against the all-pairs exact kernel (no screen, no lists):
-fused tokenize, stand-alone screened nearest, exact rows -- random shapes, seeds and adversarial rows (duplicated codes,
-bisector near-ties incl. codes congruent mod 32, rows sitting on codes).  python scripts/dev/soak.py [seconds]"""
-import sys, time
+fused tokenize, stand-alone screened nearest, exact rows -- random shapes (round 3: any latent width 1 ... 208), seeds and
+adversarial rows (duplicated codes, bisector near-ties incl. codes congruent mod 32, rows sitting on codes), both distance
+rules, and per case a random screen (three-product / one-product) and fused-kernel shape.  python scripts/dev/soak.py [seconds]"""
+import os, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import numpy as np, torch
@@ -14,8 +15,11 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(12345)
 t0, cases, rows, unc = time.time(), 0, 0, 0
 while time.time() - t0 < budget:
-    D = int(rng.choice([32, 64, 128, 208]))
-    K = int(rng.choice([37, 256, 1000, 1024, 2048, 8192])) if D != 208 else int(rng.choice([128, 1024]))
+    D = int(rng.choice([32, 64, 128, 208])) if rng.random() < 0.6 else int(rng.integers(1, 209))
+    K = int(rng.choice([37, 256, 1000, 1024, 2048, 8192])) if D <= 128 else int(rng.choice([128, 1024, 4096]))
+    os.environ["LIPVQ_SCREEN_MODE"] = str(rng.choice(["fine", "coarse"]))              # read per launch by the library
+    os.environ["LIPVQ_TOK_SHAPE"] = str(rng.choice(["w8rg1", "w8rg1", "w8rg2", "w4rg2", "w4rg1"]))
+    os.environ["LIPVQ_SCREEN_MONITOR"] = "0"
     A = int(rng.choice([3, 7, 12]))
     N = int(rng.choice([1, 33, 257, 2049, 4100, 30000, 100001]))
     torch.manual_seed(int(rng.integers(1 << 30)))
@@ -36,18 +40,21 @@ while time.time() - t0 < budget:
         ib = torch.where(same_lane, (ia + 32 * torch.randint(1, max(2, K // 32), (m,), device="cuda")) % K, ib)
         t = (0.5 + (torch.randint(-3, 4, (m, 1), device="cuda").float()) * 1e-8)
         ze = ze.clone(); ze[:m] = cb[ia] * t + cb[ib] * (1 - t); ze[m:m + max(1, m // 4)] = cb[ia[:max(1, m // 4)]]
-    ref, _, _ = ops.nearest(ze, cb)
-    if ops.nearest_screen_supported(K, D):
-        idx_s, zq_s, ws = ops.nearest_screened(ze, cb, ops.nearest_prepare(cb), return_workspace=True)
-        assert torch.equal(idx_s, ref), ("screened", N, A, D, K)
-        assert torch.equal(zq_s, cb[ref])
-        unc += int(ws[0])
-    idx_r, _ = ops.nearest_rows(ze, cb)
-    assert torch.equal(idx_r, ref), ("rows", N, A, D, K)
+    for dist in (0, 1):                                     # the norm rule (LLFQ) and the sum rule (plain VQVAE)
+        ref, _, _ = ops.nearest(ze, cb, dist=dist)
+        tag = (N, A, D, K, dist, os.environ["LIPVQ_SCREEN_MODE"])
+        if ops.nearest_screen_supported(K, D):
+            idx_s, zq_s, ws = ops.nearest_screened(ze, cb, ops.nearest_prepare(cb), return_workspace=True, dist=dist)
+            assert torch.equal(idx_s, ref), ("screened",) + tag
+            assert torch.equal(zq_s, cb[ref])
+            unc += int(ws[0])
+        if N <= (30000 if D in (32, 64, 128, 208) else 2100):          # (other widths: every row is a full scan from L2)
+            idx_r, _ = ops.nearest_rows(ze, cb, dist=dist)
+            assert torch.equal(idx_r, ref), ("rows",) + tag
     if ops.tokenize_supported(A, 64, 128, D, K):
         idx_f, zq_f = model.tokenize(x, count_usage=False)
         ref_f, _, _ = ops.nearest(model.encode(x), cb)
-        assert torch.equal(idx_f, ref_f), ("fused", N, A, D, K)
+        assert torch.equal(idx_f, ref_f), ("fused", N, A, D, K, os.environ["LIPVQ_SCREEN_MODE"], os.environ["LIPVQ_TOK_SHAPE"])
         assert torch.equal(zq_f, cb[ref_f])
     cases += 1; rows += N
 print(f"soak: {cases} random cases, {rows} rows, {unc} uncertified rows through the lists -- every route equals the all-pairs exact kernel")

@@ -162,10 +162,12 @@ def test_graphed_training_step_after_eager_training_equals_eager_trajectory(orac
     twin.invalidate_caches()
     tw = VQTokenizerTrainer(twin)
     tw.vq_optimizer.load_state_dict(copy.deepcopy(tr.vq_optimizer.state_dict()))     # (load_state_dict would alias the moments)
-    # capture: two warm-up steps on xs[3] (real steps), then the graph
+    # capture: two warm-up steps on xs[3] (real steps whose effect on parameters and optimizer state is undone: constructing the
+    # graphed step must not train the model), then the graph
+    before = {k: v.clone() for k, v in model.state_dict().items()}
     g = GraphedTokenizerStep(model, xs[3], optimizer_state=tr.vq_optimizer.state_dict(), warmup=2)
-    for _ in range(2):
-        tw.train_on_actions(xs[3])
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, before[k]), f"construction changed {k}"
     losses = []
     for i in range(4, 7):
         _, loss = g.step(xs[i])
