@@ -809,7 +809,7 @@ static int launch_tokenize(const TokArgs& a, hipStream_t st) {
     if (lds > 160 * 1024) return fail(LIPVQ_EUNSUPPORTED, "tokenize: %zu B of LDS needed", lds);
     const TokShape sh = tok_shape<S, FAST, TRAIN>(a.N);
     static LqLdsReserve reserved[5];            // per instantiation and shape: per-device, thread-safe (lipvq_common.h)
-    if constexpr (!FAST && !TRAIN) {
+    if constexpr (!FAST) {                      // (parity and training instances; the training forward writes z_e anyway)
         if (a.coarse) return launch_tokenize_as(tokenize_kernel<S, FAST, TRAIN, 1, true>, reserved[4], a, lds, 8, 1, st);
     }
     if constexpr (!FAST && !TRAIN) {
@@ -918,7 +918,7 @@ static int tokenize_impl(const float* x, const float* packed, const void* packed
     // rows it has to decide (saves a 134 MB write per 524 288-row launch at BASELINE config 2)
     float* ze_buf = ze_out;
     // the one-product screen (parity instances only): its exact stage reads z_e rows, so one is always written
-    const int coarse = (!packed16 && !pre0) ? lq_screen_coarse(lq_screen_S(D), K) : 0;
+    const int coarse = !packed16 ? lq_screen_coarse(lq_screen_S(D), K) : 0;
     if (coarse && !ze_buf) {
         size_t off = 64 + lq_lists_bytes(N) + sizeof(float) * w2q_floats(D);
         off = (off + 255) & ~(size_t)255;

@@ -281,7 +281,7 @@ class LLFQVAE_V4(_TokenizerBase):
             idx, zq, ze, ws, pre = ops.tokenize(x, packed, (w0, b0, w1, b1, Wn, b2), cb, prep, usage=usage, workspace=self._tok_ws,
                                                 want_pre=True)
             self.last_exact_rows = ws
-            self._screen_monitor.record(ws, x.shape[0])          # (training instances run the three-product screen)
+            self._screen_monitor.record(ws, x.shape[0], ops.screen_is_coarse(self.num_codes, self.latent_dim))
             return idx, zq, ze, pre
         idx, zq, ze, ws = ops.tokenize(x, packed, (w0, b0, w1, b1, Wn, b2), cb, prep, usage=usage, want_ze=want_ze,
                                        workspace=self._tok_ws, packed16=packed16)

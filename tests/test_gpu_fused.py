@@ -146,13 +146,16 @@ def test_no_grad_forward_takes_the_fused_launch_and_agrees(oracle):
     assert np.array_equal(z_b.cpu().numpy(), f["z_q"]) and abs(loss_b.item() - f["loss"]) <= 1e-5 * abs(f["loss"])
 
 
+@pytest.mark.parametrize("screen", ["fine", "coarse"])
 @pytest.mark.parametrize("N,A,D,K", [(5000, 7, 64, 1024), (2100, 12, 208, 1024), (3000, 7, 32, 256), (2500, 12, 128, 1000)])
-def test_training_forward_launch_equals_unfused(oracle, N, A, D, K):
+def test_training_forward_launch_equals_unfused(oracle, monkeypatch, N, A, D, K, screen):
     """lipvq_tokenize_train_f32 (encoder + quantizer + everything autograd saves, one launch) against lipvq_mlp3_f32 with saved
     pre-activations + the stand-alone quantizer: z_e, the three pre-activations, indices and z_q bit for bit; and the module's
     gradients at a batch that takes this route equal the ones the unfused route gives."""
     from lipvq_vae_amd import ops
     from lipvq_vae_amd.autograd import _ENC_ACTS
+    monkeypatch.setenv("LIPVQ_SCREEN_MODE", screen)          # both screens exist for the training instance too
+    monkeypatch.setenv("LIPVQ_SCREEN_MONITOR", "0")
     p, model = _setup(N + D, A, D, K, oracle)
     x = O.make_inputs(N + 1, N, A)
     xt = torch.from_numpy(x).cuda()
