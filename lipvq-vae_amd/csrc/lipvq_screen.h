@@ -443,7 +443,7 @@ struct LqDecision {
 
 // COARSE (one-product screen): the booked values are lower bounds L = d~ - w (lq_track_part); `zn` is this lane's row's
 // (2^-9 + 2^-21)(1 + 2^-10) |z'| f and `tiles` / `tile_bytes` / `S` locate the winner's |e'| -- its upper bound is L + 2 w.
-#define LQ_COARSE_CC 1.9550323486328125e-03f      /* (2^-9 + 2^-21)(1 + 2^-10), rounded up */
+#define LQ_COARSE_CC 1.9555099e-03f               /* (2^-9 + 2^-21)(1 + 2^-10) = 1.95550965e-3, rounded up */
 template <bool PACK = false, bool COARSE = false>
 __device__ __forceinline__ bool lq_screen_decide(const float (&m1)[16], const float (&m2)[16], const int (&k1)[16],
                                                  unsigned char* wave_lds /* LQ_DECIDE_BYTES, this wave only */,
