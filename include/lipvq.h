@@ -145,7 +145,9 @@ int lipvq_screen_debug_f32(const float* z, const float* codebook, const void* pr
  * its 112 KB of Lipschitz-layer weights are streamed through LDS), A <= 64.  raw6 = host array of the six device pointers {W0, b0, W1, b1,
  * W2 (normalised), b2}: the exact kernel re-encodes the few uncertified rows from x with them, so z_e is written to
  * HBM only when ze_out is given.  After the call the first int of `workspace` holds the number of rows decided by the
- * exact kernel. */
+ * exact kernel.  Shapes that run the one-product screen (lipvq_screen_is_coarse) leave 10-20 % of the rows to the exact stage,
+ * which then reads z_e rows: z_e is written to ze_out if given, else to a scratch inside the workspace -- which is why
+ * lipvq_tokenize_workspace_bytes(N, D) always includes N x D floats (plus 72 bytes of row / candidate lists per row). */
 int lipvq_tokenize_supported(int A, int J0, int J1, int D, int K);
 int lipvq_tokenize_fast_supported(int A, int J0, int J1, int D, int K);      /* lipvq_tokenize_fast_f32: D in {32, 64, 128} */
 size_t lipvq_tokenize_workspace_bytes(int64_t N, int D);
