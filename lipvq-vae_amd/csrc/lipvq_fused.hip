@@ -213,7 +213,8 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
     __syncthreads();
 
     const unsigned* hdr = reinterpret_cast<const unsigned*>(a.prep);
-    const unsigned char* tiles = a.prep + L.o_tiles;
+    const unsigned char* tiles = a.prep + (COARSE ? L.o_tiles_hi : L.o_tiles);     // (the one-product screen stages hi-only tiles)
+    const size_t tile_bytes = COARSE ? L.tile_bytes_hi : L.tile_bytes;
     // Scale of the fp16 split.  The stand-alone screen scales every latent row by its own power of two (block floating point,
     // lipvq_screen.h: it must cope with latents of any magnitude).  Here z_e is a sigmoid output, so |z_e - mu| <= 1 + max|mu|
     // =: Bz for EVERY row, and ONE power of two fz (Bz fz in [2^13, 2^14)) serves the whole launch: the split happens tile by
@@ -705,7 +706,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
             LqDecision dec;
             bool certified = lq_screen_decide<PACKF, COARSE>(m1g[g_], m2g[g_], k1g[g_], scratch, hdr, n2g[g_], fown, a.gamma, a.K, a.D, lane,
                                                              my_k, dec, PACKF ? lq_pow2f(lq_pack_bits(L.ntiles) - 23) : 0.0f, keep_mask,
-                                                             zng[g_], tiles, L.tile_bytes, S);
+                                                             zng[g_], tiles, tile_bytes, ScreenCfg<S, TCF, COARSE>::FRAG_BYTES);
             const bool row_sane = n2g[g_] >= tiny2;                   // (see fz above; such a row's screen values bound nothing)
             certified = certified && row_sane;
             lq_screen_emit<PACKF>(dec, certified, row_sane, my_k, row, row < a.N, a.amb_count, a.amb_list, a.N, a.K, lane, keep_mask, scratch);

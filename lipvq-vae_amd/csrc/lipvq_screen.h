@@ -18,6 +18,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 struct PrepLayout {
     int S, Dpad, Kpad, ntiles;
     size_t o_hdr, o_mu, o_tiles, tile_bytes, total;
+    size_t o_tiles_hi, tile_bytes_hi;      // the one-product screen's tiles: hi fragments only (half the bytes to stage)
 };
 
 // k-steps (of 16 columns) of the screening instance that serves a D-column latent: the instances are 2, 4, 8 and 13 k-steps
@@ -39,7 +40,9 @@ __host__ __device__ static inline PrepLayout prep_layout(int K, int D) {
     L.o_tiles = L.o_mu + sizeof(float) * (size_t)L.Dpad;
     L.o_tiles = (L.o_tiles + 255) & ~(size_t)255;
     L.tile_bytes = (size_t)L.S * 2048 + 256;    // S steps x {hi,lo} x 32 codes x 2 halves x 16 B, then 32 x |e'|^2, then 32 x |e'| (rounded up)
-    L.total = L.o_tiles + (size_t)L.ntiles * L.tile_bytes;
+    L.o_tiles_hi = (L.o_tiles + (size_t)L.ntiles * L.tile_bytes + 255) & ~(size_t)255;
+    L.tile_bytes_hi = (size_t)L.S * 1024 + 256;    // S steps x 32 codes x 2 halves x 16 B of hi fragments, then 32 x |e'|^2, 32 x |e'|
+    L.total = L.o_tiles_hi + (size_t)L.ntiles * L.tile_bytes_hi;
     return L;
 }
 
@@ -68,9 +71,10 @@ constexpr int screen_default_tc(int S) { return (S <= 4) ? LQ_OPT_TC : (S <= 8) 
 constexpr int screen_default_tc(int S) { return (S <= 2) ? 8 : (S <= 4) ? 4 : (S <= 8) ? 2 : 1; }
 #endif
 
-template <int S, int TC_ = screen_default_tc(S)>
+template <int S, int TC_ = screen_default_tc(S), bool COARSE = false>
 struct ScreenCfg {
-    static constexpr int TILE_BYTES = S * 2048 + 256;
+    static constexpr int FRAG_BYTES = COARSE ? S * 1024 : S * 2048;            // one tile's fragments (hi only / hi and lo per k-step)
+    static constexpr int TILE_BYTES = FRAG_BYTES + 256;
     static constexpr int TC = TC_;                                              // tiles per stage (divides 8)
     static constexpr int STAGE_BYTES = TC * TILE_BYTES;
     static constexpr int STAGE_VEC = STAGE_BYTES / 16;
@@ -208,7 +212,7 @@ __device__ __forceinline__ void lq_screen_core_rg(const f16x8 (&ah)[RG][S], cons
                                                   unsigned char* stage0, int tid, const float (&frow)[16],
                                                   const float (&znr)[RG][16],
                                                   float (&m1)[RG][16], float (&m2)[RG][16], int (&k1)[RG][16]) {
-    using C = ScreenCfg<S, TC_>;
+    using C = ScreenCfg<S, TC_, COARSE>;
     static_assert(NB >= 2 && NB <= 4, "ring of 2..4 stage buffers");
     constexpr int NW = NT / 64;
     constexpr int CHUNKS = (C::STAGE_BYTES + 1023) / 1024;          // 1 KiB = one wave-instruction of the LDS-DMA
@@ -259,7 +263,8 @@ __device__ __forceinline__ void lq_screen_core_rg(const f16x8 (&ah)[RG][S], cons
 #endif
     };
     auto frag = [&](const unsigned char* tb, int s, int hl) {
-        return *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + hl) * 64 + lane) * 16);
+        return COARSE ? *reinterpret_cast<const f16x8*>(tb + ((size_t)s * 64 + lane) * 16)          // hi-only tiles
+                      : *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + hl) * 64 + lane) * 16);
     };
     lq_wg_barrier();                              // earlier users of the stage buffers (previous row block) are done
     // prologue: stages 0 .. PD-1 in flight, stage 0 landed
@@ -291,8 +296,8 @@ __device__ __forceinline__ void lq_screen_core_rg(const f16x8 (&ah)[RG][S], cons
         fh[g] = frag(stage0, g, 0);
         if constexpr (!COARSE) fl[g] = frag(stage0, g, 1);
     }
-    e2q[0] = reinterpret_cast<const float*>(stage0 + S * 2048)[ln];
-    if constexpr (COARSE) enq[0] = reinterpret_cast<const float*>(stage0 + S * 2048 + 128)[ln];
+    e2q[0] = reinterpret_cast<const float*>(stage0 + C::FRAG_BYTES)[ln];
+    if constexpr (COARSE) enq[0] = reinterpret_cast<const float*>(stage0 + C::FRAG_BYTES + 128)[ln];
     static_assert(FD <= S, "prologue reads stay in tile 0");
 #endif
     int buf = 0;                                  // ring position of stage st
@@ -347,8 +352,8 @@ __device__ __forceinline__ void lq_screen_core_rg(const f16x8 (&ah)[RG][S], cons
                 fh[(g1 + so) % FR] = frag(tb, gg % S, 0);
                 if constexpr (!COARSE) fl[(g1 + so) % FR] = frag(tb, gg % S, 1);
                 if (gg % S == 0) {
-                    e2q[(g1 / S + par) & 1] = reinterpret_cast<const float*>(tb + S * 2048)[ln];   // g1 / S >= TC: next stage
-                    if constexpr (COARSE) enq[(g1 / S + par) & 1] = reinterpret_cast<const float*>(tb + S * 2048 + 128)[ln];
+                    e2q[(g1 / S + par) & 1] = reinterpret_cast<const float*>(tb + C::FRAG_BYTES)[ln];   // g1 / S >= TC: next stage
+                    if constexpr (COARSE) enq[(g1 / S + par) & 1] = reinterpret_cast<const float*>(tb + C::FRAG_BYTES + 128)[ln];
                 }
             }
 #endif
@@ -442,7 +447,7 @@ struct LqDecision {
 };
 
 // COARSE (one-product screen): the booked values are lower bounds L = d~ - w (lq_track_part); `zn` is this lane's row's
-// (2^-9 + 2^-21)(1 + 2^-10) |z'| f and `tiles` / `tile_bytes` / `S` locate the winner's |e'| -- its upper bound is L + 2 w.
+// (2^-9 + 2^-21)(1 + 2^-10) |z'| f and `tiles` / `tile_bytes` / `frag_bytes` locate the winner's |e'| (the hi-only tiles) -- its upper bound is L + 2 w.
 #define LQ_COARSE_CC 1.9555099e-03f               /* (2^-9 + 2^-21)(1 + 2^-10) = 1.95550965e-3, rounded up */
 template <bool PACK = false, bool COARSE = false>
 __device__ __forceinline__ bool lq_screen_decide(const float (&m1)[16], const float (&m2)[16], const int (&k1)[16],
@@ -450,7 +455,7 @@ __device__ __forceinline__ bool lq_screen_decide(const float (&m1)[16], const fl
                                                  const unsigned* hdr, float n2, float fown, float gamma, int K, int D,
                                                  int lane, int& my_k, LqDecision& dec, float pack_eps = 0.0f,
                                                  unsigned keep_mask = 0xffffffffu, float zn = 0.0f,
-                                                 const unsigned char* tiles = nullptr, size_t tile_bytes = 0, int S = 0) {
+                                                 const unsigned char* tiles = nullptr, size_t tile_bytes = 0, int frag_bytes = 0) {
     constexpr int TS = LQ_DECIDE_STRIDE;
     const int ln = lane & 31, h = lane >> 5;
     float* tv = reinterpret_cast<float*>(wave_lds);           // [32 rows][TS], reused by the passes
@@ -546,7 +551,7 @@ __device__ __forceinline__ bool lq_screen_decide(const float (&m1)[16], const fl
     float w2 = 0.0f;
     if constexpr (COARSE) {
         const int bkc = (bk >= 0 && bk < K) ? bk : 0;
-        const float en = reinterpret_cast<const float*>(tiles + (size_t)(bkc >> 5) * tile_bytes + (size_t)S * 2048 + 128)[bkc & 31];
+        const float en = reinterpret_cast<const float*>(tiles + (size_t)(bkc >> 5) * tile_bytes + (size_t)frag_bytes + 128)[bkc & 31];
         w2 = 2.0f * zn * en;
         w2 = lq_fma(w2, 9.5367431640625e-07f, w2);          // (1 + 2^-20): the product's own rounding, generously
     }

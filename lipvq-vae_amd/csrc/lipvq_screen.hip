@@ -106,6 +106,16 @@ __global__ void prep_frag_kernel(const float* __restrict__ cb, const float* __re
     }
     *reinterpret_cast<f16x8*>(t + (((size_t)s * 2 + 0) * 64 + h * 32 + c) * 16) = hi;   // lane = h*32 + c
     *reinterpret_cast<f16x8*>(t + (((size_t)s * 2 + 1) * 64 + h * 32 + c) * 16) = lo;
+    // the one-product screen's copy: hi fragments only, then the same |e'|^2 and |e'| (written by prep_e2_kernel, earlier in the
+    // stream; the pad codes' value from just above)
+    unsigned char* th = tiles + (L.o_tiles_hi - L.o_tiles) + (size_t)(k >> 5) * L.tile_bytes_hi;
+    *reinterpret_cast<f16x8*>(th + ((size_t)s * 64 + h * 32 + c) * 16) = hi;
+    if (s == 0 && h == 0) {
+        const float* src = reinterpret_cast<const float*>(t + (size_t)L.S * 2048);
+        float* dst = reinterpret_cast<float*>(th + (size_t)L.S * 1024);
+        dst[c] = src[c];
+        dst[32 + c] = src[32 + c];
+    }
 }
 
 // one thread per code: |e'|^2 (double), statistics for the error bound
@@ -160,7 +170,7 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
     int* __restrict__ amb_list, int* __restrict__ amb_count, float* __restrict__ dbg, int64_t N, int K, int D,
     float gamma) {
     using SC = StandaloneScreen<S>;
-    using C = ScreenCfg<S, SC::TC>;
+    using C = ScreenCfg<S, SC::TC, COARSE>;
     // PACK bookkeeping: where the three-product screen needs it (S <= 4), and ALWAYS for the one-product screen -- its margin
     // (2^-9 of the cross term) dwarfs the 2^(TB-23) the packed tile index perturbs a value by
     constexpr bool PK = SC::PACK || COARSE;
@@ -168,7 +178,8 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
     const PrepLayout L = prep_layout(K, D);
     const unsigned* hdr = reinterpret_cast<const unsigned*>(prep);
     const float* mu = reinterpret_cast<const float*>(prep + L.o_mu);
-    const unsigned char* tiles = prep + L.o_tiles;
+    const unsigned char* tiles = prep + (COARSE ? L.o_tiles_hi : L.o_tiles);       // (the one-product screen stages hi-only tiles)
+    const size_t tile_bytes = COARSE ? L.tile_bytes_hi : L.tile_bytes;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ln = lane & 31, h = lane >> 5;
@@ -224,15 +235,16 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
         // test hook: plain loop straight from global memory, dumping every approximate distance
         for (int ct = 0; ct < L.ntiles; ++ct) {
             const unsigned char* tb = tiles + (size_t)ct * C::TILE_BYTES;
-            const float e2 = reinterpret_cast<const float*>(tb + S * 2048)[ln];
-            const float en = reinterpret_cast<const float*>(tb + S * 2048 + 128)[ln];
+            const float e2 = reinterpret_cast<const float*>(tb + C::FRAG_BYTES)[ln];
+            const float en = reinterpret_cast<const float*>(tb + C::FRAG_BYTES + 128)[ln];
             f32x16 acc;                                   // same arithmetic as lq_screen_core: chain from zero, |e'|^2 f added last
 #pragma unroll                                            // (COARSE: chain seeded with |e'|^2 f - w, the booked lower bound)
             for (int r = 0; r < 16; ++r) acc[r] = COARSE ? lq_fma(-znr[r], en, e2 * frow[r]) : 0.0f;
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                const f16x8 bh = *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 0) * 64 + lane) * 16);
-                const f16x8 bl = *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 1) * 64 + lane) * 16);
+                const f16x8 bh = COARSE ? *reinterpret_cast<const f16x8*>(tb + ((size_t)s * 64 + lane) * 16)
+                                        : *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 0) * 64 + lane) * 16);
+                const f16x8 bl = COARSE ? bh : *reinterpret_cast<const f16x8*>(tb + (((size_t)s * 2 + 1) * 64 + lane) * 16);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh, acc, 0, 0, 0);
                 if constexpr (!COARSE) {
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh, acc, 0, 0, 0);
@@ -265,11 +277,11 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
     // (the debug hook runs with the caller's gamma, which need not bound anything: its uncertified rows get no short list)
     if (PK && !DBG) {
         certified = lq_screen_decide<true, COARSE>(m1, m2, k1, scratch, hdr, n2, fown, gamma, K, D, lane, my_k, dec, pack_eps, keep_mask,
-                                                   zn, tiles, L.tile_bytes, S);
+                                                   zn, tiles, tile_bytes, C::FRAG_BYTES);
         lq_screen_emit<true>(dec, certified, true, my_k, row, row < N, amb_count, amb_list, N, K, lane, keep_mask, scratch);
     } else {
         certified = lq_screen_decide<false, COARSE>(m1, m2, k1, scratch, hdr, n2, fown, gamma, K, D, lane, my_k, dec, 0.0f, 0xffffffffu,
-                                                    zn, tiles, L.tile_bytes, S);
+                                                    zn, tiles, tile_bytes, C::FRAG_BYTES);
         lq_screen_emit<false>(dec, certified, !DBG, my_k, row, row < N, amb_count, amb_list, N, K, lane, keep_mask, scratch);
     }
     if (h == 0 && row < N && certified) idx[row] = (int64_t)my_k;
