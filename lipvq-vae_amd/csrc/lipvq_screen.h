@@ -733,9 +733,9 @@ __device__ __forceinline__ void lq_screen_gather(const float* __restrict__ cb, f
 }
 
 // Which screen a shape runs by default (LIPVQ_SCREEN_MODE=coarse|fine overrides per launch: lipvq_screen.hip).  Measured on one box
-// (profiles/r03_k_coarse_sweep.txt: 524 288 rows, whole call incl. the exact stage, one-product / three-product time):
-//   D =  64: K = 1024 1.07, 4096 0.83, 8192 0.72      D = 128: K = 1024 0.97, 2048 0.84, 4096 0.71, 8192 0.63 (BASELINE config 3)
-//   D = 208: K = 1024 0.98, 4096 0.69, 8192 0.60
+// (profiles/r03_o_coarse_sweep_hi_only_tiles.txt: 524 288 rows, whole call incl. the exact stage, one-product / three-product time):
+//   D =  64: K = 1024 1.09, 4096 0.80, 8192 0.69      D = 128: K = 1024 0.95, 2048 0.81, 4096 0.68, 8192 0.60 (BASELINE config 3)
+//   D = 208: K = 1024 0.99, 4096 0.66, 8192 0.56
 // The one-product screen trades two thirds of the matrix work for an exact stage over 10-20 % of the rows: it pays where the
 // screen IS the launch -- large codebooks, the more so the wider the latent.
 static inline int lq_screen_coarse_default(int S, int K) { return (K >= 4096 || (S >= 8 && K >= 2048)) ? 1 : 0; }
