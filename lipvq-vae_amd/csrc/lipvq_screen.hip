@@ -568,8 +568,9 @@ __global__ __launch_bounds__(256) void nearest_rows_kernel(
 // redundant for the 10-40 % the one-product screen leaves (cfg3: 103 k rows, 926 us).  Here ONE WAVE owns a row per iteration and
 // its eight 8-lane groups score eight candidates at once: lane j of a group keeps torch's accumulator j (features j, j + 8, ...:
 // the k-ordered fma chain of lq_sqdist8; for the sum rule the four accumulators of lane column j, lq_sqdist32), the eight
-// partials are added in lane order, roots compared, lower code among equal values.  Rows without a short list (lane masks, no
-// list) are appended to slot2_list for the scanning kernel.
+// partials are added in lane order, roots compared, lower code among equal values.  Lane-mask rows (4 % of the one-product
+// screen's rows; popcount(mask) x K/32 candidates) take the same loop; rows with no list at all (n = -1: a meaningless screen) are
+// appended to slot2_list for the scanning kernel.
 // ------------------------------------------------------------------------------------------
 template <int DCH, int DIST>
 __global__ __launch_bounds__(256) void nearest_lists_kernel(
@@ -586,19 +587,33 @@ __global__ __launch_bounds__(256) void nearest_lists_kernel(
         const int* cl = cand_list + (size_t)((size_t)slot < cand_cap ? slot : 0) * 16;
         if ((size_t)slot < cand_cap) { n0 = cl[0]; n1 = cl[8]; }
         const bool shortlist = n0 >= 0 && n1 >= 0 && n0 + n1 >= 1 && n0 <= LQ_CAND_MAX && n1 <= LQ_CAND_MAX;   // wave-uniform
-        if (!shortlist) {
-            if (lane == 0) slot2_list[atomicAdd(slot2_count, 1)] = slot;
+        // lane masks (some lane's second minimum may be within the margin, or a part listed more than LQ_CAND_MAX codes): every
+        // code congruent to a flagged lane mod 32 is a candidate -- popcount(mask) x K/32 of them, eight at a time like a short list
+        const bool lanescan = !shortlist && n0 != -1 && n1 != -1 && (n0 == -2 || n1 == -2 || n0 > LQ_CAND_MAX || n1 > LQ_CAND_MAX);
+        const unsigned lmask = lanescan ? (((unsigned)cl[1] & 0xffffu) | (((unsigned)cl[9] & 0xffffu) << 16)) : 0u;
+        if (!shortlist && !(lanescan && lmask != 0u)) {
+            if (lane == 0) slot2_list[atomicAdd(slot2_count, 1)] = slot;      // no list at all: the scanning kernel
             continue;
         }
         const int64_t row = row_list[slot];
         const float* zr = z + (size_t)(z_by_slot ? (int64_t)slot : row) * D;
-        const int nc = n0 + n1;
+        const int P = lanescan ? __builtin_popcount(lmask) : 0;
+        const int nc = lanescan ? P * ((K + 31) / 32) : n0 + n1;
         float best_v = INFINITY;
         int best_k = 0x7fffffff;
         for (int c0 = 0; c0 < nc; c0 += 8) {
             const int ci = c0 + g;
-            const bool live = ci < nc;
-            int code = live ? (ci < n0 ? cl[2 + ci] : cl[10 + (ci - n0)]) : cl[n0 > 0 ? 2 : 10];
+            bool live = ci < nc;
+            int code;
+            if (lanescan) {
+                const int t = ci / P, w = ci - t * P;                          // the w-th flagged lane of tile t
+                unsigned m = lmask;
+                for (int q = 0; q < w; ++q) m &= m - 1;
+                code = 32 * t + __builtin_ctz(m | 0x80000000u);
+                live = live && code < K;
+            } else {
+                code = live ? (ci < n0 ? cl[2 + ci] : cl[10 + (ci - n0)]) : cl[n0 > 0 ? 2 : 10];
+            }
             code = (code >= 0 && code < K) ? code : 0;                       // (lq_screen_emit lists valid codes only)
             const float* c = cb + (size_t)code * D;
             float s;
@@ -633,7 +648,10 @@ __global__ __launch_bounds__(256) void nearest_lists_kernel(
             const int ok = __shfl_xor(best_k, off, 64);
             if (ov < best_v || (ov == best_v && ok < best_k)) { best_v = ov; best_k = ok; }
         }
-        if (best_k < 0 || best_k >= K) best_k = (cl[n0 > 0 ? 2 : 10] >= 0 && cl[n0 > 0 ? 2 : 10] < K) ? cl[n0 > 0 ? 2 : 10] : 0;   // every value NaN
+        if (best_k < 0 || best_k >= K) {                                     // every value NaN: any valid code of the list
+            const int fb = lanescan ? __builtin_ctz(lmask) : cl[n0 > 0 ? 2 : 10];
+            best_k = (fb >= 0 && fb < K) ? fb : 0;
+        }
         if (lane == 0) {
             idx[row] = (int64_t)best_k;
             if (usage) atomicAdd(&usage[best_k], 1ull);
