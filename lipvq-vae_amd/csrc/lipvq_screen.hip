@@ -569,8 +569,8 @@ __global__ __launch_bounds__(256) void nearest_rows_kernel(
 // its eight 8-lane groups score eight candidates at once: lane j of a group keeps torch's accumulator j (features j, j + 8, ...:
 // the k-ordered fma chain of lq_sqdist8; for the sum rule the four accumulators of lane column j, lq_sqdist32), the eight
 // partials are added in lane order, roots compared, lower code among equal values.  Lane-mask rows (4 % of the one-product
-// screen's rows; popcount(mask) x K/32 candidates) take the same loop; rows with no list at all (n = -1: a meaningless screen) are
-// appended to slot2_list for the scanning kernel.
+// screen's rows; popcount(mask) x K/32 candidates) take the same loop while that is at most 128 candidates; longer scans and rows
+// with no list at all (n = -1: a meaningless screen) are appended to slot2_list for the scanning kernel.
 // ------------------------------------------------------------------------------------------
 template <int DCH, int DIST>
 __global__ __launch_bounds__(256) void nearest_lists_kernel(
@@ -591,8 +591,12 @@ __global__ __launch_bounds__(256) void nearest_lists_kernel(
         // code congruent to a flagged lane mod 32 is a candidate -- popcount(mask) x K/32 of them, eight at a time like a short list
         const bool lanescan = !shortlist && n0 != -1 && n1 != -1 && (n0 == -2 || n1 == -2 || n0 > LQ_CAND_MAX || n1 > LQ_CAND_MAX);
         const unsigned lmask = lanescan ? (((unsigned)cl[1] & 0xffffu) | (((unsigned)cl[9] & 0xffffu) << 16)) : 0u;
-        if (!shortlist && !(lanescan && lmask != 0u)) {
-            if (lane == 0) slot2_list[atomicAdd(slot2_count, 1)] = slot;      // no list at all: the scanning kernel
+        // ... as long as that is a few rounds of eight: a long scan would hold this wave for hundreds of dependent rounds while
+        // the scanning kernel spreads a row over 64 slices (measured at K = 8192: 4.6 k such rows, 256 codes per flagged lane:
+        // 290 us here against 101 us there)
+        const bool scan_here = lanescan && lmask != 0u && __builtin_popcount(lmask) * ((K + 31) / 32) <= 128;
+        if (!shortlist && !scan_here) {
+            if (lane == 0) slot2_list[atomicAdd(slot2_count, 1)] = slot;      // long lane scans, no list at all: the scanning kernel
             continue;
         }
         const int64_t row = row_list[slot];
