@@ -109,7 +109,7 @@ size_t lipvq_nearest_workspace_bytes(int64_t N);
 /* The screen comes in two strengths with identical results: three fp16 products per algorithmic product (22-bit operands; a
  * fraction of a percent of the rows left to the exact kernel) or ONE (11-bit operands, a third of the matrix work, lower-bound
  * bookkeeping; 10-40 % of the rows left to the exact stage with their two or three candidates each).  The library picks per
- * shape (large codebooks take the one-product screen: K >= 4096, or K >= 2048 from D = 65 on); this query tells which one
+ * shape (the one-product screen from K = 4096 on, and from K = 1024 on for D > 64); this query tells which one
  * a call with (K, D) would run now (environment LIPVQ_SCREEN_MODE=coarse|fine overrides: a measurement knob). */
 int lipvq_screen_is_coarse(int K, int D);
 /* idx / zq / usage exactly as lipvq_nearest_f32.  After the call the first int of `workspace`

@@ -733,12 +733,12 @@ __device__ __forceinline__ void lq_screen_gather(const float* __restrict__ cb, f
 }
 
 // Which screen a shape runs by default (LIPVQ_SCREEN_MODE=coarse|fine overrides per launch: lipvq_screen.hip).  Measured on one box
-// (profiles/r03_o_coarse_sweep_hi_only_tiles.txt: 524 288 rows, whole call incl. the exact stage, one-product / three-product time):
-//   D =  64: K = 1024 1.09, 4096 0.80, 8192 0.69      D = 128: K = 1024 0.95, 2048 0.81, 4096 0.68, 8192 0.60 (BASELINE config 3)
-//   D = 208: K = 1024 0.99, 4096 0.66, 8192 0.56
+// (profiles/r03_p_coarse_sweep_final.txt: 524 288 rows, whole call incl. the exact stage, one-product / three-product time):
+//   D =  64: K = 1024 1.08, 4096 0.83, 8192 0.74      D = 128: K = 1024 0.91, 2048 0.81, 4096 0.69, 8192 0.61 (BASELINE config 3)
+//   D = 208: K = 1024 0.93 (the reference's own widths), 4096 0.67, 8192 0.58
 // The one-product screen trades two thirds of the matrix work for an exact stage over 10-20 % of the rows: it pays where the
-// screen IS the launch -- large codebooks, the more so the wider the latent.
-static inline int lq_screen_coarse_default(int S, int K) { return (K >= 4096 || (S >= 8 && K >= 2048)) ? 1 : 0; }
+// screen is most of the launch -- wide latents from the reference's default codebook size on, narrow ones against large codebooks.
+static inline int lq_screen_coarse_default(int S, int K) { return (K >= 4096 || (S >= 8 && K >= 1024)) ? 1 : 0; }
 int lq_screen_coarse(int S, int K);
 
 // workspace of the screened routes: [64 B: counter] [row list: lq_list_ints(N) ints] [best-candidate list: the same]
