@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/../.."
 TAG=$1; OUT=gpurun_out/$TAG; mkdir -p $OUT
 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
-for wl in cfg3 icrt; do python bench.py --workload $wl --traffic off > $OUT/bench_$wl.json 2>> $OUT/bench.err; done
+for wl in cfg3 icrt; do python bench.py --workload $wl > $OUT/bench_$wl.json 2>> $OUT/bench.err; done
 for wl in cfg2 cfg3 icrt; do bash scripts/prof_stats.sh $TAG $wl > /dev/null; done
 ( cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/train -- python3 $OLDPWD/scripts/profile_train_step_big.py > /dev/null 2>&1 )
 cp $(ls $OUT/train/*/*kernel_stats.csv | head -1) $OUT/kernel_stats_train_step_cfg2.csv
