@@ -601,24 +601,13 @@ __device__ __forceinline__ void lq_screen_emit(const LqDecision& dec, bool certi
     const bool need = row_valid && !certified;                          // the same in both halves of the row
     if (__builtin_amdgcn_ballot_w64(need) == 0ull) return;              // wave-uniform: most waves have nothing to list
     const int ln = lane & 31, h = lane >> 5;
-    int slot = 0;
-    {
-        // ONE atomic per wave for all its listed rows (the one-product screen lists several rows per wave and block; a slot per
-        // row by its own atomicAdd serialised them on one address): the first listed lane reserves popcount slots
-        const unsigned long long lm = __builtin_amdgcn_ballot_w64(h == 0 && need);        // (bits 0 .. 31 only)
-        const int leader = __builtin_ctzll(lm);
-        int base = 0;
-        if (lane == leader) base = atomicAdd(amb_count, __builtin_popcountll(lm));
-        base = __shfl(base, leader, 64);
-        slot = base + __builtin_popcountll(lm & ((1ull << lane) - 1ull));
-    }
-    if (h == 0 && need) {
-        amb_list[slot] = (int)row;
-        amb_list[lq_list_ints(N) + slot] = my_k;                        // the screen's best candidate: bounds the exact scan
-    }
-    slot = __shfl(slot, ln, 64);                                        // the row's other half learns the slot
-    if (!need || (size_t)slot >= lq_cand_cap(N)) return;
-    int* out = amb_list + 2 * lq_list_ints(N) + (size_t)slot * 16 + 8 * h;
+    // ONE atomic per wave for all its listed rows (the one-product screen lists several rows per wave and block; a slot per row by
+    // its own atomicAdd serialised them on one address): the first listed lane reserves popcount slots.  It is issued FIRST and its
+    // result used LAST: the candidates are worked out into registers while the reservation travels to L2 and back.
+    const unsigned long long lm = __builtin_amdgcn_ballot_w64(h == 0 && need);            // (bits 0 .. 31 only)
+    const int leader = __builtin_ctzll(lm);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(amb_count, __builtin_popcountll(lm));
     const float ab = lq_abs(dec.best);
     // vmax, rounded up generously (the two roundings of the quotient are far below the 2^-20 slack)
     const float vmax0 = (dec.best + dec.t0 + dec.p * ab) / (1.0f - dec.p);
@@ -627,6 +616,9 @@ __device__ __forceinline__ void lq_screen_emit(const LqDecision& dec, bool certi
     unsigned mask = 0u;
     bool nothing = !lists_ok || !dec.screen_ok || !(vmax == vmax);
     const bool second_in = !(dec.m2min - dec.best > dec.t0 + dec.p * (ab + lq_abs(dec.m2min)));
+    int codes[LQ_CAND_MAX];
+#pragma unroll
+    for (int q = 0; q < LQ_CAND_MAX; ++q) codes[q] = 0;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const float v = dec.vv[e];
@@ -636,10 +628,25 @@ __device__ __forceinline__ void lq_screen_emit(const LqDecision& dec, bool certi
             if constexpr (PACK) code = (int)(__float_as_uint(v) & ~keep_mask) * 32 + 16 * h + e;
             else code = reinterpret_cast<const int*>(wave_lds)[ln * LQ_DECIDE_STRIDE + 16 * h + e];
             nothing = nothing || code < 0 || code >= K;
-            if (n < LQ_CAND_MAX) out[2 + n] = code;
+#pragma unroll
+            for (int q = 0; q < LQ_CAND_MAX; ++q)
+                if (q == n) codes[q] = code;                             // (static indexing: the array stays in registers)
             ++n;
         }
     }
+    // ---- now the slot ----
+    base = __shfl(base, leader, 64);
+    int slot = base + __builtin_popcountll(lm & ((1ull << lane) - 1ull));
+    if (h == 0 && need) {
+        amb_list[slot] = (int)row;
+        amb_list[lq_list_ints(N) + slot] = my_k;                        // the screen's best candidate: bounds the exact scan
+    }
+    slot = __shfl(slot, ln, 64);                                        // the row's other half learns the slot
+    if (!need || (size_t)slot >= lq_cand_cap(N)) return;
+    int* out = amb_list + 2 * lq_list_ints(N) + (size_t)slot * 16 + 8 * h;
+#pragma unroll
+    for (int q = 0; q < LQ_CAND_MAX; ++q)
+        if (q < n) out[2 + q] = codes[q];
     out[1] = (int)mask;
     out[0] = nothing ? -1 : ((second_in || n > LQ_CAND_MAX) ? -2 : n);
 }
