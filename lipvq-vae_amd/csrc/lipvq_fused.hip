@@ -283,7 +283,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
         st_prev = __builtin_amdgcn_s_memtime();
 #endif
         f16x8 ahg[RG][S], alg[RG][S];
-        float n2g[RG];
+        float n2g[RG], a2g[RG];
       // ---- phase A of row group GC: the round-2 block body, on this group's rows / fragments / pending z_q copy ----
       auto encode_group = [&](auto GC) {
         constexpr int g = decltype(GC)::value;
@@ -296,7 +296,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
         const int pend_k = pend_kg[g];
         const bool pend_ok = pend_okg[g];
         const int64_t pend_row0 = pend_row0g[g];
-        float n2 = 0.0f;
+        float n2 = 0.0f, a2lo = 0.0f;
         // sigmoid, centring, row statistics and the optional z_e store of one finished 32-feature tile
         auto finish_tile = [&](const int t, f32x16& acc) {
             if constexpr (TRAIN) lq_tile_store16(a.pre2, a.D, row, row < a.N, t, h, acc, a.D, true);
@@ -337,8 +337,10 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                 // kernel-wide power of two fz and split into fp16 hi + lo right here (nothing of z_e is kept in fp32)
                 const float vs = v * fz;
                 const _Float16 vh = (_Float16)vs;
+                const float rs = vs - (float)vh;                       // exact: the one-product screen's row-side residual
                 ah[2 * t + (r >> 3)][r & 7] = vh;
-                al[2 * t + (r >> 3)][r & 7] = (_Float16)(vs - (float)vh);
+                al[2 * t + (r >> 3)][r & 7] = (_Float16)rs;
+                if constexpr (COARSE) a2lo = lq_fma(rs, rs, a2lo);
             }
             // z_e row store.  Lane (n, h) holds features 32t + 2r + h (r = 0..15) of row n: the even ones in
             // the low half-wave, the odd ones in the high half.  One v_permlane32_swap per register pair
@@ -663,6 +665,8 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
         LQ_STAMP(2);
         n2 += __shfl_xor(n2, 32, 64);
         n2g[g] = n2;
+        if constexpr (COARSE) a2lo += __shfl_xor(a2lo, 32, 64);
+        a2g[g] = a2lo;
       };
         encode_group(std::integral_constant<int, 0>{});
         if constexpr (RG > 1) encode_group(std::integral_constant<int, 1>{});
@@ -687,7 +691,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
         float zng[RG], znrg[RG][16];                       // COARSE: the rows' error scale (lq_track_part), in frow's register layout
 #pragma unroll
         for (int g_ = 0; g_ < RG; ++g_) {
-            zng[g_] = COARSE ? LQ_COARSE_CC * lq_sqrt(n2g[g_]) * fown : 0.0f;
+            zng[g_] = COARSE ? lq_coarse_zn(a2g[g_], n2g[g_], fz, fown, __uint_as_float(hdr[5])) : 0.0f;
             if constexpr (COARSE) lq_row_factors(zng[g_], lane, znrg[g_]);
             else {
 #pragma unroll

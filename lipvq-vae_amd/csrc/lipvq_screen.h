@@ -35,7 +35,8 @@ __host__ __device__ static inline PrepLayout prep_layout(int K, int D) {
     L.Dpad = L.S * 16;
     L.Kpad = ((K + 31) / 32) * 32;
     L.ntiles = ((L.Kpad / 32 + 7) / 8) * 8;   // whole LDS stages: pad tiles carry e2 = +inf, zero fragments
-    L.o_hdr = 0;                       // 16 words: [0] E2max bits, [1] Emax^2 bits, [2] max|2e'| bits, [3] se (int), [4] max|mu| bits
+    L.o_hdr = 0;                       // 16 words: [0] E2max bits, [1] Emax^2 bits, [2] max|2e'| bits, [3] se (int), [4] max|mu| bits,
+                                       // [5] max_k |E_k - hi(E_k)| / |E_k| bits (the one-product screen's codebook-side residual ratio)
     L.o_mu = 64;
     L.o_tiles = L.o_mu + sizeof(float) * (size_t)L.Dpad;
     L.o_tiles = (L.o_tiles + 255) & ~(size_t)255;
@@ -131,11 +132,22 @@ __device__ __forceinline__ void lq_track_one(float v, int id, unsigned keep_mask
 // term of the lane's code is added here, one fma per element, off the MFMA chain's critical path): per row (register)
 // and lane (code mod 32) the smallest value, its code and the second smallest.
 // COARSE (round 3): the chain holds ONE product per k-step, hi x hi -- a third of the matrix work -- and the value that is booked is
-// a LOWER BOUND of the code's distance: the hi-only product is off by at most w(n, k) = (2^-9 + 2^-21) |z'_n| |e'_k| (each operand
-// rounded to 11 significant bits; Cauchy-Schwarz over the row), so  L = d~ - w <= d  for every code, and  L + 2 w >= d  for the
-// winner (lq_screen_decide).  en = |e'_k| of the lane's code (rounded up, from the tile), znr[r] = (2^-9 + 2^-21)(1 + 2^-10) |z'_n| f
-// of the register's row.  The chain is SEEDED with |e'|^2 f - w (one fma per element when the tile starts) instead of starting from
+// a LOWER BOUND of the code's distance.  With Z = the row's scaled centred latent, Zh its fp16 rounding, dZ = Z - Zh (EXACT in
+// fp32: the split computes it), and E_k, Eh_k, dE_k the same for the code's scaled (-2 e'):
+//     Z.E_k - Zh.Eh_k = dZ.Eh_k + Zh.dE_k + dZ.dE_k,   |.| <= |dZ| (|E_k| + |dE_k|) + (|Z| + |dZ|) |dE_k| + |dZ| |dE_k|   (Cauchy-Schwarz)
+//                                                         <= |E_k| (|dZ| + rho (|Z| + 3 |dZ|)),   rho = max_k |dE_k| / |E_k|
+// -- the MEASURED residual norms of this row and this codebook (about 0.3 x 2^-11 of the operand norms: 3-4x tighter than the
+// a-priori half-ulp bound, and rigorous whatever the operands do in fp16: denormals, zeros).  So  w(n, k) = znr_n en_k  with
+// en_k = |E_k| / 2^se = |-2 e'_k| as represented (prep_res_kernel, rounded up) and znr_n = (|dZ| + rho (|Z| + 3 |dZ|)) 2^se (1 + 2^-10)
+// (lq_coarse_zn);  L = d~ - w <= d  for every code, and  L + 2 w >= d  for the winner (lq_screen_decide).
+// The chain is SEEDED with |e'|^2 f - w (one fma per element when the tile starts) instead of starting from
 // zero and adding the terms afterwards (two): the accumulator is the booked value.
+// a2lo = sum of the squared split residuals (scaled units), n2 = |z'|^2 (unscaled), fz = 2^sz, fown = 2^(sz + se)
+__device__ __forceinline__ float lq_coarse_zn(float a2lo, float n2, float fz, float fown, float rho) {
+    const float A = lq_sqrt(a2lo), B = lq_sqrt(n2) * fz;
+    const float t = lq_fma(rho, lq_fma(3.0f, A, B), A);
+    return t * (fown / fz) * 1.0009765625f;                 // (1 + 2^-10): the norms' own fp32 rounding (D + 2 roundings each), generously
+}
 template <int LO, int HI, bool PACK = false, bool COARSE = false>
 __device__ __forceinline__ void lq_track_part(const f32x16& acc, float e2, float en, const float (&frow)[16], const float (&znr)[16],
                                               int id, unsigned keep_mask, float (&m1)[16], float (&m2)[16], int (&k1)[16]) {
@@ -447,8 +459,7 @@ struct LqDecision {
 };
 
 // COARSE (one-product screen): the booked values are lower bounds L = d~ - w (lq_track_part); `zn` is this lane's row's
-// (2^-9 + 2^-21)(1 + 2^-10) |z'| f and `tiles` / `tile_bytes` / `frag_bytes` locate the winner's |e'| (the hi-only tiles) -- its upper bound is L + 2 w.
-#define LQ_COARSE_CC 1.9555099e-03f               /* (2^-9 + 2^-21)(1 + 2^-10) = 1.95550965e-3, rounded up */
+// error scale (lq_coarse_zn) and `tiles` / `tile_bytes` / `frag_bytes` locate the winner's |e'| (the hi-only tiles) -- its upper bound is L + 2 w.
 template <bool PACK = false, bool COARSE = false>
 __device__ __forceinline__ bool lq_screen_decide(const float (&m1)[16], const float (&m2)[16], const int (&k1)[16],
                                                  unsigned char* wave_lds /* LQ_DECIDE_BYTES, this wave only */,

@@ -118,6 +118,26 @@ __global__ void prep_frag_kernel(const float* __restrict__ cb, const float* __re
     }
 }
 
+// one thread per code, after the scale is known: the one-product screen's codebook-side numbers.  With E = (-2 e') 2^se as
+// prep_frag_kernel forms it (the same fp32 expression) and Eh its fp16 rounding:  en = |E| / 2^se (rounded up) into the tile,
+// rho = max_k |E - Eh| / |E| into hdr[5].
+__global__ void prep_res_kernel(const float* __restrict__ cb, const float* __restrict__ mu, unsigned char* __restrict__ tiles,
+                                unsigned* __restrict__ hdr, int K, int D, PrepLayout L) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const float fe = lq_pow2f((int)hdr[3]);
+    double c2 = 0.0, d2 = 0.0;
+    for (int d = 0; d < D; ++d) {
+        const float v = (-2.0f * (cb[(size_t)k * D + d] - mu[d])) * fe;
+        const float r = v - (float)(_Float16)v;                       // exact
+        c2 += (double)r * (double)r;
+        d2 += (double)v * (double)v;
+    }
+    float* enp = reinterpret_cast<float*>(tiles + (size_t)(k >> 5) * L.tile_bytes + (size_t)L.S * 2048) + 32 + (k & 31);
+    *enp = (float)(sqrt(d2) / (double)fe * (1.0 + 1e-6));
+    if (d2 > 0.0) atomicMax(&hdr[5], __float_as_uint((float)(sqrt(c2 / d2) * (1.0 + 1e-6))));      // non-negative floats order like their bits
+}
+
 // one thread per code: |e'|^2 (double), statistics for the error bound
 __global__ void prep_e2_kernel(const float* __restrict__ cb, const float* __restrict__ mu,
                                unsigned char* __restrict__ tiles, unsigned* __restrict__ hdr, int K, int D,
@@ -154,6 +174,7 @@ extern "C" int lipvq_nearest_prepare_f32(const float* codebook, void* prep, int 
     hipLaunchKernelGGL(prep_e2_kernel, dim3((L.ntiles * 32 + 255) / 256), dim3(256), 0, st, codebook, mu, base + L.o_tiles,
                        (unsigned*)base, K, D, L);
     hipLaunchKernelGGL(prep_scale_kernel, dim3(1), dim3(1), 0, st, (unsigned*)base);
+    hipLaunchKernelGGL(prep_res_kernel, dim3((K + 255) / 256), dim3(256), 0, st, codebook, mu, base + L.o_tiles, (unsigned*)base, K, D, L);
     size_t n = (size_t)L.ntiles * 32 * L.S * 2;
     hipLaunchKernelGGL(prep_frag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, codebook, mu,
                        (const unsigned*)base, base + L.o_tiles, K, D, L);
@@ -189,7 +210,7 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
 
     // this wave's 32 rows -> centred, row-scaled fp16 hi/lo A fragments (slot (h, j) of step s = feature 16s + 2j + h)
     f16x8 ah[S], al[S];
-    float n2 = 0.0f, fown;
+    float n2 = 0.0f, fown, a2lo = 0.0f, fzr = 1.0f;
     {
         const float* zr = z + (size_t)rowc * D;
         float vv[S][8];
@@ -209,20 +230,24 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
         const int sz = lq_scale_exp(amax);
         const float fz = lq_pow2f(sz);
         fown = lq_pow2f(sz + (int)hdr[3]);                // units of this row's MFMA results: 2^(sz+se), |sz+se| <= 120
+        fzr = fz;
 #pragma unroll
         for (int s = 0; s < S; ++s)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float v = vv[s][j] * fz;
                 const _Float16 vh = (_Float16)v;
+                const float r = v - (float)vh;                         // exact: the one-product screen's row-side residual
                 ah[s][j] = vh;
-                al[s][j] = (_Float16)(v - (float)vh);
+                al[s][j] = (_Float16)r;
+                if constexpr (COARSE) a2lo = lq_fma(r, r, a2lo);
             }
+        if constexpr (COARSE) a2lo += __shfl_xor(a2lo, 32, 64);
     }
     float frow[16];
     lq_row_factors(fown, lane, frow);
-    // COARSE: the per-row scale of the one-product error bound, (2^-9 + 2^-21)(1 + 2^-10) |z'| f, in the register layout of frow
-    const float zn = COARSE ? LQ_COARSE_CC * lq_sqrt(n2) * fown : 0.0f;
+    // COARSE: the per-row scale of the one-product error bound (lq_coarse_zn), in the register layout of frow
+    const float zn = COARSE ? lq_coarse_zn(a2lo, n2, fzr, fown, __uint_as_float(hdr[5])) : 0.0f;
     float znr[16];
     lq_row_factors(zn, lane, znr);
 
