@@ -561,12 +561,9 @@ __device__ __forceinline__ bool lq_screen_decide(const float (&m1)[16], const fl
     //      at least its own booked value: the same inequality with the winner's side raised by w2 = 2 w.
     float w2 = 0.0f;
     if constexpr (COARSE) {
-        // the winner's own |E_k| would have to be fetched from the prepared tiles -- a dependent L2 round trip in every block's
-        // decision (measured: ~2.5 k of a block's 115 k cycles at cfg2); the codebook's LARGEST |E| is in the header and only
-        // makes the margin a little wider than necessary (|E_k| varies by ~20 % over a codebook): en_k <= 2 Emax (1 + 1e-5)
-        (void)tiles; (void)tile_bytes; (void)frag_bytes;
-        const float en_max = 2.0f * Emax * 1.00001f;
-        w2 = 2.0f * zn * en_max;
+        const int bkc = (bk >= 0 && bk < K) ? bk : 0;
+        const float en = reinterpret_cast<const float*>(tiles + (size_t)(bkc >> 5) * tile_bytes + (size_t)frag_bytes + 128)[bkc & 31];
+        w2 = 2.0f * zn * en;
         w2 = lq_fma(w2, 9.5367431640625e-07f, w2);          // (1 + 2^-20): the product's own rounding, generously
     }
     const float s1 = fmaxf(0.0f, best + w2 + n2s) + eps_s + (float)(Dpad16 + 2) * u24 * n2s;
