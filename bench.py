@@ -536,7 +536,7 @@ def main():
         # "report also full fwd (+decode+loss) and fwd+bwd+AdamW step" -- same batch, a few steps each,
         # beside the metric (never `value`)
         def timed_ms(fn, n):
-            for _ in range(2):
+            for _ in range(4):              # (the first steps size the allocator's pools: a 2-step warm-up once read 3.2 ms for 2.8)
                 fn()
             torch.cuda.synchronize()
             a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -560,8 +560,8 @@ def main():
             opt.step()
 
         saved = {k: v.clone() for k, v in model.state_dict().items()}
-        ff_ms = timed_ms(full_forward, 5)
-        ts_ms = timed_ms(train_step, 5)
+        ff_ms = timed_ms(full_forward, 10)
+        ts_ms = timed_ms(train_step, 10)
         model.load_state_dict(saved)                 # the cpu_baseline below compares against the untrained parameters
         # denominators for the two side readings (the same pricing as `roofline`: fp32 work at the fp32 MFMA peak, the distance
         # screen's three split products at the fp16 MFMA peak; HBM is not the binding roof for either)
