@@ -162,6 +162,16 @@ int lipvq_tokenize_train_f32(const float* x, const float* packed, const float* c
                              float* pre1, float* pre2, void* workspace, int64_t N, int A, int J0, int J1, int D, int K,
                              void* stream);
 
+/* The plain VQVAE's encode + quantize in ONE launch (reference robomimic/models/vq_vae/backbone.py:40-66: encoder = three
+ * Linear + ReLU, `(z_e.unsqueeze(1) - E).pow(2).sum(-1)`, argmin, embedding lookup): the same persistent kernel with ReLU
+ * activations and a per-row fp16 scale (a ReLU latent is unbounded).  packed = lipvq_mlp3_pack_f32 of the encoder (plain weights),
+ * prep = lipvq_nearest_prepare_f32 of the embedding table, ze_out [N][D] REQUIRED (the straight-through value of vq:74 and the
+ * exact stage read it).  Same results as lipvq_mlp3_f32(relu, relu, relu) + lipvq_nearest_f32(LIPVQ_DIST_SQSUM).  Shapes as
+ * lipvq_tokenize_supported; workspace lipvq_tokenize_workspace_bytes(N, D). */
+int lipvq_vq_tokenize_f32(const float* x, const float* packed, const float* codebook, const void* prep, int64_t* idx,
+                          float* zq, int64_t* usage, float* ze_out, void* workspace, int64_t N, int A, int J0, int J1, int D,
+                          int K, void* stream);
+
 /* ---- fast mode (opt-in): the encoder's three GEMMs on fp16 MFMAs with fp32 accumulation -- the half-precision
  * encoder of BASELINE.json's config 2 / SURVEY section 7.  NOT bit-identical to lipvq_tokenize_f32: a fraction of a
  * percent of the indices differ, always between near-equidistant codes (the flip rate is reported by bench.py and

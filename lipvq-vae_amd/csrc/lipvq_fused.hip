@@ -93,6 +93,18 @@ struct Gelu2 {
     }
 };
 
+// the hidden layers' activation in the staged form of Gelu2: the ReLU instance needs no stages
+template <bool RELU>
+struct ActStage : Gelu2 {};
+template <>
+struct ActStage<true> {
+    float a_, b_;
+    __device__ __forceinline__ void stage0(float a, float b) { a_ = a; b_ = b; }
+    __device__ __forceinline__ void stage1() {}
+    __device__ __forceinline__ void stage2() {}
+    __device__ __forceinline__ void stage3(float& o0, float& o1) { o0 = a_ > 0.0f ? a_ : 0.0f; o1 = b_ > 0.0f ? b_ : 0.0f; }
+};
+
 struct TokArgs {
     const float* x;              // [N][A]
     const float* packed;         // lipvq_mlp3_pack_f32 of (A -> 64 -> 128 -> D)
@@ -128,9 +140,14 @@ struct TokArgs {
 // COARSE (round 3): phase B runs the one-product screen (lq_screen_core_rg<.., COARSE>): a third of the matrix work, lower-bound
 // bookkeeping, 10-40 % of the rows left to the exact kernel with their two or three candidates -- which then needs z_e, so the
 // host always passes a z_e buffer in this mode (a.ze_out).
-template <int S, bool FAST, bool TRAIN, int RG, int WAVES, bool COARSE = false>
+// VQ (round 3): the plain VQVAE's encoder in the same launch (reference backbone.py:14-21: three Linear + ReLU, the last one on the
+// latent itself) -- ReLU instead of GELU / GELU / sigmoid, no Lipschitz scale (the packed weights are the plain ones).  A ReLU
+// latent is unbounded, so the launch-wide fp16 scale of the sigmoid instance does not exist: the row keeps its centred latent
+// in fp32 until all tiles are finished and is then split with its OWN power of two, as the stand-alone screen does.
+template <int S, bool FAST, bool TRAIN, int RG, int WAVES, bool COARSE = false, bool VQ = false>
 __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
     static_assert(!(FAST && TRAIN), "training uses the parity arithmetic");
+    static_assert(!VQ || (RG == 1 && !FAST && !TRAIN), "the ReLU instance: one row group, parity arithmetic, no training stores");
     static_assert(RG == 1 || RG == 2, "one or two row groups per wave");
     constexpr int THREADS = WAVES * 64;
     constexpr int TCF = fused_ring_tc(S), NBF = fused_ring_nb(S);
@@ -283,7 +300,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
         st_prev = __builtin_amdgcn_s_memtime();
 #endif
         f16x8 ahg[RG][S], alg[RG][S];
-        float n2g[RG], a2g[RG];
+        float n2g[RG], a2g[RG], fzg[RG], fowng[RG];
       // ---- phase A of row group GC: the round-2 block body, on this group's rows / fragments / pending z_q copy ----
       auto encode_group = [&](auto GC) {
         constexpr int g = decltype(GC)::value;
@@ -296,10 +313,23 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
         const int pend_k = pend_kg[g];
         const bool pend_ok = pend_okg[g];
         const int64_t pend_row0 = pend_row0g[g];
-        float n2 = 0.0f, a2lo = 0.0f;
+        float n2 = 0.0f, a2lo = 0.0f, amax = 0.0f;
+        float zt[VQ ? T2 : 1][16];                           // VQ: the centred latent in fp32 until the row's scale is known
         // sigmoid, centring, row statistics and the optional z_e store of one finished 32-feature tile
         auto finish_tile = [&](const int t, f32x16& acc) {
             if constexpr (TRAIN) lq_tile_store16(a.pre2, a.D, row, row < a.N, t, h, acc, a.D, true);
+          if constexpr (VQ) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (2 * t + (r >> 3) >= S) { zt[t][r] = 0.0f; continue; }
+                const float zv = acc[r] > 0.0f ? acc[r] : 0.0f;      // the canonical ReLU (lq_act_apply)
+                acc[r] = zv;
+                const float v = zv - w_mu[32 * t + 2 * r + h];
+                zt[t][r] = v;
+                n2 = lq_fma(v, v, n2);
+                amax = fmaxf(amax, lq_abs(v));
+            }
+          } else {
 #if !defined(LQ_ABL_NOSIGMOID) && !defined(LQ_SCALAR_SIGMOID)
             if constexpr (!FAST) {
                 // the canonical sigmoid, two elements per instruction; a tile that holds a NaN or an infinity (wave-uniform test,
@@ -342,6 +372,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                 al[2 * t + (r >> 3)][r & 7] = (_Float16)rs;
                 if constexpr (COARSE) a2lo = lq_fma(rs, rs, a2lo);
             }
+          }
             // z_e row store.  Lane (n, h) holds features 32t + 2r + h (r = 0..15) of row n: the even ones in
             // the low half-wave, the odd ones in the high half.  One v_permlane32_swap per register pair
             // (low half's r >= 8 <-> high half's r < 8) leaves the low lane with features 32t .. 32t+15 and
@@ -456,6 +487,10 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                 for (int t = 0; t < T0; ++t) {
                     const f32x16 pre = h0[t];
                     if constexpr (TRAIN) lq_tile_store16(a.pre0, 32 * T0, row, row < a.N, t, h, pre, 32 * T0, true);
+                    if constexpr (VQ) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) h0[t][r] = pre[r] > 0.0f ? pre[r] : 0.0f;
+                    } else {
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
 #ifndef LQ_ABL_NOGELU
@@ -466,6 +501,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
 #ifndef LQ_ABL_NOGELU
                     gelu_fixup(h0[t], pre);
 #endif
+                    }
                 }
             }
             if (gnow) {
@@ -522,7 +558,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                     wn = wread(t * G1 + sq + 1);                 // the next group's weights (layer 2's first group after the last)
                     if (sq == G1 - 1 && (t + 1 < T1 || !STREAM2)) bnext = (t + 1 < T1) ? bias16(w_B1, t + 1) : bias16(w_B2, 0);
                     __builtin_amdgcn_sched_barrier(0x6);         // reads stay in front of this group's MFMAs (VALU/SALU may move)
-                    Gelu2 g;
+                    ActStage<VQ> g;
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, h0[(4 * sq + 0) / 16][(4 * sq + 0) % 16], acc, 0, 0, 0);
                     if (t > 0) g.stage0(pend[2 * sq], pend[2 * sq + 1]);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, h0[(4 * sq + 1) / 16][(4 * sq + 1) % 16], acc, 0, 0, 0);
@@ -542,7 +578,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                     __builtin_amdgcn_sched_barrier(0x6);
                 }
 #ifndef LQ_ABL_NOGELU
-                if (t > 0) gelu_fixup(h1[t - 1], pend);
+                if constexpr (!VQ) { if (t > 0) gelu_fixup(h1[t - 1], pend); }
 #endif
                 pend = acc;
                 if constexpr (TRAIN) lq_tile_store16(a.pre1, 32 * T1, row, row < a.N, t, h, acc, 32 * T1, true);
@@ -572,7 +608,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                     if (t == 0 && sq == 3 * (S2 / 16)) {
                         // h1[T1-1] is needed from here on (k-steps 48..63 of a 128-wide layer): finish its GELU
 #ifndef LQ_ABL_NOGELU
-                        gelu_fixup(h1[T1 - 1], pend);
+                        if constexpr (!VQ) gelu_fixup(h1[T1 - 1], pend);
 #endif
                     }
                     const float4 av = wn;
@@ -584,7 +620,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                     if (!STREAM2 && sq == G2 - 1 && t + 1 < T2) bnext = bias16(w_B2, t + 1);
                     __builtin_amdgcn_sched_barrier(0x6);
                     const bool pg = (t == 0 && sq < 8);          // the 16 pending GELUs ride on groups 0..7 (< 12: they only read h1[0..2])
-                    Gelu2 g;
+                    ActStage<VQ> g;
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, h1[(4 * sq + 0) / 16][(4 * sq + 0) % 16], acc, 0, 0, 0);
                     if (pg) g.stage0(pend[(2 * sq) & 15], pend[(2 * sq + 1) & 15]);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, h1[(4 * sq + 1) / 16][(4 * sq + 1) % 16], acc, 0, 0, 0);
@@ -665,14 +701,39 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
         LQ_STAMP(2);
         n2 += __shfl_xor(n2, 32, 64);
         n2g[g] = n2;
+        fzg[g] = fz;
+        fowng[g] = fown;
+        if constexpr (VQ) {
+            // the row's own scale (block floating point, lipvq_screen.h): its largest |z'| lands in [2^13, 2^14)
+            amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+            const int szr = lq_scale_exp(amax);
+            const float fzr = lq_pow2f(szr);
+            fzg[g] = fzr;
+            fowng[g] = lq_pow2f(szr + (int)hdr[3]);
+#pragma unroll
+            for (int t = 0; t < T2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (2 * t + (r >> 3) >= S) continue;
+                    const float vs = zt[t][r] * fzr;
+                    const _Float16 vh = (_Float16)vs;
+                    const float rs = vs - (float)vh;
+                    ah[2 * t + (r >> 3)][r & 7] = vh;
+                    al[2 * t + (r >> 3)][r & 7] = (_Float16)rs;
+                    if constexpr (COARSE) a2lo = lq_fma(rs, rs, a2lo);
+                }
+        }
         if constexpr (COARSE) a2lo += __shfl_xor(a2lo, 32, 64);
         a2g[g] = a2lo;
       };
         encode_group(std::integral_constant<int, 0>{});
         if constexpr (RG > 1) encode_group(std::integral_constant<int, 1>{});
         float frow[16];                                       // one scale for every row here (see fz): a single register
+        if constexpr (VQ) lq_row_factors(fowng[0], lane, frow);  // (the ReLU instance: every row its own)
+        else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) frow[r] = fown;
+            for (int r = 0; r < 16; ++r) frow[r] = fown;
+        }
         // ================= phase B: MFMA screen (lq_screen_core_rg, lipvq_screen.h) ==============
         float m1g[RG][16], m2g[RG][16];
         int k1g[RG][16];
@@ -691,7 +752,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
         float zng[RG], znrg[RG][16];                       // COARSE: the rows' error scale (lq_track_part), in frow's register layout
 #pragma unroll
         for (int g_ = 0; g_ < RG; ++g_) {
-            zng[g_] = COARSE ? lq_coarse_zn(a2g[g_], n2g[g_], fz, fown, __uint_as_float(hdr[5])) : 0.0f;
+            zng[g_] = COARSE ? lq_coarse_zn(a2g[g_], n2g[g_], fzg[g_], fowng[g_], __uint_as_float(hdr[5])) : 0.0f;
             if constexpr (COARSE) lq_row_factors(zng[g_], lane, znrg[g_]);
             else {
 #pragma unroll
@@ -708,10 +769,10 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
             const int64_t row = row0 + ln;
             int my_k;
             LqDecision dec;
-            bool certified = lq_screen_decide<PACKF, COARSE>(m1g[g_], m2g[g_], k1g[g_], scratch, hdr, n2g[g_], fown, a.gamma, a.K, a.D, lane,
+            bool certified = lq_screen_decide<PACKF, COARSE>(m1g[g_], m2g[g_], k1g[g_], scratch, hdr, n2g[g_], fowng[g_], a.gamma, a.K, a.D, lane,
                                                              my_k, dec, PACKF ? lq_pow2f(lq_pack_bits(L.ntiles) - 23) : 0.0f, keep_mask,
                                                              zng[g_], tiles, tile_bytes, ScreenCfg<S, TCF, COARSE>::FRAG_BYTES);
-            const bool row_sane = n2g[g_] >= tiny2;                   // (see fz above; such a row's screen values bound nothing)
+            const bool row_sane = VQ || n2g[g_] >= tiny2;             // (see fz above; such a row's screen values bound nothing)
             certified = certified && row_sane;
             lq_screen_emit<PACKF>(dec, certified, row_sane, my_k, row, row < a.N, a.amb_count, a.amb_list, a.N, a.K, lane, keep_mask, scratch);
             if (h == 0 && row < a.N && certified) {
@@ -750,9 +811,9 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
 }
 
 // two waves per SIMD (8 waves, 256 registers each) / one wave per SIMD (4 waves, the whole 512-register file each)
-template <int S, bool FAST, bool TRAIN = false, int RG = 1, bool COARSE = false>
+template <int S, bool FAST, bool TRAIN = false, int RG = 1, bool COARSE = false, bool VQ = false>
 __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
-    tokenize_body<S, FAST, TRAIN, RG, FUSED_WAVES, COARSE>(a);
+    tokenize_body<S, FAST, TRAIN, RG, FUSED_WAVES, COARSE, VQ>(a);
 }
 template <int S, bool FAST, bool TRAIN, int RG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void tokenize_kernel_w4(TokArgs a) {
@@ -825,6 +886,16 @@ static int launch_tokenize(const TokArgs& a, hipStream_t st) {
         if (sh.waves == 4 && sh.rg == 2) return launch_tokenize_as(tokenize_kernel_w4<S, FAST, TRAIN, 2>, reserved[2], a, lds, 4, 2, st);
     }
     return launch_tokenize_as(tokenize_kernel<S, FAST, TRAIN, 1>, reserved[0], a, lds, 8, 1, st);
+}
+
+// the plain VQVAE's instances (ReLU encoder, per-row scales): both screens
+template <int S>
+static int launch_tokenize_vq(const TokArgs& a, hipStream_t st) {
+    const size_t lds = fused_lds_bytes<S, false>(a.A, a.K);
+    if (lds > 160 * 1024) return fail(LIPVQ_EUNSUPPORTED, "vq_tokenize: %zu B of LDS needed", lds);
+    static LqLdsReserve reserved[2];
+    if (a.coarse) return launch_tokenize_as(tokenize_kernel<S, false, false, 1, true, true>, reserved[1], a, lds, 8, 1, st);
+    return launch_tokenize_as(tokenize_kernel<S, false, false, 1, false, true>, reserved[0], a, lds, 8, 1, st);
 }
 
 // fp16 MFMA fragments of the encoder stack for the fast mode: [layer][tile t][step s][lane][8 halfs] with
@@ -988,6 +1059,49 @@ extern "C" int lipvq_tokenize_train_f32(const float* x, const float* packed, con
     if (!ze_out || !pre0 || !pre1 || !pre2) return fail(LIPVQ_EINVAL, "tokenize_train: z_e and the three pre-activation buffers are required");
     return tokenize_impl(x, packed, nullptr, raw6, codebook, prep, idx, zq, usage, ze_out, workspace, N, A, J0, J1, D, K, stream,
                          pre0, pre1, pre2);
+}
+
+// The plain VQVAE's encode + quantize in one launch (reference backbone.py:40-66: encoder = Linear/ReLU x 3, then
+// `(z_e.unsqueeze(1) - E).pow(2).sum(-1)`, argmin, embedding lookup).  packed: lipvq_mlp3_pack_f32 of the encoder (A -> 64 -> 128 -> D,
+// plain weights); prep: lipvq_nearest_prepare_f32 of the embedding table; ze_out [N][D] is REQUIRED (the straight-through value
+// z_e + (z_q - z_e) of vq:74 needs it, and so does the exact stage).  Same results as lipvq_mlp3_f32(relu, relu, relu) followed by
+// lipvq_nearest_f32(LIPVQ_DIST_SQSUM).  workspace: lipvq_tokenize_workspace_bytes(N, D).
+extern "C" int lipvq_vq_tokenize_f32(const float* x, const float* packed, const float* codebook, const void* prep, int64_t* idx,
+                                     float* zq, int64_t* usage, float* ze_out, void* workspace, int64_t N, int A, int J0, int J1,
+                                     int D, int K, void* stream) {
+    if (N < 0) return fail(LIPVQ_EINVAL, "vq_tokenize: N < 0");
+    if (N == 0) return LIPVQ_OK;
+    if (!x || !packed || !codebook || !prep || !idx || !ze_out || !workspace) return fail(LIPVQ_EINVAL, "vq_tokenize: null pointer");
+    if (!lipvq_tokenize_supported(A, J0, J1, D, K))
+        return fail(LIPVQ_EUNSUPPORTED, "vq_tokenize: unsupported shape A=%d J0=%d J1=%d D=%d K=%d", A, J0, J1, D, K);
+    if (N > 2147483647LL) return fail(LIPVQ_EUNSUPPORTED, "vq_tokenize: N too large");
+    if ((((uintptr_t)codebook | (uintptr_t)zq | (uintptr_t)ze_out | (uintptr_t)workspace) & 15) != 0)
+        return fail(LIPVQ_EINVAL, "vq_tokenize: codebook, zq, ze_out and workspace must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char* ws = (unsigned char*)workspace;
+    int* amb_count = (int*)ws;
+    int* amb_list = (int*)(ws + 64);
+    hipError_t e = hipMemsetAsync(amb_count, 0, 64, st);
+    if (e != hipSuccess) return fail(LIPVQ_EHIP, "vq_tokenize: %s", hipGetErrorString(e));
+    float* w2q = nullptr;
+    if (w2q_floats(D)) {
+        w2q = reinterpret_cast<float*>(ws + 64 + lq_lists_bytes(N));
+        const PackedLayout PL = packed_layout(A, J0, J1, D);
+        const size_t n = w2q_floats(D);
+        hipLaunchKernelGGL(w2q_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, packed + PL.oP2, w2q, PL.T2, PL.S2);
+    }
+    const int coarse = lq_screen_coarse(lq_screen_S(D), K);
+    TokArgs a{x, packed, nullptr, (const unsigned char*)prep, codebook, idx, zq, (unsigned long long*)usage, ze_out, amb_count,
+              amb_list, w2q, nullptr, nullptr, nullptr, N, A, D, K, LIPVQ_SCREEN_GAMMA, coarse};
+    int rc;
+    switch (D) {
+        case 32: rc = launch_tokenize_vq<2>(a, st); break;
+        case 64: rc = launch_tokenize_vq<4>(a, st); break;
+        case 128: rc = launch_tokenize_vq<8>(a, st); break;
+        default: rc = launch_tokenize_vq<13>(a, st); break;
+    }
+    if (rc) return rc;
+    return lipvq_launch_rows(ze_out, 0, codebook, idx, zq, usage, amb_list, amb_count, N, K, D, st, LIPVQ_DIST_SQSUM);
 }
 
 // Fast mode: the encoder's GEMMs on fp16 MFMAs (packed16 = lipvq_mlp3_pack_f16_f32 of the same weights; `packed` still

@@ -472,6 +472,28 @@ def tokenize(x, packed: PackedMlp3, raw, codebook, prep: PreparedCodebook, usage
     return idx, zq, ze, ws
 
 
+def vq_tokenize(x, packed: PackedMlp3, codebook, prep: PreparedCodebook, usage=None, workspace=None):
+    """(idx, zq, ze, workspace) of the plain VQVAE's fused encode + quantize launch (lipvq_vq_tokenize_f32: ReLU encoder,
+    `pow(2).sum(-1)` argmin): the same results as mlp3(relu x 3) + nearest(DIST_SQSUM).  z_e is always returned (the
+    straight-through value needs it)."""
+    x, codebook = _chk(x, "x"), _chk(codebook, "codebook")
+    N, A = x.shape
+    K, D = codebook.shape
+    if (packed.K0, packed.J2) != (A, D) or (prep.K, prep.D) != (K, D):
+        raise ValueError("vq_tokenize: packed encoder / prepared codebook do not match the inputs")
+    if usage is not None:
+        usage = _chk(usage, "usage", torch.int64)
+    dev = x.device
+    idx = torch.empty(N, device=dev, dtype=torch.int64)
+    zq = torch.empty((N, D), device=dev, dtype=torch.float32)
+    ze = torch.empty((N, D), device=dev, dtype=torch.float32)
+    ws = workspace if workspace is not None else tokenize_workspace(N, D, dev)
+    with _on(dev):
+        check(lib.lipvq_vq_tokenize_f32(_ptr(x), _ptr(packed.buf), _ptr(codebook), _ptr(prep.buf), _ptr(idx), _ptr(zq), _ptr(usage),
+                                        _ptr(ze), _ptr(ws), N, A, packed.J0, packed.J1, D, K, _stream()), "lipvq_vq_tokenize_f32")
+    return idx, zq, ze, ws
+
+
 # ---------------------------------------------------------------------------------------------------
 # the step after the tokenizer: input embedding + interleave (csrc/lipvq_embed.hip)
 # ---------------------------------------------------------------------------------------------------

@@ -367,7 +367,7 @@ class VQVAE(_TokenizerBase):
     # bound in 0.4 ms per 524 288 rows, where a screen launch + its uncertified rows would gain nothing
     SCREEN_MIN_CODES = 256
 
-    def _quantize(self, z_e, usage):
+    def _quantize(self, z_e, usage, screen=None):
         """(idx, z_q) of vq:57-66 (`pow(2).sum(-1)`, argmin, embedding lookup): MFMA screen + exact re-scoring where the latent
         width has a screening instance and the codebook is large enough to pay for it, the all-pairs exact kernel otherwise.
         Identical results on every route."""
@@ -378,7 +378,9 @@ class VQVAE(_TokenizerBase):
             if n <= self.EXACT_ROWS_MAX:
                 self.last_exact_rows = None
                 return ops.nearest_rows(z_e, cb, usage=usage, dist=DIST_SQSUM)
-            if self._screen_monitor.use_screen():
+            if screen is None:
+                screen = self._screen_monitor.use_screen()
+            if screen:
                 prep = self._cb_cache.get((self.embedding.weight,), lambda: ops.nearest_prepare(cb))
                 idx, zq, ws = ops.nearest_screened(z_e, cb, prep, usage=usage, return_workspace=True, dist=DIST_SQSUM)
                 self.last_exact_rows = ws
@@ -388,10 +390,36 @@ class VQVAE(_TokenizerBase):
         idx, zq, _ = ops.nearest(z_e, cb, DIST_SQSUM, usage=usage)
         return idx, zq
 
+    def fused_shape(self) -> bool:
+        return ops.tokenize_supported(self.feature_dim, 64, 128, self.latent_dim, self.num_embeddings)
+
+    def _tokenize_fused(self, x, usage):
+        """(idx, z_q, z_e) from ONE persistent launch (lipvq_vq_tokenize_f32: the fused kernel's ReLU instance, per-row fp16
+        scales): encoder + screen, then the exact stage for the rows the screen leaves."""
+        cb = self.embedding.weight.detach()
+        prep = self._cb_cache.get((self.embedding.weight,), lambda: ops.nearest_prepare(cb))
+        key = (x.shape[0], x.device)
+        if self._tok_ws_key != key:
+            self._tok_ws, self._tok_ws_key = ops.tokenize_workspace(x.shape[0], self.latent_dim, x.device), key
+        idx, zq, ze, ws = ops.vq_tokenize(x, self._packed_encoder(), cb, prep, usage=usage, workspace=self._tok_ws)
+        self.last_exact_rows = ws
+        self._screen_monitor.record(ws, x.shape[0], ops.screen_is_coarse(cb.shape[0], cb.shape[1]))
+        return idx, zq, ze
+
     @torch.no_grad()
     def tokenize(self, x, count_usage=True):
-        z_e = self.encode(x)
-        idx, zq = self._quantize(z_e, self.code_usage if count_usage else None)
+        x = self._as_rows(x)
+        usage = self.code_usage if count_usage else None
+        n = x.shape[0]
+        # the fused launch from the codebook size on where a screen pays at all (below, the all-pairs kernel at its VALU bound);
+        # ONE routing decision per call (see _ScreenMonitor)
+        big = n > self.EXACT_ROWS_MAX and self.num_embeddings >= self.SCREEN_MIN_CODES
+        screen = self._screen_monitor.use_screen() if big else None
+        if big and screen and self.fused_shape():
+            idx, zq, z_e = self._tokenize_fused(x, usage)
+        else:
+            z_e = self.encode(x)
+            idx, zq = self._quantize(z_e, usage, screen=screen)
         self.last_indices = idx
         return idx, ops.ste(z_e, zq)
 

@@ -152,6 +152,31 @@ def test_vq_forward_backward(name, oracle, golden_dir):
         _grad_close(got, g["grad/" + k], f"{k} vs reference")
 
 
+@pytest.mark.parametrize("screen", ["fine", "coarse"])
+@pytest.mark.parametrize("A,D,K,N", [(7, 64, 1024, 70000), (12, 208, 512, 9000), (7, 32, 256, 5000), (9, 128, 2048, 6000)])
+def test_vq_fused_tokenize_equals_oracle(oracle, monkeypatch, A, D, K, N, screen):
+    """The plain VQVAE's encode + quantize in ONE launch (lipvq_vq_tokenize_f32: the fused kernel's ReLU instance with per-row fp16
+    scales, either screen): indices, z_e (through the straight-through value), usage -- the oracle's, bit for bit; and it equals
+    the unfused route (mlp3 + screened quantizer)."""
+    from lipvq_vae_amd.tokenizer import VQVAE
+    monkeypatch.setenv("LIPVQ_SCREEN_MODE", screen)
+    monkeypatch.setenv("LIPVQ_SCREEN_MONITOR", "0")
+    p = O.make_params(900 + D + K, A, D, K, variant="vq", oracle=oracle)
+    x = O.make_inputs(901 + N, N, A)
+    model = _model(VQVAE, p, A, D, num_embeddings=K)
+    f = oracle.vq_forward(p, x)
+    xt = torch.from_numpy(x).cuda()
+    model.code_usage.zero_()
+    assert model.fused_shape() and N > model.EXACT_ROWS_MAX
+    idx, z_st = model.tokenize(xt)
+    assert np.array_equal(idx.cpu().numpy(), f["indices"])
+    assert np.array_equal(z_st.cpu().numpy(), f["z_latent"])
+    assert np.array_equal(model.code_usage.cpu().numpy(), f["usage"])
+    assert model.last_exact_rows is not None and int(model.last_exact_rows[0]) < N // 2
+    idx_u, _ = model._quantize(model.encode(xt), None)
+    assert torch.equal(idx_u, idx)
+
+
 @pytest.mark.parametrize("K,N", [(1024, 5000), (1024, 300), (128, 5000)])
 def test_vq_module_routes(oracle, K, N):
     """VQVAE.tokenize / forward pick the screened quantizer (large codebook, large batch), the exact-rows kernel (large
