@@ -366,6 +366,8 @@ class VQVAE(_TokenizerBase):
     # the all-pairs kernel stays the route for small codebooks: at K = 128 (the reference's default, vq:7) it runs at its VALU
     # bound in 0.4 ms per 524 288 rows, where a screen launch + its uncertified rows would gain nothing
     SCREEN_MIN_CODES = 256
+    # ... but the FUSED launch (encoder + screen in one kernel, z_e never re-read) beats encoder + all-pairs from far fewer codes on
+    FUSED_MIN_CODES = 64
 
     def _quantize(self, z_e, usage, screen=None):
         """(idx, z_q) of vq:57-66 (`pow(2).sum(-1)`, argmin, embedding lookup): MFMA screen + exact re-scoring where the latent
@@ -413,7 +415,7 @@ class VQVAE(_TokenizerBase):
         n = x.shape[0]
         # the fused launch from the codebook size on where a screen pays at all (below, the all-pairs kernel at its VALU bound);
         # ONE routing decision per call (see _ScreenMonitor)
-        big = n > self.EXACT_ROWS_MAX and self.num_embeddings >= self.SCREEN_MIN_CODES
+        big = n > self.EXACT_ROWS_MAX and self.num_embeddings >= self.FUSED_MIN_CODES
         screen = self._screen_monitor.use_screen() if big else None
         if big and screen and self.fused_shape():
             idx, zq, z_e = self._tokenize_fused(x, usage)
