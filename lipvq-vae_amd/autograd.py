@@ -115,11 +115,18 @@ class _VQFn(torch.autograd.Function):
         dec_packed = module._packed_decoder()
         E = module.embedding.weight.detach()
         need_grad = any(ctx.needs_input_grad[2:])
+        big = x.shape[0] > module.EXACT_ROWS_MAX and module.num_embeddings >= module.FUSED_MIN_CODES
+        screen = module._screen_monitor.use_screen() if big else None          # one routing decision per call
         if need_grad:
             z_e, pre_e = ops.mlp3(x, enc_packed, _RELU3, save_pre=True)
+            idx, z_q = module._quantize(z_e, module.code_usage, screen=screen)  # vq:57-66 (screened / exact rows / all-pairs: same results)
+        elif big and screen and module.fused_shape():
+            # no autograd (rollouts, bulk evaluation): encoder + quantizer in ONE launch (lipvq_vq_tokenize_f32)
+            idx, z_q, z_e = module._tokenize_fused(x, module.code_usage)
+            pre_e = None
         else:
             z_e, pre_e = ops.mlp3(x, enc_packed, _RELU3), None
-        idx, z_q = module._quantize(z_e, module.code_usage)       # vq:57-66 (screened / exact rows / all-pairs: same results)
+            idx, z_q = module._quantize(z_e, module.code_usage, screen=screen)
         z_st = ops.ste(z_e, z_q)                                   # vq:74
         if need_grad:
             x_rec, pre_d = ops.mlp3(z_st, dec_packed, _RELU3, save_pre=True)
