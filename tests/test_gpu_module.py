@@ -175,6 +175,11 @@ def test_vq_fused_tokenize_equals_oracle(oracle, monkeypatch, A, D, K, N, screen
     assert model.last_exact_rows is not None and int(model.last_exact_rows[0]) < N // 2
     idx_u, _ = model._quantize(model.encode(xt), None)
     assert torch.equal(idx_u, idx)
+    with torch.no_grad():                               # the no-grad forward takes the same launch, then decoder + losses
+        z_latent, loss = model(xt)
+    assert np.array_equal(z_latent.cpu().numpy(), f["z_latent"]) and abs(loss.item() - f["loss"]) <= FLOAT_TOL * abs(f["loss"])
+    z_latent, loss = model(xt)                          # with autograd: the unfused route (pre-activations are saved)
+    assert np.array_equal(z_latent.detach().cpu().numpy(), f["z_latent"]) and abs(loss.item() - f["loss"]) <= FLOAT_TOL * abs(f["loss"])
 
 
 @pytest.mark.parametrize("K,N", [(1024, 5000), (1024, 300), (128, 5000)])
