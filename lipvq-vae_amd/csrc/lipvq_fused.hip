@@ -995,7 +995,10 @@ static int tokenize_impl(const float* x, const float* packed, const void* packed
     float* ze_buf = ze_out;
     // the one-product screen (parity instances only): its exact stage reads z_e rows, so one is always written
     const int coarse = !packed16 ? lq_screen_coarse(lq_screen_S(D), K) : 0;
-    if (coarse && !ze_buf) {
+    // ... and so is one for small batches with either screen (N <= 131 072: shards of a strongly scaled batch): the exact stage
+    // on stored rows (nearest_lists_kernel: a wave per row) is ~8 us where re-encoding the listed rows from x is ~16 us -- a tenth
+    // of a 65 536-row launch; at the full batch the re-encode is kept, because there the z_e write would double the HBM traffic
+    if ((coarse || N <= 131072) && !ze_buf) {
         size_t off = 64 + lq_lists_bytes(N) + sizeof(float) * w2q_floats(D);
         off = (off + 255) & ~(size_t)255;
         ze_buf = reinterpret_cast<float*>(ws + off);
