@@ -8,7 +8,8 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import numpy as np, torch
 import lipvq_vae_amd
 from lipvq_vae_amd import ops
-from lipvq_vae_amd.tokenizer import LLFQVAE_V4
+from lipvq_vae_amd.tokenizer import LLFQVAE_V4, VQVAE
+from lipvq_vae_amd.ops import ACT_RELU
 from bench import trained_like_
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
@@ -56,5 +57,16 @@ while time.time() - t0 < budget:
         ref_f, _, _ = ops.nearest(model.encode(x), cb)
         assert torch.equal(idx_f, ref_f), ("fused", N, A, D, K, os.environ["LIPVQ_SCREEN_MODE"], os.environ["LIPVQ_TOK_SHAPE"])
         assert torch.equal(zq_f, cb[ref_f])
+    if ops.tokenize_supported(A, 64, 128, D, K) and N > 2048 and K >= 64:
+        # the plain VQVAE's fused launch (ReLU instance, per-row scales) against its own encoder + the all-pairs kernel
+        vq = VQVAE(A, D, num_embeddings=K).cuda()
+        with torch.no_grad():
+            vq.embedding.weight.copy_(cb * float(rng.choice([1.0, 0.01])))
+        vq.invalidate_caches()
+        idx_v, zst_v = vq.tokenize(x, count_usage=False)
+        ze_v = vq.encode(x)
+        ref_v, zq_v, _ = ops.nearest(ze_v, vq.embedding.weight.detach(), dist=1)
+        assert torch.equal(idx_v, ref_v), ("vq fused", N, A, D, K, os.environ["LIPVQ_SCREEN_MODE"])
+        assert torch.equal(zst_v, ops.ste(ze_v, zq_v))
     cases += 1; rows += N
 print(f"soak: {cases} random cases, {rows} rows, {unc} uncertified rows through the lists -- every route equals the all-pairs exact kernel")
