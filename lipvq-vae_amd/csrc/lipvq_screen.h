@@ -655,11 +655,14 @@ __device__ __forceinline__ void lq_screen_emit(const LqDecision& dec, bool certi
     slot = __shfl(slot, ln, 64);                                        // the row's other half learns the slot
     if (!need || (size_t)slot >= lq_cand_cap(N)) return;
     int* out = amb_list + 2 * lq_list_ints(N) + (size_t)slot * 16 + 8 * h;
-#pragma unroll
-    for (int q = 0; q < LQ_CAND_MAX; ++q)
-        if (q < n) out[2 + q] = codes[q];
-    out[1] = (int)mask;
-    out[0] = nothing ? -1 : ((second_in || n > LQ_CAND_MAX) ? -2 : n);
+    // the part's eight ints {n, mask, c0 .. c5} as TWO 16-byte stores (the slot is 64-byte aligned, the part 32): eight scattered
+    // dword stores per listed half-row kept the wave's vmcnt busy well into the next block (its z_q copy waits for vmcnt(0))
+    static_assert(LQ_CAND_MAX == 6, "a part is {n, mask, six codes}");
+    const int head = nothing ? -1 : ((second_in || n > LQ_CAND_MAX) ? -2 : n);
+    typedef int lq_i4 __attribute__((ext_vector_type(4)));
+    lq_i4* out4 = reinterpret_cast<lq_i4*>(out);
+    out4[0] = lq_i4{head, (int)mask, codes[0], codes[1]};
+    out4[1] = lq_i4{codes[2], codes[3], codes[4], codes[5]};
 }
 
 // z_q rows of certified rows: 16 lanes copy one codebook row (16 B each), 4 rows per pass

@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "$(dirname "$0")/../.."
-O=gpurun_out/r03o; mkdir -p $O
+O=gpurun_out/r03y; mkdir -p $O
 timeout -k 10 900 python -m pytest tests -x -q -m gpu > $O/pytest_all.txt 2>&1 || { grep -E "^E|FAILED" $O/pytest_all.txt | head -20; }
 tail -2 $O/pytest_all.txt
 export LIPVQ_SCREEN_MONITOR=0
