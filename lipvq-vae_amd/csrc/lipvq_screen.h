@@ -754,11 +754,12 @@ __device__ __forceinline__ void lq_screen_gather(const float* __restrict__ cb, f
 }
 
 // Which screen a shape runs by default (LIPVQ_SCREEN_MODE=coarse|fine overrides per launch: lipvq_screen.hip).  Measured on one box
-// (profiles/r03_p_coarse_sweep_final.txt: 524 288 rows, whole call incl. the exact stage, one-product / three-product time):
-//   D =  64: K = 1024 1.08, 4096 0.83, 8192 0.74      D = 128: K = 1024 0.91, 2048 0.81, 4096 0.69, 8192 0.61 (BASELINE config 3)
-//   D = 208: K = 1024 0.93 (the reference's own widths), 4096 0.67, 8192 0.58
-// The one-product screen trades two thirds of the matrix work for an exact stage over 10-20 % of the rows: it pays where the
-// screen is most of the launch -- wide latents from the reference's default codebook size on, narrow ones against large codebooks.
+// (profiles/r03_y_coarse_sweep_last_build.txt: 524 288 rows, whole call incl. the exact stage, one-product / three-product time):
+//   D =  64: K = 1024 0.99, 4096 0.78, 8192 0.68      D = 128: K = 1024 0.87, 2048 0.76, 4096 0.65, 8192 0.57 (BASELINE config 3)
+//   D = 208: K = 1024 0.91 (the reference's own widths), 4096 0.64, 8192 0.55
+// The one-product screen trades two thirds of the matrix work for an exact stage over 5-10 % of the rows: it pays where the
+// screen is most of the launch -- wide latents from the reference's default codebook size on, narrow ones against large codebooks
+// (at D = 64, K = 1024 -- the metric's shape -- the two are level and the three-product screen stays).
 static inline int lq_screen_coarse_default(int S, int K) { return (K >= 4096 || (S >= 8 && K >= 1024)) ? 1 : 0; }
 int lq_screen_coarse(int S, int K);
 
