@@ -551,7 +551,10 @@ def main():
             with torch.no_grad():
                 model(x)
 
-        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)       # icl.py:885-889
+        # icl.py:885-889's optimizer as the library's trainer builds it (icl.VQTokenizerTrainer): torch.optim.AdamW's state and
+        # arithmetic, step() in two launches for the whole parameter list (optim.py) instead of torch's eight to ten
+        from lipvq_vae_amd.optim import AdamW
+        opt = AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)
 
         def train_step():
             opt.zero_grad()

@@ -205,6 +205,35 @@ int lipvq_mlp3_bwd_f32(const float* gy, const float* pre0, const float* pre1, co
                        const float* packed_bwd, float* g2, float* g1, float* g0, float* gx, int64_t N,
                        int K0, int J0, int J1, int J2, int act0, int act1, int act2, void* stream);
 
+/* lipvq_mlp3_f32 with the tokenizer's loss folded in (the decoder of backbone_lfqvae_v5.py:76-83 at large batches): besides y
+ * and the saved pre-activations,
+ *   out3[0] = mean((y - target)^2)            target [N][J2]   (the reconstruction error)
+ *   out3[1] = mean((input rows - latent)^2)   latent [N][K0]   (input rows = x, or x[gather_idx[n]]: z_q against z_e)
+ *   out3[2] = the loss, as lipvq_mse_pair_loss_f32 forms it from the two means (w, form)
+ * summed in double by the kernel itself -- no second pass over the operands.  workspace: lipvq_mse_workspace_bytes().
+ * Large batches on the reference's hidden widths only: lipvq_mlp3_loss_supported() (LIPVQ_EUNSUPPORTED otherwise). */
+int lipvq_mlp3_loss_supported(int64_t N, int K0, int J0, int J1, int J2);
+int lipvq_mlp3_loss_f32(const float* x, const int64_t* gather_idx, const float* packed, float* y, float* pre0, float* pre1,
+                        float* pre2, int64_t N, int K0, int J0, int J1, int J2, int act0, int act1, int act2,
+                        const float* target, const float* latent, float* out3, float w, int form, void* workspace,
+                        void* stream);
+
+/* The same chain with the VQ losses' gradient terms folded in (what autograd derives from backbone_lfqvae_v5.py:79-83 /
+ * backbone.py:69-74 next to the stack's own backward; three lipvq_scaled_diff_f32 launches per step otherwise):
+ *   in_b  != NULL:  gy := (in_alpha  * *gscale) * (act2(pre2) - B)   -- gy is not read; act2(pre2) is the forward's own output
+ *                                                                       (z_e), re-evaluated from the saved pre-activation
+ *   out_a != NULL:  gx := (out_alpha * *gscale) * (A - B) + gx
+ * (one of the two per launch) with A / B the rows of out_a / in_b / out_b, [N][K0] ([N][J2] for in_b) floats, or -- when the
+ * matching index vector is given -- rows of a table picked by it (z_q = codebook[idx] without materialising it).  gscale: device scalar or NULL (= 1).
+ * Same numbers as lipvq_scaled_diff_f32 followed by lipvq_mlp3_bwd_f32.  Large batches on the reference's hidden widths
+ * only: ask lipvq_mlp3_bwd_vq_supported() first (LIPVQ_EUNSUPPORTED otherwise). */
+int lipvq_mlp3_bwd_vq_supported(int64_t N, int K0, int J0, int J1, int J2);
+int lipvq_mlp3_bwd_vq_f32(const float* gy, const float* pre0, const float* pre1, const float* pre2,
+                          const float* packed_bwd, float* g2, float* g1, float* g0, float* gx, int64_t N,
+                          int K0, int J0, int J1, int J2, int act0, int act1, int act2,
+                          const float* in_b, const int64_t* in_b_idx, float in_alpha, const float* out_a, const int64_t* out_a_idx, const float* out_b,
+                          const int64_t* out_b_idx, float out_alpha, const float* gscale, void* stream);
+
 /* Weight/bias gradient of one Linear layer:  gW [J][Kd] = G^T . act(H),  gb [J] = column sums of G.
  * G [N][J] = dL/d(pre-activation); H [N][Kd] = the layer's input, given as a saved pre-activation
  * plus the activation code h_act to re-apply (LIPVQ_ACT_NONE for raw inputs), or, with hidx,
@@ -234,6 +263,13 @@ int lipvq_scatter_add_sorted_supported(int64_t N, int K, int D);
 size_t lipvq_scatter_add_sorted_workspace_bytes(int64_t N, int K, int D);
 int lipvq_scatter_add_sorted_f32(const float* g, const int64_t* idx, float* gC, void* workspace, int64_t N, int K, int D,
                                  int sequential, void* stream);
+/* The same scatter with the rows formed inside the summing kernel instead of read (the codebook gradient of a training step,
+ * backbone_lfqvae_v5.py:81-83 / backbone.py:69-70, without its [N][D] intermediate):
+ *   row n contributes  (alpha * *gscale) * (table[idx[n]] - ze[n])  (+ g[n] when g is not NULL)
+ * with the roundings of lipvq_scaled_diff_f32; gscale: device scalar or NULL (= 1).  Same support, workspace and orders. */
+int lipvq_scatter_add_sorted_vq_f32(const float* g, const float* ze, const float* table, float alpha, const float* gscale,
+                                    const int64_t* idx, float* gC, void* workspace, int64_t N, int K, int D, int sequential,
+                                    void* stream);
 
 /* Backward of lipvq_lipschitz_scale_f32: gWn [D][H] -> gW [D][H], gci [D]. */
 int lipvq_lipschitz_bwd_f32(const float* W, const float* ci, const float* gWn, float* gW, float* gci, int D,

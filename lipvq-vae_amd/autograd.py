@@ -58,12 +58,17 @@ class _LLFQFn(torch.autograd.Function):
         else:
             z_e, pre_e = ops.mlp3(x, enc_packed, _ENC_ACTS), None
             idx, z_q = module._quantize(z_e, module.code_usage, screen=screen)
-        if need_grad:
-            x_rec, pre_d = ops.mlp3(codebook, dec_packed, _DEC_ACTS, gather_idx=idx, save_pre=True)
+        # recon + 0.25*commit + 0.25*codebook, left to right (v5:83): (m0 + q) + q with q = 0.25 m1, evaluated on the device
+        if ops.mlp3_loss_supported(x.shape[0], dec_packed):
+            # large batches: the decoder launch sums both squared errors itself (its input rows ARE z_q, its output x_rec)
+            x_rec, pre_d, l3 = ops.mlp3_loss(codebook, dec_packed, _DEC_ACTS, idx, x, z_e, 0.25, ops.LOSS_LLFQ, save_pre=need_grad)
+            loss = l3[2]
         else:
-            x_rec, pre_d = ops.mlp3(codebook, dec_packed, _DEC_ACTS, gather_idx=idx), None
-        # recon + 0.25*commit + 0.25*codebook, left to right (v5:83): (m0 + q) + q with q = 0.25 m1, evaluated by the mse launch
-        loss = ops.mse_pair_loss(x_rec, x, z_q, z_e, 0.25, ops.LOSS_LLFQ)[2]
+            if need_grad:
+                x_rec, pre_d = ops.mlp3(codebook, dec_packed, _DEC_ACTS, gather_idx=idx, save_pre=True)
+            else:
+                x_rec, pre_d = ops.mlp3(codebook, dec_packed, _DEC_ACTS, gather_idx=idx), None
+            loss = ops.mse_pair_loss(x_rec, x, z_q, z_e, 0.25, ops.LOSS_LLFQ)[2]
         module.last_indices = idx
         ctx.module = module
         if need_grad:

@@ -37,14 +37,19 @@ def llfq_backward(module, saved, g_loss):
     # decoder + to_output (input = codebook[idx])
     pk, pk_enc = ops.mlp3_pack_bwd2((dec0.weight.detach(), dec2.weight.detach(), outl.weight.detach()),
                                     (enc0.weight.detach(), enc2.weight.detach(), Wn))          # both stacks, one launch
+    alpha = 0.25 * 2.0 / (N * D)
     _, g1d, g0d, g_zq_dec = ops.mlp3_bwd(g_xrec, (pd0, pd1, None), pk, _DEC_ACTS, want_gx=True)
     gWd0, gbd0, gWd2, gbd2, gWo, gbo = _stack_grads(cb, (pd0, pd1), g_xrec, g1d, g0d, _DEC_ACTS, hidx=idx)
-    # codebook: decoder path + 0.25 * codebook loss
-    g_zq = ops.scaled_diff(z_q, z_e, 0.25 * 2.0 / (N * D), gscale=g, c=g_zq_dec)
-    g_cb = ops.scatter_add(g_zq, idx, K)
-    # encoder side: 0.25 * commitment loss only (no straight-through estimator, v5:74-81)
-    g_ze = ops.scaled_diff(z_e, z_q, 0.25 * 2.0 / (N * D), gscale=g)
-    g2e, g1e, g0e, _ = ops.mlp3_bwd(g_ze, (pe0, pe1, pe2), pk_enc, _ENC_ACTS, want_gx=False)
+    # codebook: decoder path + 0.25 d mse(z_q, z_e.detach()); large batches form the rows inside the scatter (no [N, D] stream)
+    g_cb = ops.scatter_add_vq(g_zq_dec, z_e, cb, idx, alpha, gscale=g, zq=z_q)
+    # encoder side: 0.25 d mse(z_q.detach(), z_e) only (no straight-through estimator, v5:74-81)
+    if ops.mlp3_bwd_vq_supported(N, pk_enc):
+        # large batches: the encoder chain forms its own input gradient, alpha g (sigmoid(pe2) - codebook[idx])
+        g2e, g1e, g0e, _ = ops.mlp3_bwd(None, (pe0, pe1, pe2), pk_enc, _ENC_ACTS, want_gx=False,
+                                        in_term=(None, None, cb, idx, alpha), gscale=g)
+    else:
+        g_ze = ops.scaled_diff(z_e, z_q, alpha, gscale=g)
+        g2e, g1e, g0e, _ = ops.mlp3_bwd(g_ze, (pe0, pe1, pe2), pk_enc, _ENC_ACTS, want_gx=False)
     gWe0, gbe0, gWe2, gbe2, gWn, gbl = _stack_grads(x, (pe0, pe1), g2e, g1e, g0e, _ENC_ACTS)
     gWl, gci = ops.lipschitz_bwd(module.to_latent.W.detach(), module.to_latent.ci.detach(), gWn)
     return (gWe0, gbe0, gWe2, gbe2, gWl, gbl, gci, g_cb, gWd0, gbd0, gWd2, gbd2, gWo, gbo)
@@ -64,14 +69,17 @@ def vq_backward(module, saved, g_loss):
     g_xrec = ops.scaled_diff(x_rec, x, 2.0 / (N * A), gscale=g)
     pk, pk_enc = ops.mlp3_pack_bwd2((d[0].weight.detach(), d[2].weight.detach(), d[4].weight.detach()),
                                     (e[0].weight.detach(), e[2].weight.detach(), e[4].weight.detach()))
-    g2d, g1d, g0d, g_zst = ops.mlp3_bwd(g_xrec, (pd0, pd1, pd2), pk, _RELU3, want_gx=True)
+    E = module.embedding.weight.detach()
+    if ops.mlp3_bwd_vq_supported(N, pk):
+        # z_e: straight-through decoder gradient + commitment term, stored by the decoder chain itself (z_q read as E[idx])
+        g2d, g1d, g0d, g_ze = ops.mlp3_bwd(g_xrec, (pd0, pd1, pd2), pk, _RELU3, want_gx=True,
+                                           out_term=(z_e, None, E, idx, cc * 2.0 / (N * D)), gscale=g)
+    else:
+        g2d, g1d, g0d, g_zst = ops.mlp3_bwd(g_xrec, (pd0, pd1, pd2), pk, _RELU3, want_gx=True)
+        g_ze = ops.scaled_diff(z_e, z_q, cc * 2.0 / (N * D), gscale=g, c=g_zst)
     gWd0, gbd0, gWd2, gbd2, gWd4, gbd4 = _stack_grads(z_st, (pd0, pd1), g2d, g1d, g0d, _RELU3)
     # embedding loss mse(z_q, z_e.detach()) -> embedding rows only (the decoder sees z_e through the STE)
-    g_zq = ops.scaled_diff(z_q, z_e, 2.0 / (N * D), gscale=g)
-    g_emb = ops.scatter_add(g_zq, idx, K)
-    # z_e: straight-through decoder gradient + commitment
-    g_ze = ops.scaled_diff(z_e, z_q, cc * 2.0 / (N * D), gscale=g, c=g_zst)
-    pk = pk_enc
-    g2e, g1e, g0e, _ = ops.mlp3_bwd(g_ze, (pe0, pe1, pe2), pk, _RELU3, want_gx=False)
+    g_emb = ops.scatter_add_vq(None, z_e, E, idx, 2.0 / (N * D), gscale=g, zq=z_q)
+    g2e, g1e, g0e, _ = ops.mlp3_bwd(g_ze, (pe0, pe1, pe2), pk_enc, _RELU3, want_gx=False)
     gWe0, gbe0, gWe2, gbe2, gWe4, gbe4 = _stack_grads(x, (pe0, pe1), g2e, g1e, g0e, _RELU3)
     return (gWe0, gbe0, gWe2, gbe2, gWe4, gbe4, gWd0, gbd0, gWd2, gbd2, gWd4, gbd4, g_emb)

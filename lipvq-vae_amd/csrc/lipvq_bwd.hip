@@ -697,8 +697,8 @@ __global__ void scaled_diff_kernel(const float* __restrict__ a, const float* __r
                                    float* __restrict__ out, int64_t n) {
     const float f = gscale ? alpha * gscale[0] : alpha;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float v = f * (a[i] - b[i]);
-        out[i] = c ? v + c[i] : v;
+        const float v = f * (a[i] - b[i]);                      // (built with -ffp-contract=off: product and sum round separately,
+        out[i] = c ? v + c[i] : v;                              //  here and in mlp3_lds_kernel's folded terms)
     }
 }
 

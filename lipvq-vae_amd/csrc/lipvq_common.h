@@ -62,6 +62,9 @@ __device__ __forceinline__ void lq_usage_add(unsigned long long* __restrict__ us
 // error plumbing (defined in lipvq_misc.hip)
 int lipvq_fail(int code, const char* fmt, ...);
 int lipvq_check_launch(const char* what);
+// lipvq_misc.hip: the second pass of the mean-squared-error pair over 2 x 2048 double partial sums (what lipvq_mse_pair_loss_f32
+// runs after its own first pass; lipvq_mlp3_loss_f32's first pass is the decoder kernel itself)
+int lipvq_mse_finish(const double* partial, int64_t nx, int64_t nz, float* out, float* loss, float w, int form, void* stream);
 #define fail lipvq_fail
 #define check_launch lipvq_check_launch
 

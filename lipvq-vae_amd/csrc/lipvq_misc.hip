@@ -174,6 +174,11 @@ static int mse_pair_launch(const float* xr, const float* x, int64_t nx, const fl
     return check_launch(who);
 }
 
+int lipvq_mse_finish(const double* partial, int64_t nx, int64_t nz, float* out, float* loss, float w, int form, void* stream) {
+    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nx, nz, out, loss, w, form);
+    return check_launch("mse_finish");
+}
+
 extern "C" int lipvq_mse_pair_f32(const float* xr, const float* x, int64_t nx, const float* zq,
                                   const float* ze, int64_t nz, float* out2, void* workspace, void* stream) {
     return mse_pair_launch(xr, x, nx, zq, ze, nz, out2, nullptr, 0.0f, 0, workspace, stream, "mse_pair");

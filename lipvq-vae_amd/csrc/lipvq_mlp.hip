@@ -157,6 +157,17 @@ struct Mlp3Args {
     int64_t N;
     int K0, J0, J1, J2;          // widths of THIS chain (bwd: J2, J1, J0, K0 of the forward stack)
     int act0, act1, act2, act_in;
+    // the VQ losses' gradient terms folded into the backward chain (mlp3_lds_kernel<.., FUSE> only; lipvq_mlp3_bwd_vq_f32):
+    //   din_b  != NULL:  gy := (in_alpha  * *gscale) * (act_in(pre2) - B)   instead of reading gy (act_in(pre2) = the forward's output)
+    //   dout_a != NULL:  gx := (out_alpha * *gscale) * (A - B) + gx         (product and sum rounded separately, as scaled_diff_kernel)
+    // A / B = rows of dout_a / din_b / dout_b, picked by their index vector when one is given (codebook rows)
+    const float* din_b; const int64_t* din_ib;
+    const float* dout_a; const int64_t* dout_ia; const float* dout_b; const int64_t* dout_ib;
+    const float* gscale;
+    float in_alpha, out_alpha;
+    // the forward with the tokenizer's two mean-squared errors folded in (mlp3_lds_kernel<.., 3>; lipvq_mlp3_loss_f32): per-wave
+    // double sums of (y - loss_x)^2 and (layer-0 input rows - loss_z)^2 into loss_part[0 / MSE slots + 8 blockIdx.x + wave]
+    const float* loss_x; const float* loss_z; double* loss_part;
 };
 
 template <int T0, int T1, bool BWD>
@@ -457,6 +468,7 @@ __global__ __launch_bounds__(64 * MLPS_WAVES) void mlp3_wg_kernel(Mlp3Args a) {
 // at the tile top (+5 %), 12 waves per workgroup (+6 % forward, spills backward).
 // ------------------------------------------------------------------------------------------
 #define MLPL_WAVES 8
+#define MLPL_LOSS_SLOTS 2048          // = MSE_BLOCKS of lipvq_misc.hip (mse_final_kernel sums that many partials per pair)
 
 __device__ __forceinline__ void mlpl_act16(f32x16& v, int act) {
     if (act == LIPVQ_ACT_GELU) {
@@ -523,7 +535,10 @@ __device__ __forceinline__ void mlpl_store(float* __restrict__ base, int ld, int
     lq_tile_store16(base, ld, rr, rr < N, t, lane >> 5, v, J, vec);
 }
 
-template <int T0, int T1, bool BWD>
+// FUSE: 0 = plain chain; backward: 1 = gy computed from a difference term (Mlp3Args::din_*), 2 = a difference term added to gx
+// (dout_*); forward: 3 = squared-error sums of the output and of the layer-0 input against two more operands (loss_*).
+// Separate instances: the plain encoder backward sits at 245 VGPRs, every live tile more is scratch traffic.
+template <int T0, int T1, bool BWD, int FUSE = 0>
 __global__ __launch_bounds__(64 * MLPL_WAVES) void mlp3_lds_kernel(Mlp3Args a) {
     extern __shared__ __attribute__((aligned(16))) float mlpl_w[];
     const PackedLayout L = packed_layout(a.K0, a.J0, a.J1, a.J2);
@@ -544,6 +559,13 @@ __global__ __launch_bounds__(64 * MLPL_WAVES) void mlp3_lds_kernel(Mlp3Args a) {
     const float* B2 = mlpl_w + L.oB2 + h;
     auto al16 = [](const void* p, int ld) { return p && ((((uintptr_t)p) & 15) == 0) && (ld & 3) == 0; };
     const bool vecx = al16(a.x, a.K0), vecp = BWD && al16(a.in_pre, a.K0);
+    constexpr bool fin = BWD && FUSE == 1, fout = BWD && FUSE == 2, floss = !BWD && FUSE == 3;
+    const bool veclz = floss && al16(a.loss_z, a.K0), veclx = floss && al16(a.loss_x, a.J2);
+    double lsum_x = 0.0, lsum_z = 0.0;                                  // (floss) this lane's share, over all of the wave's tiles
+    const bool vecib = fin && al16(a.din_b, a.K0);
+    const bool vecoa = fout && al16(a.dout_a, a.J2), vecob = fout && al16(a.dout_b, a.J2);
+    const float gs = FUSE && a.gscale ? a.gscale[0] : 1.0f;
+    const float f_in = a.in_alpha * gs, f_out = a.out_alpha * gs;      // scaled_diff_kernel's factor: alpha * *gscale
     const bool vec0 = al16(a.out0, a.J0), vec1 = al16(a.out1, a.J1), vec2o = al16(a.out2, BWD ? a.K0 : a.J2), vec2y = al16(a.y, a.J2);
     const bool vec0m = BWD && al16(a.mul0, a.J0), vec1m = BWD && al16(a.mul1, a.J1);
     const int KT0 = (a.K0 + 31) / 32;
@@ -553,13 +575,39 @@ __global__ __launch_bounds__(64 * MLPL_WAVES) void mlp3_lds_kernel(Mlp3Args a) {
     for (int64_t tile = (int64_t)blockIdx.x * MLPL_WAVES + wave; tile < ntiles; tile += nwaves) {
         const int64_t row0 = tile * 32;
         // one 32-feature slice of the input rows as a B operand; backward: act2'(pre2) folded in and g2 saved
-        f32x16 xraw, praw;
+        // (forward: requesting the NEXT tile's first slice under this tile's second and third layer changed nothing -- decoder
+        // forward with the loss 284 -> 280 us, plain 204 -> 204)
+        f32x16 xraw, praw, qraw;
         auto in_issue = [&](int kt) {
-            xraw = mlpl_load(a.x, a.gather_idx, a.K0, row0, a.N, kt, lane, a.K0, vecx);
+            if (fin) {
+                qraw = mlpl_load(a.din_b, a.din_ib, a.K0, row0, a.N, kt, lane, a.K0, vecib);
+            } else {
+                xraw = mlpl_load(a.x, a.gather_idx, a.K0, row0, a.N, kt, lane, a.K0, vecx);
+            }
             if (BWD && a.in_pre) praw = mlpl_load(a.in_pre, nullptr, a.K0, row0, a.N, kt, lane, a.K0, vecp);
+            if (floss) qraw = mlpl_load(a.loss_z, nullptr, a.K0, row0, a.N, kt, lane, a.K0, veclz);
         };
         auto in_finish = [&](int kt) -> f32x16 {
-            f32x16 v = xraw;
+            f32x16 v;
+            if (fin) {
+                if (a.act_in == LIPVQ_ACT_SIGMOID) {                // LipVQ's encoder: z_e = sigmoid(pre2), one evaluation for z_e and act'
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float sg = lq_sigmoid(praw[r]);
+                        v[r] = (f_in * (sg - qraw[r])) * (sg * (1.0f - sg));
+                    }
+                    if (a.out2) mlpl_store(a.out2, a.K0, row0, a.N, kt, lane, v, a.K0, vec2o);
+                    return v;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = f_in * (lq_act_apply(praw[r], a.act_in) - qraw[r]);
+            } else {
+                v = xraw;
+            }
+            if (floss && row0 + (lane & 31) < a.N) {            // (features past K0 load as 0 from both operands)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const double d = (double)xraw[r] - (double)qraw[r]; lsum_z += d * d; }
+            }
             if (BWD) {
                 if (a.in_pre) mlpl_actgrad16(v, praw, a.act_in);
                 if (a.out2) mlpl_store(a.out2, a.K0, row0, a.N, kt, lane, v, a.K0, vec2o);
@@ -639,7 +687,17 @@ __global__ __launch_bounds__(64 * MLPL_WAVES) void mlp3_lds_kernel(Mlp3Args a) {
         // ---- layer 2: 32 T1 -> J2, one 32-feature output tile at a time (backward: only if the caller wants d/d input) ----
         if (!BWD || a.y) {
             for (int t2 = 0; t2 < L.T2; ++t2) {
-                f32x16 acc2;
+                f32x16 acc2, ea, eb;
+                if (fout) {
+                    // requested before the chain, consumed after it.  (The 32 MFMAs of one output tile do not cover the round trip:
+                    // the cfg2 decoder backward runs 359 us with the term, 303 without.  Requesting a layer ahead costs registers
+                    // this instance does not have -- 8 to 23 spilled, 389 us.  LipVQ's codebook term therefore rides in the
+                    // scatter instead, lipvq_scatter_add_sorted_vq_f32; the plain VQVAE's z_e term uses this.)
+                    ea = mlpl_load(a.dout_a, a.dout_ia, a.J2, row0, a.N, t2, lane, a.J2, vecoa);
+                    eb = mlpl_load(a.dout_b, a.dout_ib, a.J2, row0, a.N, t2, lane, a.J2, vecob);
+                }
+                f32x16 lx;
+                if (floss) lx = mlpl_load(a.loss_x, nullptr, a.J2, row0, a.N, t2, lane, a.J2, veclx);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc2[r] = B2[32 * t2 + 2 * r];
                 const float* P2t = P2 + (size_t)t2 * (16 * T1) * 64;
@@ -650,8 +708,27 @@ __global__ __launch_bounds__(64 * MLPL_WAVES) void mlp3_lds_kernel(Mlp3Args a) {
                     if (a.out2) mlpl_store(a.out2, a.J2, row0, a.N, t2, lane, acc2, a.J2, vec2o);
                     mlpl_act16(acc2, a.act2);
                 }
+                if (fout) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc2[r] = f_out * (ea[r] - eb[r]) + acc2[r];
+                }
+                if (floss && row0 + (lane & 31) < a.N) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const double d = (double)acc2[r] - (double)lx[r];
+                        if (32 * t2 + 2 * r + h < a.J2) lsum_x += d * d;          // (padded features of the last tile hold no output)
+                    }
+                }
                 mlpl_store(a.y, a.J2, row0, a.N, t2, lane, acc2, a.J2, vec2y);
             }
+        }
+    }
+    if (floss) {                                                 // every wave of every workgroup owns one slot of each sum
+        for (int o = 32; o > 0; o >>= 1) { lsum_x += __shfl_down(lsum_x, o, 64); lsum_z += __shfl_down(lsum_z, o, 64); }
+        if (lane == 0) {
+            const int slot = blockIdx.x * MLPL_WAVES + wave;
+            a.loss_part[slot] = lsum_x;
+            a.loss_part[MLPL_LOSS_SLOTS + slot] = lsum_z;
         }
     }
 }
@@ -712,22 +789,28 @@ static int64_t mlp3_lds_rows() {
     return v;
 }
 
-template <bool BWD>
+template <bool BWD, int FUSE>
 static mlp3_fn mlp3_lds_select(int T0, int T1) {      // the reference's hidden widths (64, 128) only; others keep mlp3_wg_kernel
-#define LQ_CASE(a_, b_) if (T0 == a_ && T1 == b_) return mlp3_lds_kernel<a_, b_, BWD>;
+#define LQ_CASE(a_, b_) if (T0 == a_ && T1 == b_) return mlp3_lds_kernel<a_, b_, BWD, FUSE>;
     LQ_CASE(2, 4) LQ_CASE(4, 2)
 #undef LQ_CASE
     return nullptr;
 }
 
-template <bool BWD>
+// does the LDS-resident kernel take this chain?  (also what lipvq_mlp3_bwd_vq_supported answers: only that kernel folds the VQ terms)
+static bool mlp3_lds_takes(int64_t N, int K0, int J0, int J1, int J2) {
+    if (N < mlp3_lds_rows()) return false;
+    const PackedLayout L = packed_layout(K0, J0, J1, J2);
+    return L.total * sizeof(float) <= 156 * 1024 && ((J0 == 64 && J1 == 128) || (J0 == 128 && J1 == 64));
+}
+
+template <bool BWD, int FUSE = 0>
 static int launch_mlp3_lds(const Mlp3Args& a, hipStream_t st, const char* what, bool* done) {
     *done = false;
-    if (a.N < mlp3_lds_rows()) return LIPVQ_OK;
+    if (!mlp3_lds_takes(a.N, a.K0, a.J0, a.J1, a.J2) || (((uintptr_t)a.packed) & 15)) return LIPVQ_OK;
     const PackedLayout L = packed_layout(a.K0, a.J0, a.J1, a.J2);
     const size_t lds = L.total * sizeof(float);
-    if (lds > 156 * 1024 || (((uintptr_t)a.packed) & 15)) return LIPVQ_OK;
-    mlp3_fn fn = mlp3_lds_select<BWD>(a.J0 / 32, a.J1 / 32);
+    mlp3_fn fn = mlp3_lds_select<BWD, FUSE>(a.J0 / 32, a.J1 / 32);
     if (!fn) return LIPVQ_OK;
     static LqLdsReserve reserved[2];             // per instantiation: per-device, thread-safe (lipvq_common.h)
     if (int rc = lipvq_reserve_lds(reserved[a.J0 == 64 ? 0 : 1], (const void*)fn, 156 * 1024, what)) return rc;
@@ -739,6 +822,10 @@ static int launch_mlp3_lds(const Mlp3Args& a, hipStream_t st, const char* what, 
     const int64_t ntiles = (a.N + 31) / 32;
     int64_t blocks = (ntiles + MLPL_WAVES - 1) / MLPL_WAVES;
     if (blocks > cus) blocks = cus;                  // one persistent workgroup per CU
+    if (FUSE == 3) {                                 // one slot per wave in the partial sums; unused slots must read 0
+        if (blocks * MLPL_WAVES > MLPL_LOSS_SLOTS) blocks = MLPL_LOSS_SLOTS / MLPL_WAVES;
+        if (hipMemsetAsync(a.loss_part, 0, 2 * MLPL_LOSS_SLOTS * sizeof(double), st) != hipSuccess) return fail(LIPVQ_EHIP, "%s: memset", what);
+    }
     hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(64 * MLPL_WAVES), lds, st, a);
     *done = true;
     return check_launch(what);
@@ -792,4 +879,58 @@ extern "C" int lipvq_mlp3_bwd_f32(const float* gy, const float* pre0, const floa
     mlp3_fn fn = mlp3_select<true>(J1 / 32, J0 / 32);
     if (!fn) return fail(LIPVQ_EUNSUPPORTED, "mlp3_bwd: no kernel instance for hidden widths %d,%d with J2=%d", J0, J1, J2);
     return launch_mlp3(fn, a, (hipStream_t)stream, "mlp3_bwd");
+}
+
+// The forward stack with the tokenizer's loss folded in (round 3): the decoder of a training / evaluation step at large batches reads
+// its input rows (z_q = codebook[idx]) and holds its output (x_rec) in registers anyway -- the separate first pass of
+// lipvq_mse_pair_loss_f32 streamed 300 MB for the same sums (102 us at the metric's batch).
+extern "C" int lipvq_mlp3_loss_supported(int64_t N, int K0, int J0, int J1, int J2) {
+    return K0 > 0 && J2 > 0 && mlp3_lds_takes(N, K0, J0, J1, J2) ? 1 : 0;
+}
+
+extern "C" int lipvq_mlp3_loss_f32(const float* x, const int64_t* gather_idx, const float* packed, float* y, float* pre0, float* pre1,
+                                   float* pre2, int64_t N, int K0, int J0, int J1, int J2, int act0, int act1, int act2,
+                                   const float* target, const float* latent, float* out3, float w, int form, void* workspace,
+                                   void* stream) {
+    if (N <= 0) return fail(LIPVQ_EINVAL, "mlp3_loss: N <= 0");
+    if (!x || !packed || !y || !target || !latent || !out3 || !workspace) return fail(LIPVQ_EINVAL, "mlp3_loss: null pointer");
+    if (form != LIPVQ_LOSS_LLFQ && form != LIPVQ_LOSS_VQ) return fail(LIPVQ_EINVAL, "mlp3_loss: unknown loss form %d", form);
+    if (!lipvq_mlp3_loss_supported(N, K0, J0, J1, J2) || (((uintptr_t)packed) & 15))
+        return fail(LIPVQ_EUNSUPPORTED, "mlp3_loss: N=%lld widths %d,%d,%d,%d (lipvq_mlp3_loss_supported)", (long long)N, K0, J0, J1, J2);
+    Mlp3Args a{x, gather_idx, packed, y, pre0, pre1, pre2, nullptr, nullptr, nullptr,
+               N, K0, J0, J1, J2, act0, act1, act2, LIPVQ_ACT_NONE};
+    a.loss_x = target; a.loss_z = latent; a.loss_part = (double*)workspace;
+    bool done;
+    if (int e = launch_mlp3_lds<false, 3>(a, (hipStream_t)stream, "mlp3_lds_loss", &done)) return e;
+    if (!done) return fail(LIPVQ_EUNSUPPORTED, "mlp3_loss: no kernel instance");
+    return lipvq_mse_finish(a.loss_part, N * (int64_t)J2, N * (int64_t)K0, out3, out3 + 2, w, form, stream);
+}
+
+// The backward chain with the VQ losses' gradient terms folded in (round 3: the three scaled_diff launches of a training step were
+// 171 us of streaming at the metric's batch).  Large batches on the reference's hidden widths only (the LDS-resident kernel).
+extern "C" int lipvq_mlp3_bwd_vq_supported(int64_t N, int K0, int J0, int J1, int J2) {
+    return K0 > 0 && J2 > 0 && mlp3_lds_takes(N, J2, J1, J0, K0) ? 1 : 0;
+}
+
+extern "C" int lipvq_mlp3_bwd_vq_f32(const float* gy, const float* pre0, const float* pre1, const float* pre2,
+                                     const float* packed_bwd, float* g2, float* g1, float* g0, float* gx, int64_t N,
+                                     int K0, int J0, int J1, int J2, int act0, int act1, int act2,
+                                     const float* in_b, const int64_t* in_b_idx, float in_alpha, const float* out_a, const int64_t* out_a_idx, const float* out_b,
+                                     const int64_t* out_b_idx, float out_alpha, const float* gscale, void* stream) {
+    if (N <= 0) return N < 0 ? fail(LIPVQ_EINVAL, "mlp3_bwd_vq: N < 0") : LIPVQ_OK;
+    if ((!gy && !in_b) || !pre0 || !pre1 || !packed_bwd || !g1 || !g0) return fail(LIPVQ_EINVAL, "mlp3_bwd_vq: null pointer");
+    if (out_a && (!out_b || !gx)) return fail(LIPVQ_EINVAL, "mlp3_bwd_vq: the output term needs both operands and gx");
+    if (in_b && out_a) return fail(LIPVQ_EUNSUPPORTED, "mlp3_bwd_vq: one folded term per launch");
+    if (!in_b && !out_a) return fail(LIPVQ_EINVAL, "mlp3_bwd_vq: no term given (use lipvq_mlp3_bwd_f32)");
+    if (in_b && act2 == LIPVQ_ACT_NONE) return fail(LIPVQ_EINVAL, "mlp3_bwd_vq: the input term is act2(pre2) - B: act2 must not be the identity");
+    if (act2 != LIPVQ_ACT_NONE && !pre2) return fail(LIPVQ_EINVAL, "mlp3_bwd_vq: pre2 required when act2 is not the identity");
+    if (!lipvq_mlp3_bwd_vq_supported(N, K0, J0, J1, J2) || (((uintptr_t)packed_bwd) & 15))
+        return fail(LIPVQ_EUNSUPPORTED, "mlp3_bwd_vq: N=%lld widths %d,%d,%d,%d (lipvq_mlp3_bwd_vq_supported)", (long long)N, K0, J0, J1, J2);
+    Mlp3Args a{gy, nullptr, packed_bwd, gx, g1, g0, g2, (act2 != LIPVQ_ACT_NONE) ? pre2 : nullptr, pre1, pre0,
+               N, J2, J1, J0, K0, act1, act0, LIPVQ_ACT_NONE, act2,
+               in_b, in_b_idx, out_a, out_a_idx, out_b, out_b_idx, gscale, in_alpha, out_alpha};
+    bool done;
+    if (int e = in_b ? launch_mlp3_lds<true, 1>(a, (hipStream_t)stream, "mlp3_lds_bwd_vq_in", &done)
+                     : launch_mlp3_lds<true, 2>(a, (hipStream_t)stream, "mlp3_lds_bwd_vq_out", &done)) return e;
+    return done ? LIPVQ_OK : fail(LIPVQ_EUNSUPPORTED, "mlp3_bwd_vq: no kernel instance");
 }

@@ -198,10 +198,16 @@ __device__ __forceinline__ int scs_code_of_item(const int* itemoff, int K, int i
 
 // One wave per (segment, slice of 64 columns): lane = column; rows in sorted (= ascending row) order, one fp32 chain per column.
 // SEQUENTIAL: a segment is ALL rows of a code (item = code): the strictly sequential order of lipvq_scatter_add_det_f32.
-template <bool SEQUENTIAL>
+// FOLD (round 3, lipvq_scatter_add_sorted_vq_f32): the row's value is not read but formed here,
+//   (alpha * *gscale) * (tab[k][col] - sub[row][col]) (+ g[row][col] when g is given)
+// -- the codebook-loss gradient of the row plus what the decoder sent back, with the roundings of lipvq_scaled_diff_f32 -- so
+// that a training step needs neither that stream (97 us at the metric's batch) nor its [N][D] result.
+template <bool SEQUENTIAL, bool FOLD = false>
 __global__ __launch_bounds__(256) void sc_sum_kernel(const float* __restrict__ g, const int* __restrict__ perm,
                                                      const int* __restrict__ offsets, const int* __restrict__ itemoff,
-                                                     float* __restrict__ partial, float* __restrict__ gC, int K, int D, int slices) {
+                                                     float* __restrict__ partial, float* __restrict__ gC, int K, int D, int slices,
+                                                     const float* __restrict__ sub = nullptr, const float* __restrict__ tab = nullptr,
+                                                     float alpha = 0.0f, const float* __restrict__ gscale = nullptr) {
     extern __shared__ int sc_io[];                            // itemoff [K + 1]: the binary search below runs on LDS
     if (!SEQUENTIAL) {
         for (int i = threadIdx.x; i <= K; i += 256) sc_io[i] = itemoff[i];
@@ -220,10 +226,31 @@ __global__ __launch_bounds__(256) void sc_sum_kernel(const float* __restrict__ g
     const bool cv = col < D;
     const float* __restrict__ gc = g + (cv ? col : 0);
     float acc = SEQUENTIAL && cv ? gC[(size_t)k * D + col] : 0.0f;     // sequential: the chain starts from what gC holds, like index_add_
+    const float* __restrict__ sc = FOLD ? sub + (cv ? col : 0) : nullptr;
+    const float tk = FOLD ? tab[(size_t)k * D + (cv ? col : 0)] : 0.0f;
+    const float f = FOLD ? (gscale ? alpha * gscale[0] : alpha) : 0.0f;
     for (int p = p0; p < p1; p += 64) {
         const int mine = p + lane < p1 ? perm[p + lane] : 0;  // (lanes past the end: row 0, loaded and not added)
         const int n = p1 - p < 64 ? p1 - p : 64;
-        if (n > 16) {
+        if (FOLD) {                                           // two gathered operands per row: 32 rows in flight
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                if (32 * half >= n) break;                    // (wave-uniform)
+                float v[32], u[32];
+#pragma unroll
+                for (int r = 0; r < 32; ++r) {
+                    const size_t row = (size_t)__builtin_amdgcn_readlane(mine, 32 * half + r) * D;
+                    u[r] = sc[row];
+                    v[r] = g ? gc[row] : 0.0f;
+                }
+#pragma unroll
+                for (int r = 0; r < 32; ++r)
+                    if (32 * half + r < n) {
+                        const float d = f * (tk - u[r]);
+                        acc += g ? d + v[r] : d;
+                    }
+            }
+        } else if (n > 16) {
             float v[64];
 #pragma unroll
             for (int r = 0; r < 64; ++r) v[r] = gc[(size_t)__builtin_amdgcn_readlane(mine, r) * D];
@@ -277,9 +304,10 @@ extern "C" size_t lipvq_scatter_add_sorted_workspace_bytes(int64_t N, int K, int
     return scs_layout(N, K, D).total;
 }
 
-extern "C" int lipvq_scatter_add_sorted_f32(const float* g, const int64_t* idx, float* gC, void* workspace, int64_t N, int K, int D,
-                                            int sequential, void* stream) {
-    if (!g || !idx || !gC || !workspace) return fail(LIPVQ_EINVAL, "scatter_add_sorted: null pointer");
+static int scatter_sorted_impl(const float* g, const float* sub, const float* tab, float alpha, const float* gscale, const int64_t* idx,
+                               float* gC, void* workspace, int64_t N, int K, int D, int sequential, void* stream) {
+    const bool fold = sub != nullptr;
+    if ((!g && !fold) || (fold && !tab) || !idx || !gC || !workspace) return fail(LIPVQ_EINVAL, "scatter_add_sorted: null pointer");
     if (!lipvq_scatter_add_sorted_supported(N, K, D))
         return fail(LIPVQ_EUNSUPPORTED, "scatter_add_sorted: N=%lld K=%d D=%d outside the supported range (N >= 32768, K <= %d)",
                     (long long)N, K, D, SCS_MAX_K);
@@ -295,14 +323,15 @@ extern "C" int lipvq_scatter_add_sorted_f32(const float* g, const int64_t* idx, 
     const int waves = scs_waves(K), nb = scs_blocks(N, K);
     int bits = 1;
     while ((1 << bits) < K) ++bits;
-    static LqLdsReserve reserved_place, reserved_count, reserved_sum;      // per device, thread-safe (lipvq_common.h)
+    static LqLdsReserve reserved_place, reserved_count, reserved_sum, reserved_sum_fold;      // per device, thread-safe (lipvq_common.h)
     const size_t lds_place = (size_t)waves * K * sizeof(int), lds_count = (size_t)K * sizeof(int), lds_sum = (size_t)(K + 1) * sizeof(int);
     if (lds_place > 64 * 1024)
         if (int rc = lipvq_reserve_lds(reserved_place, (const void*)sc_place_kernel, lds_place, "scatter_add_sorted")) return rc;
     if (lds_count > 64 * 1024)
         if (int rc = lipvq_reserve_lds(reserved_count, (const void*)sc_count_kernel, lds_count, "scatter_add_sorted")) return rc;
     if (lds_sum > 64 * 1024 && !sequential)
-        if (int rc = lipvq_reserve_lds(reserved_sum, (const void*)sc_sum_kernel<false>, lds_sum, "scatter_add_sorted")) return rc;
+        if (int rc = fold ? lipvq_reserve_lds(reserved_sum_fold, (const void*)sc_sum_kernel<false, true>, lds_sum, "scatter_add_sorted")
+                          : lipvq_reserve_lds(reserved_sum, (const void*)sc_sum_kernel<false, false>, lds_sum, "scatter_add_sorted")) return rc;
     hipLaunchKernelGGL(sc_count_kernel, dim3(nb), dim3(64 * waves), lds_count, st, idx, cnt, N, K);
     hipLaunchKernelGGL(sc_scan_blocks_kernel, dim3((K + 63) / 64), dim3(1024), 0, st, cnt, tot, nb, K);
     hipLaunchKernelGGL(sc_scan_codes_kernel, dim3(1), dim3(1024), 0, st, tot, offsets, itemoff, K);
@@ -310,13 +339,34 @@ extern "C" int lipvq_scatter_add_sorted_f32(const float* g, const int64_t* idx, 
     const int slices = (D + 63) / 64;
     if (sequential) {                                          // one chain per (code, column) over ALL its rows in ascending row order
         const int64_t nwaves = (int64_t)K * slices;
-        hipLaunchKernelGGL(sc_sum_kernel<true>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, g, perm, offsets, itemoff, partial, gC,
-                           K, D, slices);
+        if (fold)
+            hipLaunchKernelGGL((sc_sum_kernel<true, true>), dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, g, perm, offsets, itemoff,
+                               partial, gC, K, D, slices, sub, tab, alpha, gscale);
+        else
+            hipLaunchKernelGGL((sc_sum_kernel<true, false>), dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, g, perm, offsets, itemoff,
+                               partial, gC, K, D, slices, nullptr, nullptr, 0.0f, nullptr);
         return check_launch("scatter_add_sorted");
     }
     const int64_t nwaves = scs_max_items(N, K) * slices;
-    hipLaunchKernelGGL(sc_sum_kernel<false>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), lds_sum, st, g, perm, offsets, itemoff, partial,
-                       gC, K, D, slices);
+    if (fold)
+        hipLaunchKernelGGL((sc_sum_kernel<false, true>), dim3((unsigned)((nwaves + 3) / 4)), dim3(256), lds_sum, st, g, perm, offsets, itemoff,
+                           partial, gC, K, D, slices, sub, tab, alpha, gscale);
+    else
+        hipLaunchKernelGGL((sc_sum_kernel<false, false>), dim3((unsigned)((nwaves + 3) / 4)), dim3(256), lds_sum, st, g, perm, offsets, itemoff,
+                           partial, gC, K, D, slices, nullptr, nullptr, 0.0f, nullptr);
     hipLaunchKernelGGL(sc_combine_kernel, dim3(K), dim3(256), 0, st, partial, itemoff, gC, K, D);
     return check_launch("scatter_add_sorted");
+}
+
+extern "C" int lipvq_scatter_add_sorted_f32(const float* g, const int64_t* idx, float* gC, void* workspace, int64_t N, int K, int D,
+                                            int sequential, void* stream) {
+    if (!g) return fail(LIPVQ_EINVAL, "scatter_add_sorted: null pointer");
+    return scatter_sorted_impl(g, nullptr, nullptr, 0.0f, nullptr, idx, gC, workspace, N, K, D, sequential, stream);
+}
+
+extern "C" int lipvq_scatter_add_sorted_vq_f32(const float* g, const float* ze, const float* table, float alpha, const float* gscale,
+                                               const int64_t* idx, float* gC, void* workspace, int64_t N, int K, int D,
+                                               int sequential, void* stream) {
+    if (!ze || !table) return fail(LIPVQ_EINVAL, "scatter_add_sorted_vq: null pointer");
+    return scatter_sorted_impl(g, ze, table, alpha, gscale, idx, gC, workspace, N, K, D, sequential, stream);
 }

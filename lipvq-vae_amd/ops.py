@@ -121,6 +121,38 @@ def mlp3(x: torch.Tensor, packed: PackedMlp3, acts, gather_idx: torch.Tensor | N
     return (y, pre) if save_pre else y
 
 
+def mlp3_loss_supported(N, packed: PackedMlp3) -> bool:
+    """Can lipvq_mlp3_loss_f32 (the forward stack with the two mean-squared errors folded in) take this batch and stack?"""
+    return bool(lib.lipvq_mlp3_loss_supported(int(N), packed.K0, packed.J0, packed.J1, packed.J2))
+
+
+def mlp3_loss(x, packed: PackedMlp3, acts, gather_idx, target, latent, w: float, form: int, save_pre: bool = False):
+    """(y, pre or None, out3): mlp3() plus out3 = tensor([mean((y - target)^2), mean((input rows - latent)^2), loss]) as
+    mse_pair_loss() forms it, summed by the stack's own launch (mlp3_loss_supported() must hold)."""
+    x, target, latent = _chk(x, "x"), _chk(target, "target"), _chk(latent, "latent")
+    if x.dim() != 2 or x.shape[1] != packed.K0:
+        raise ValueError(f"mlp3_loss: x must be [N,{packed.K0}], got {tuple(x.shape)}")
+    if gather_idx is not None:
+        gather_idx = _chk(gather_idx, "gather_idx", torch.int64)
+        N = gather_idx.numel()
+    else:
+        N = x.shape[0]
+    if tuple(target.shape) != (N, packed.J2) or tuple(latent.shape) != (N, packed.K0):
+        raise ValueError(f"mlp3_loss: target must be [{N},{packed.J2}] and latent [{N},{packed.K0}]")
+    dev = x.device
+    y = torch.empty((N, packed.J2), device=dev, dtype=torch.float32)
+    pre = [torch.empty((N, J), device=dev, dtype=torch.float32) if save_pre else None
+           for J in (packed.J0, packed.J1, packed.J2)]
+    out = torch.empty(3, device=dev, dtype=torch.float32)
+    ws = torch.empty(lib.lipvq_mse_workspace_bytes(), device=dev, dtype=torch.uint8)
+    with _on(dev):
+        check(lib.lipvq_mlp3_loss_f32(_ptr(x), _ptr(gather_idx), _ptr(packed.buf), _ptr(y), _ptr(pre[0]), _ptr(pre[1]), _ptr(pre[2]),
+                                      N, packed.K0, packed.J0, packed.J1, packed.J2, int(acts[0]), int(acts[1]), int(acts[2]),
+                                      _ptr(target), _ptr(latent), _ptr(out), float(w), int(form), _ptr(ws), _stream()),
+              "lipvq_mlp3_loss_f32")
+    return y, (pre if save_pre else None), out
+
+
 def nearest(z: torch.Tensor, codebook: torch.Tensor, dist: int = DIST_NORM, usage: torch.Tensor | None = None,
             want_zq: bool = True, want_best: bool = False):
     """(idx[N] int64, zq[N,D] or None, best[N] or None); usage[K] int64 is accumulated in place."""
@@ -211,24 +243,72 @@ def mlp3_pack_bwd2(a, b):
     return PackedMlp3(bufs[0], *dims[0]), PackedMlp3(bufs[1], *dims[1])
 
 
-def mlp3_bwd(gy, pre, packed_bwd: PackedMlp3, acts, want_gx=True):
-    """(g2, g1, g0, gx): dL/d(pre-activation) of the three layers and dL/d(input)."""
-    gy = _chk(gy, "gy")
+def mlp3_bwd_vq_supported(N, packed_bwd: PackedMlp3) -> bool:
+    """Can lipvq_mlp3_bwd_vq_f32 (the chain with the VQ losses' gradient terms folded in) take this batch and stack?"""
+    p = packed_bwd
+    return bool(lib.lipvq_mlp3_bwd_vq_supported(int(N), p.K0, p.J0, p.J1, p.J2))
+
+
+def _diff_term(term, N, width, name):
+    """(a, a_idx, b, b_idx, alpha) -> checked tensors; an operand is [N, width] rows or (with its index vector) a table of such rows."""
+    if term is None:
+        return None, None, None, None, 0.0
+    a, ia, b, ib, alpha = term
+    a = _chk(a, name + ".a") if a is not None else None           # (in_term only: None = the forward's output, act2(pre2))
+    b = _chk(b, name + ".b")
+    ia = _chk(ia, name + ".a_idx", torch.int64) if ia is not None else None
+    ib = _chk(ib, name + ".b_idx", torch.int64) if ib is not None else None
+    for t, i, nm in ((a, ia, "a"), (b, ib, "b")):
+        if t is None:
+            continue
+        if t.dim() != 2 or t.shape[1] != width or (i is None and t.shape[0] != N) or (i is not None and i.numel() != N):
+            raise ValueError(f"{name}.{nm}: expected [{N}, {width}] rows or a table with an index vector of {N} entries")
+    return a, ia, b, ib, float(alpha)
+
+
+def mlp3_bwd(gy, pre, packed_bwd: PackedMlp3, acts, want_gx=True, in_term=None, out_term=None, gscale=None):
+    """(g2, g1, g0, gx): dL/d(pre-activation) of the three layers and dL/d(input).
+    in_term / out_term = (a, a_idx, b, b_idx, alpha): gy := alpha * gscale * (A - B) (gy may then be None; a = None stands for
+    the forward's own output act2(pre2)) / gx += alpha * gscale * (A - B), folded into the launch; one term per launch,
+    mlp3_bwd_vq_supported() must hold."""
     pre0, pre1 = _chk(pre[0], "pre0"), _chk(pre[1], "pre1")
     pre2 = _chk(pre[2], "pre2") if pre[2] is not None else None
     p = packed_bwd
-    N = gy.shape[0]
-    dev = gy.device
+    N = pre0.shape[0]
+    dev = pre0.device
     ident = int(acts[2]) == ACT_NONE
-    g2 = gy if ident else torch.empty_like(gy)
+    fused = in_term is not None or out_term is not None
+    if gy is not None:
+        gy = _chk(gy, "gy")
+    elif in_term is None:
+        raise ValueError("mlp3_bwd: gy is required without an in_term")
+    if in_term is not None or not ident:
+        g2 = torch.empty((N, p.J2), device=dev, dtype=torch.float32)
+    else:
+        g2 = gy
     g1 = torch.empty((N, p.J1), device=dev, dtype=torch.float32)
     g0 = torch.empty((N, p.J0), device=dev, dtype=torch.float32)
     gx = torch.empty((N, p.K0), device=dev, dtype=torch.float32) if want_gx else None
     with _on(dev):
-        check(lib.lipvq_mlp3_bwd_f32(_ptr(gy), _ptr(pre0), _ptr(pre1), _ptr(pre2), _ptr(p.buf),
-                                     None if ident else _ptr(g2), _ptr(g1), _ptr(g0), _ptr(gx), N, p.K0, p.J0,
-                                     p.J1, p.J2, int(acts[0]), int(acts[1]), int(acts[2]), _stream()),
-              "lipvq_mlp3_bwd_f32")
+        if fused:
+            if out_term is not None and not want_gx:
+                raise ValueError("mlp3_bwd: an out_term needs want_gx")
+            ia_, iai, ib_, ibi, ial = _diff_term(in_term, N, p.J2, "in_term")
+            if ia_ is not None or iai is not None:
+                raise ValueError("mlp3_bwd: in_term's A is the forward's own output act2(pre2): pass a = a_idx = None")
+            oa_, oai, ob_, obi, oal = _diff_term(out_term, N, p.K0, "out_term")
+            gs = _chk(gscale, "gscale") if gscale is not None else None
+            check(lib.lipvq_mlp3_bwd_vq_f32(_ptr(gy), _ptr(pre0), _ptr(pre1), _ptr(pre2), _ptr(p.buf),
+                                            _ptr(g2) if g2 is not gy else None, _ptr(g1), _ptr(g0), _ptr(gx), N, p.K0, p.J0,
+                                            p.J1, p.J2, int(acts[0]), int(acts[1]), int(acts[2]),
+                                            _ptr(ib_), _ptr(ibi), ial,
+                                            _ptr(oa_), _ptr(oai), _ptr(ob_), _ptr(obi), oal, _ptr(gs), _stream()),
+                  "lipvq_mlp3_bwd_vq_f32")
+        else:
+            check(lib.lipvq_mlp3_bwd_f32(_ptr(gy), _ptr(pre0), _ptr(pre1), _ptr(pre2), _ptr(p.buf),
+                                         None if ident else _ptr(g2), _ptr(g1), _ptr(g0), _ptr(gx), N, p.K0, p.J0,
+                                         p.J1, p.J2, int(acts[0]), int(acts[1]), int(acts[2]), _stream()),
+                  "lipvq_mlp3_bwd_f32")
     return g2, g1, g0, gx
 
 
@@ -281,6 +361,33 @@ def scatter_add(g, idx, K, deterministic=None, route=None):
             check(lib.lipvq_scatter_add_f32(_ptr(g), _ptr(idx), _ptr(gC), N, K, D, _stream()), "lipvq_scatter_add_f32")
         else:
             raise ValueError(f"scatter_add: unknown route {route!r}")
+    return gC
+
+
+def scatter_add_vq(g, ze, table, idx, alpha, gscale=None, zq=None, deterministic=None):
+    """gC[k] = sum over the rows n with idx[n] = k of  alpha * gscale * (table[k] - ze[n]) (+ g[n] when g is given):
+    the codebook gradient of a training step -- the codebook-loss term formed per row plus what the decoder sent back --
+    without the [N, D] intermediate.  Batches the counting-sort scatter takes (scatter_add's rule) form the rows inside its
+    summing kernel (lipvq_scatter_add_sorted_vq_f32); smaller ones run scaled_diff + scatter_add: the same numbers either way."""
+    ze, table, idx = _chk(ze, "ze"), _chk(table, "table"), _chk(idx, "idx", torch.int64)
+    if g is not None:
+        g = _chk(g, "g")
+    N, D = ze.shape
+    K = table.shape[0]
+    if gscale is not None:
+        gscale = _chk(gscale.reshape(1), "gscale")
+    if deterministic is None:
+        deterministic = torch.are_deterministic_algorithms_enabled()
+    sortable = bool(lib.lipvq_scatter_add_sorted_supported(N, K, D))
+    if not sortable or (not deterministic and N < 65536):
+        return scatter_add(scaled_diff(zq if zq is not None else table[idx], ze, alpha, gscale=gscale, c=g), idx, K,
+                           deterministic=deterministic)
+    gC = torch.zeros((K, D), device=ze.device, dtype=torch.float32)
+    ws = torch.empty(lib.lipvq_scatter_add_sorted_workspace_bytes(N, K, D), device=ze.device, dtype=torch.uint8)
+    with _on(ze.device):
+        check(lib.lipvq_scatter_add_sorted_vq_f32(_ptr(g), _ptr(ze), _ptr(table), float(alpha), _ptr(gscale), _ptr(idx), _ptr(gC),
+                                                  _ptr(ws), N, K, D, 1 if deterministic else 0, _stream()),
+              "lipvq_scatter_add_sorted_vq_f32")
     return gC
 
 

@@ -184,6 +184,133 @@ def test_training_forward_launch_equals_unfused(oracle, monkeypatch, N, A, D, K,
         assert torch.allclose(g_fused[k], v.grad, rtol=0, atol=1e-5 * max(1e-12, float(v.grad.abs().max()))), k
 
 
+@pytest.mark.parametrize("N,A,D,K", [(66000, 7, 64, 1024), (65537, 12, 128, 1000), (70001, 3, 32, 256)])
+def test_decoder_launch_with_folded_loss_equals_separate_launches(oracle, N, A, D, K):
+    """lipvq_mlp3_loss_f32 (the decoder stack summing both squared errors itself, from 65 536 rows on) against lipvq_mlp3_f32 +
+    lipvq_mse_pair_loss_f32: x_rec and the saved pre-activations bit for bit; the two means and the loss -- double sums in a
+    different order -- to 1e-7; and the loss the module returns against the oracle's."""
+    from lipvq_vae_amd import ops
+    from lipvq_vae_amd.autograd import _DEC_ACTS
+    p, model = _setup(N + D, A, D, K, oracle)
+    x = O.make_inputs(N + 5, N, A)
+    xt = torch.from_numpy(x).cuda()
+    dec = model._packed_decoder()
+    cb = model.quantizer.codebook.detach()
+    assert ops.mlp3_loss_supported(N, dec)
+    idx, z_q, z_e = model._tokenize_fused(xt, None, want_ze=True)
+    y, pre, l3 = ops.mlp3_loss(cb, dec, _DEC_ACTS, idx, xt, z_e, 0.25, ops.LOSS_LLFQ, save_pre=True)
+    y_u, pre_u = ops.mlp3(cb, dec, _DEC_ACTS, gather_idx=idx, save_pre=True)
+    l3_u = ops.mse_pair_loss(y_u, xt, z_q, z_e, 0.25, ops.LOSS_LLFQ)
+    assert torch.equal(y, y_u)
+    for a, b in zip(pre, pre_u):
+        assert torch.equal(a, b)
+    assert torch.allclose(l3, l3_u, rtol=1e-7, atol=0), (l3, l3_u)
+    y2, none, l3b = ops.mlp3_loss(cb, dec, _DEC_ACTS, idx, xt, z_e, 0.25, ops.LOSS_LLFQ)      # without saving: same sums
+    assert none is None and torch.equal(y2, y) and torch.equal(l3b, l3)
+    with torch.no_grad():
+        _, loss = model(xt)
+    assert loss.item() == l3[2].item()
+    f = oracle.llfq_forward(p, x[:4096])                       # (the oracle's loss on a slice the CPU finishes quickly ...)
+    with torch.no_grad():
+        _, loss_s = model(xt[:4096])                           # (... which takes the separate launches: same numbers as before)
+    assert abs(loss_s.item() - f["loss"]) <= 1e-5 * abs(f["loss"])
+
+
+@pytest.mark.parametrize("with_g", [True, False])
+@pytest.mark.parametrize("N,D,K,det", [(70001, 64, 1024, False), (66000, 208, 1000, False), (40000, 64, 128, True), (131072, 32, 37, True)])
+def test_scatter_with_rows_formed_in_kernel_equals_scaled_diff_then_scatter(N, D, K, det, with_g):
+    """lipvq_scatter_add_sorted_vq_f32 against lipvq_scaled_diff_f32 + lipvq_scatter_add_sorted_f32, both orders (256-row segments /
+    one sequential chain per code): bit for bit."""
+    from lipvq_vae_amd import ops
+    gen = torch.Generator(device="cuda").manual_seed(N + D)
+    ze = torch.rand(N, D, device="cuda", generator=gen)
+    table = torch.rand(K, D, device="cuda", generator=gen)
+    idx = torch.randint(0, K, (N,), device="cuda", generator=gen)
+    idx[: N // 3] = 5                                          # one hot code (many segments / a long chain)
+    g = torch.randn(N, D, device="cuda", generator=gen) * 1e-6 if with_g else None
+    gs = torch.tensor([1.7], device="cuda")
+    alpha = 0.5 / (N * D)
+    got = ops.scatter_add_vq(g, ze, table, idx, alpha, gscale=gs, deterministic=det)
+    rows = ops.scaled_diff(table[idx], ze, alpha, gscale=gs, c=g)
+    want = ops.scatter_add(rows, idx, K, route="sequential_sorted" if det else "sorted")
+    assert torch.equal(got, want)
+    ref = torch.zeros(K, D, dtype=torch.float64, device="cuda").index_add_(0, idx, rows.double())
+    assert torch.allclose(got.double(), ref, rtol=0, atol=1e-5 * float(ref.abs().max()))
+
+
+def oracle_grads_cpu(model, xt, kind, gscale):
+    """Parameter gradients of gscale * loss by torch autograd on the CPU in float64 (stock ops, the reference's forward as
+    oracle/lipvq_oracle.py restates it; float64 so that the comparison sees the launches' rounding only -- a sequential fp32
+    index_add_ over the thousands of rows of one code is itself 1e-5 off), with the code indices taken from the launch (the [N, K, D] distance tensor of the
+    reference's argmin is 17 GB at these batches; index parity is what the other tests are for)."""
+    import torch.nn.functional as F
+    p = {k: v.detach().cpu().double().requires_grad_(True) for k, v in model.named_parameters()}
+    x = xt.cpu().double()
+    idx = model.last_indices.cpu()
+    if kind == "llfq":
+        z_e = O.torch_llfq_encode(p, x)
+        z_q = p["quantizer.codebook"][idx]
+        h = F.gelu(F.linear(z_q, p["decoder.0.weight"], p["decoder.0.bias"]))
+        h = F.gelu(F.linear(h, p["decoder.2.weight"], p["decoder.2.bias"]))
+        x_rec = F.linear(h, p["to_output.weight"], p["to_output.bias"])
+        loss = F.mse_loss(x_rec, x) + 0.25 * F.mse_loss(z_q.detach(), z_e) + 0.25 * F.mse_loss(z_q, z_e.detach())
+    else:
+        h = x
+        for i in (0, 2, 4):
+            h = F.relu(F.linear(h, p[f"encoder.{i}.weight"], p[f"encoder.{i}.bias"]))
+        z_e = h
+        z_q = F.embedding(idx, p["embedding.weight"])
+        q_loss = F.mse_loss(z_q, z_e.detach()) + float(model.commitment_cost) * F.mse_loss(z_q.detach(), z_e)
+        h = z_e + (z_q - z_e).detach()
+        for i in (0, 2, 4):
+            h = F.relu(F.linear(h, p[f"decoder.{i}.weight"], p[f"decoder.{i}.bias"]))
+        loss = F.mse_loss(h, x) + q_loss
+    (loss * gscale).backward()
+    return {k: (v.grad if v.grad is not None else torch.zeros_like(v)).float() for k, v in p.items()}
+
+
+@pytest.mark.parametrize("kind,N,A,D,K", [("llfq", 66000, 7, 64, 1024), ("llfq", 65537, 12, 128, 1000), ("vq", 66001, 7, 64, 128)])
+def test_backward_with_folded_loss_terms_equals_separate_launches(oracle, monkeypatch, kind, N, A, D, K):
+    """From 65 536 rows on the latent-loss gradient terms ride in their consumers instead of three lipvq_scaled_diff_f32 streams:
+    LipVQ's encoder chain computes its input alpha g (sigmoid(pre2) - codebook[idx]) itself (lipvq_mlp3_bwd_vq_f32), the plain
+    VQVAE's decoder chain adds cc alpha g (z_e - E[idx]) to its last store, and the codebook rows alpha g (z_q - z_e) (+ the
+    decoder's gradient) are formed inside the counting-sort scatter (lipvq_scatter_add_sorted_vq_f32).  Every parameter gradient
+    must carry the same bits as the separate launches give (same operations in the same order, -ffp-contract=off), and agree
+    with torch autograd on the CPU."""
+    from lipvq_vae_amd import ops
+    from lipvq_vae_amd.tokenizer import VQVAE
+    if kind == "llfq":
+        p, model = _setup(N + D, A, D, K, oracle)
+    else:
+        torch.manual_seed(N)
+        model = VQVAE(A, D, num_embeddings=K).cuda()
+        with torch.no_grad():
+            model.embedding.weight.uniform_(0.0, 0.4)
+        model.invalidate_caches()
+    xt = torch.from_numpy(O.make_inputs(N + 2, N, A)).cuda()
+    calls = []
+    real, real_s = ops.lib.lipvq_mlp3_bwd_vq_f32, ops.lib.lipvq_scatter_add_sorted_vq_f32
+    monkeypatch.setattr(ops.lib, "lipvq_mlp3_bwd_vq_f32", lambda *a: (calls.append("chain"), real(*a))[1])
+    monkeypatch.setattr(ops.lib, "lipvq_scatter_add_sorted_vq_f32", lambda *a: (calls.append("scatter"), real_s(*a))[1])
+    _, loss = model(xt)
+    (loss * 3.0).backward()                                    # (a gscale that is not 1)
+    assert calls == ["chain", "scatter"] or calls == ["scatter", "chain"]          # the folded launches ran
+    g_folded = {k: v.grad.clone() for k, v in model.named_parameters()}
+    model.zero_grad()
+    monkeypatch.setattr(ops, "mlp3_bwd_vq_supported", lambda N, pk: False)
+    monkeypatch.setattr(ops, "scatter_add_vq", lambda g, ze, table, idx, alpha, gscale=None, zq=None, deterministic=None:
+                        ops.scatter_add(ops.scaled_diff(zq, ze, alpha, gscale=gscale, c=g), idx, table.shape[0]))
+    _, loss2 = model(xt)
+    (loss2 * 3.0).backward()
+    assert len(calls) == 2
+    for k, v in model.named_parameters():
+        assert torch.equal(g_folded[k], v.grad), k
+    # and against torch autograd on the CPU (float64)
+    ref = oracle_grads_cpu(model, xt, kind, 3.0)
+    for k, v in model.named_parameters():
+        assert torch.allclose(v.grad.cpu(), ref[k], rtol=0, atol=2e-5 * max(1e-12, float(ref[k].abs().max()))), k
+
+
 @pytest.mark.parametrize("shape", ["w8rg2", "w4rg2", "w4rg1"])
 @pytest.mark.parametrize("N,A,D,K", [(256 * 300 + 5, 7, 64, 1024), (9000, 7, 32, 256), (4100, 7, 128, 2048), (3000, 12, 208, 1024)])
 def test_other_kernel_shapes_give_the_same_results(oracle, monkeypatch, shape, N, A, D, K):
