@@ -10,8 +10,8 @@ from lipvq_vae_amd.tokenizer import LLFQVAE_V4, VQVAE
 from bench import trained_like_
 from lipvq_vae_amd.optim import AdamW
 
-N, A, D, K = 524288, 7, 64, 1024
 kind = sys.argv[1] if len(sys.argv) > 1 else "llfq"
+N, A, D, K = {"cfg3": (524288, 7, 128, 8192), "icrt": (524280, 12, 208, 1024)}.get(sys.argv[2] if len(sys.argv) > 2 else "", (524288, 7, 64, 1024))
 if os.environ.get("LIPVQ_NO_FOLD") == "1":
     ops.mlp3_bwd_vq_supported = lambda N, pk: False
 torch.manual_seed(0)
@@ -36,4 +36,4 @@ for rep in range(3):
     for _ in range(20): step()
     e1.record(); torch.cuda.synchronize()
     best.append(e0.elapsed_time(e1) / 20)
-print(f"{kind} train step N={N}: " + " / ".join(f"{b:.3f}" for b in best) + " ms" + ("  (separate scaled_diff launches)" if os.environ.get("LIPVQ_NO_FOLD") == "1" else "  (folded terms)"))
+print(f"{kind} train step N={N} A={A} D={D} K={K}: " + " / ".join(f"{b:.3f}" for b in best) + " ms" + ("  (separate scaled_diff launches)" if os.environ.get("LIPVQ_NO_FOLD") == "1" else "  (folded terms)"))

@@ -184,7 +184,7 @@ def test_training_forward_launch_equals_unfused(oracle, monkeypatch, N, A, D, K,
         assert torch.allclose(g_fused[k], v.grad, rtol=0, atol=1e-5 * max(1e-12, float(v.grad.abs().max()))), k
 
 
-@pytest.mark.parametrize("N,A,D,K", [(66000, 7, 64, 1024), (65537, 12, 128, 1000), (70001, 3, 32, 256)])
+@pytest.mark.parametrize("N,A,D,K", [(66000, 7, 64, 1024), (65537, 12, 128, 1000), (70001, 3, 32, 256), (65539, 12, 208, 1024)])
 def test_decoder_launch_with_folded_loss_equals_separate_launches(oracle, N, A, D, K):
     """lipvq_mlp3_loss_f32 (the decoder stack summing both squared errors itself, from 65 536 rows on) against lipvq_mlp3_f32 +
     lipvq_mse_pair_loss_f32: x_rec and the saved pre-activations bit for bit; the two means and the loss -- double sums in a
@@ -269,7 +269,8 @@ def oracle_grads_cpu(model, xt, kind, gscale):
     return {k: (v.grad if v.grad is not None else torch.zeros_like(v)).float() for k, v in p.items()}
 
 
-@pytest.mark.parametrize("kind,N,A,D,K", [("llfq", 66000, 7, 64, 1024), ("llfq", 65537, 12, 128, 1000), ("vq", 66001, 7, 64, 128)])
+@pytest.mark.parametrize("kind,N,A,D,K", [("llfq", 66000, 7, 64, 1024), ("llfq", 65537, 12, 128, 1000), ("llfq", 65600, 12, 208, 1024),
+                                          ("vq", 66001, 7, 64, 128), ("vq", 65536, 12, 208, 1024)])
 def test_backward_with_folded_loss_terms_equals_separate_launches(oracle, monkeypatch, kind, N, A, D, K):
     """From 65 536 rows on the latent-loss gradient terms ride in their consumers instead of three lipvq_scaled_diff_f32 streams:
     LipVQ's encoder chain computes its input alpha g (sigmoid(pre2) - codebook[idx]) itself (lipvq_mlp3_bwd_vq_f32), the plain
