@@ -171,6 +171,11 @@ int lipvq_tokenize_train_f32(const float* x, const float* packed, const float* c
 int lipvq_vq_tokenize_f32(const float* x, const float* packed, const float* codebook, const void* prep, int64_t* idx,
                           float* zq, int64_t* usage, float* ze_out, void* workspace, int64_t N, int A, int J0, int J1, int D,
                           int K, void* stream);
+/* The same launch as the forward half of a VQVAE training step: also stores the three pre-activations pre0 [N][J0], pre1 [N][J1],
+ * pre2 [N][D] (16-byte aligned) that lipvq_mlp3_bwd_f32 consumes -- bit for bit what lipvq_mlp3_f32 would save. */
+int lipvq_vq_tokenize_train_f32(const float* x, const float* packed, const float* codebook, const void* prep, int64_t* idx,
+                                float* zq, int64_t* usage, float* ze_out, float* pre0, float* pre1, float* pre2, void* workspace,
+                                int64_t N, int A, int J0, int J1, int D, int K, void* stream);
 
 /* ---- fast mode (opt-in): the encoder's three GEMMs on fp16 MFMAs with fp32 accumulation -- the half-precision
  * encoder of BASELINE.json's config 2 / SURVEY section 7.  NOT bit-identical to lipvq_tokenize_f32: a fraction of a

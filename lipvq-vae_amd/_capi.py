@@ -56,6 +56,7 @@ SIGNATURES = {
     "lipvq_tokenize_workspace_bytes": (_sz, [_i64, _i]),
     "lipvq_tokenize_f32": (_i, [_vp] * 10 + [_i64] + [_i] * 5 + [_vp]),
     "lipvq_vq_tokenize_f32": (_i, [_vp] * 9 + [_i64] + [_i] * 5 + [_vp]),
+    "lipvq_vq_tokenize_train_f32": (_i, [_vp] * 12 + [_i64] + [_i] * 5 + [_vp]),
     "lipvq_tokenize_train_f32": (_i, [_vp] * 13 + [_i64] + [_i] * 5 + [_vp]),
     "lipvq_mlp3_packed_f16_bytes": (_sz, [_i] * 4),
     "lipvq_mlp3_pack_f16_f32": (_i, [_vp] * 4 + [_i] * 4 + [_vp]),

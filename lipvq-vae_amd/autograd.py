@@ -122,7 +122,10 @@ class _VQFn(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad[2:])
         big = x.shape[0] > module.EXACT_ROWS_MAX and module.num_embeddings >= module.FUSED_MIN_CODES
         screen = module._screen_monitor.use_screen() if big else None          # one routing decision per call
-        if need_grad:
+        if need_grad and big and screen and module.fused_shape():
+            # large training batches: encoder + quantizer + the saved pre-activations in ONE launch (lipvq_vq_tokenize_train_f32)
+            idx, z_q, z_e, pre_e = module._tokenize_fused(x, module.code_usage, want_pre=True)
+        elif need_grad:
             z_e, pre_e = ops.mlp3(x, enc_packed, _RELU3, save_pre=True)
             idx, z_q = module._quantize(z_e, module.code_usage, screen=screen)  # vq:57-66 (screened / exact rows / all-pairs: same results)
         elif big and screen and module.fused_shape():

@@ -147,7 +147,7 @@ struct TokArgs {
 template <int S, bool FAST, bool TRAIN, int RG, int WAVES, bool COARSE = false, bool VQ = false>
 __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
     static_assert(!(FAST && TRAIN), "training uses the parity arithmetic");
-    static_assert(!VQ || (RG == 1 && !FAST && !TRAIN), "the ReLU instance: one row group, parity arithmetic, no training stores");
+    static_assert(!VQ || (RG == 1 && !FAST), "the ReLU instance: one row group, parity arithmetic");
     static_assert(RG == 1 || RG == 2, "one or two row groups per wave");
     constexpr int THREADS = WAVES * 64;
     constexpr int TCF = fused_ring_tc(S), NBF = fused_ring_nb(S);
@@ -893,7 +893,11 @@ template <int S>
 static int launch_tokenize_vq(const TokArgs& a, hipStream_t st) {
     const size_t lds = fused_lds_bytes<S, false>(a.A, a.K);
     if (lds > 160 * 1024) return fail(LIPVQ_EUNSUPPORTED, "vq_tokenize: %zu B of LDS needed", lds);
-    static LqLdsReserve reserved[2];
+    static LqLdsReserve reserved[4];
+    if (a.pre0) {                                              // the training forward: the three pre-activations are stored too
+        if (a.coarse) return launch_tokenize_as(tokenize_kernel<S, false, true, 1, true, true>, reserved[3], a, lds, 8, 1, st);
+        return launch_tokenize_as(tokenize_kernel<S, false, true, 1, false, true>, reserved[2], a, lds, 8, 1, st);
+    }
     if (a.coarse) return launch_tokenize_as(tokenize_kernel<S, false, false, 1, true, true>, reserved[1], a, lds, 8, 1, st);
     return launch_tokenize_as(tokenize_kernel<S, false, false, 1, false, true>, reserved[0], a, lds, 8, 1, st);
 }
@@ -1069,9 +1073,9 @@ extern "C" int lipvq_tokenize_train_f32(const float* x, const float* packed, con
 // plain weights); prep: lipvq_nearest_prepare_f32 of the embedding table; ze_out [N][D] is REQUIRED (the straight-through value
 // z_e + (z_q - z_e) of vq:74 needs it, and so does the exact stage).  Same results as lipvq_mlp3_f32(relu, relu, relu) followed by
 // lipvq_nearest_f32(LIPVQ_DIST_SQSUM).  workspace: lipvq_tokenize_workspace_bytes(N, D).
-extern "C" int lipvq_vq_tokenize_f32(const float* x, const float* packed, const float* codebook, const void* prep, int64_t* idx,
-                                     float* zq, int64_t* usage, float* ze_out, void* workspace, int64_t N, int A, int J0, int J1,
-                                     int D, int K, void* stream) {
+static int vq_tokenize_impl(const float* x, const float* packed, const float* codebook, const void* prep, int64_t* idx,
+                            float* zq, int64_t* usage, float* ze_out, float* pre0, float* pre1, float* pre2, void* workspace, int64_t N,
+                            int A, int J0, int J1, int D, int K, void* stream) {
     if (N < 0) return fail(LIPVQ_EINVAL, "vq_tokenize: N < 0");
     if (N == 0) return LIPVQ_OK;
     if (!x || !packed || !codebook || !prep || !idx || !ze_out || !workspace) return fail(LIPVQ_EINVAL, "vq_tokenize: null pointer");
@@ -1095,7 +1099,7 @@ extern "C" int lipvq_vq_tokenize_f32(const float* x, const float* packed, const 
     }
     const int coarse = lq_screen_coarse(lq_screen_S(D), K);
     TokArgs a{x, packed, nullptr, (const unsigned char*)prep, codebook, idx, zq, (unsigned long long*)usage, ze_out, amb_count,
-              amb_list, w2q, nullptr, nullptr, nullptr, N, A, D, K, LIPVQ_SCREEN_GAMMA, coarse};
+              amb_list, w2q, pre0, pre1, pre2, N, A, D, K, LIPVQ_SCREEN_GAMMA, coarse};
     int rc;
     switch (D) {
         case 32: rc = launch_tokenize_vq<2>(a, st); break;
@@ -1105,6 +1109,23 @@ extern "C" int lipvq_vq_tokenize_f32(const float* x, const float* packed, const 
     }
     if (rc) return rc;
     return lipvq_launch_rows(ze_out, 0, codebook, idx, zq, usage, amb_list, amb_count, N, K, D, st, LIPVQ_DIST_SQSUM);
+}
+
+extern "C" int lipvq_vq_tokenize_f32(const float* x, const float* packed, const float* codebook, const void* prep, int64_t* idx,
+                                     float* zq, int64_t* usage, float* ze_out, void* workspace, int64_t N, int A, int J0, int J1,
+                                     int D, int K, void* stream) {
+    return vq_tokenize_impl(x, packed, codebook, prep, idx, zq, usage, ze_out, nullptr, nullptr, nullptr, workspace, N, A, J0, J1, D, K,
+                            stream);
+}
+
+// The training forward of the plain VQVAE in one launch: lipvq_vq_tokenize_f32 that also stores the three pre-activations
+// [N][J0], [N][J1], [N][D] its backward needs (what lipvq_mlp3_f32 with pre0..2 would save, bit for bit).
+extern "C" int lipvq_vq_tokenize_train_f32(const float* x, const float* packed, const float* codebook, const void* prep, int64_t* idx,
+                                           float* zq, int64_t* usage, float* ze_out, float* pre0, float* pre1, float* pre2,
+                                           void* workspace, int64_t N, int A, int J0, int J1, int D, int K, void* stream) {
+    if (N > 0 && (!pre0 || !pre1 || !pre2)) return fail(LIPVQ_EINVAL, "vq_tokenize_train: the three pre-activation buffers are required");
+    if ((((uintptr_t)pre0 | (uintptr_t)pre1 | (uintptr_t)pre2) & 15) != 0) return fail(LIPVQ_EINVAL, "vq_tokenize_train: pre0..2 must be 16-byte aligned");
+    return vq_tokenize_impl(x, packed, codebook, prep, idx, zq, usage, ze_out, pre0, pre1, pre2, workspace, N, A, J0, J1, D, K, stream);
 }
 
 // Fast mode: the encoder's GEMMs on fp16 MFMAs (packed16 = lipvq_mlp3_pack_f16_f32 of the same weights; `packed` still

@@ -579,10 +579,11 @@ def tokenize(x, packed: PackedMlp3, raw, codebook, prep: PreparedCodebook, usage
     return idx, zq, ze, ws
 
 
-def vq_tokenize(x, packed: PackedMlp3, codebook, prep: PreparedCodebook, usage=None, workspace=None):
+def vq_tokenize(x, packed: PackedMlp3, codebook, prep: PreparedCodebook, usage=None, workspace=None, want_pre=False):
     """(idx, zq, ze, workspace) of the plain VQVAE's fused encode + quantize launch (lipvq_vq_tokenize_f32: ReLU encoder,
     `pow(2).sum(-1)` argmin): the same results as mlp3(relu x 3) + nearest(DIST_SQSUM).  z_e is always returned (the
-    straight-through value needs it)."""
+    straight-through value needs it).  want_pre: (idx, zq, ze, [pre0, pre1, pre2], workspace) -- the training forward,
+    lipvq_vq_tokenize_train_f32."""
     x, codebook = _chk(x, "x"), _chk(codebook, "codebook")
     N, A = x.shape
     K, D = codebook.shape
@@ -595,6 +596,13 @@ def vq_tokenize(x, packed: PackedMlp3, codebook, prep: PreparedCodebook, usage=N
     zq = torch.empty((N, D), device=dev, dtype=torch.float32)
     ze = torch.empty((N, D), device=dev, dtype=torch.float32)
     ws = workspace if workspace is not None else tokenize_workspace(N, D, dev)
+    if want_pre:
+        pre = [torch.empty((N, J), device=dev, dtype=torch.float32) for J in (packed.J0, packed.J1, D)]
+        with _on(dev):
+            check(lib.lipvq_vq_tokenize_train_f32(_ptr(x), _ptr(packed.buf), _ptr(codebook), _ptr(prep.buf), _ptr(idx), _ptr(zq),
+                                                  _ptr(usage), _ptr(ze), _ptr(pre[0]), _ptr(pre[1]), _ptr(pre[2]), _ptr(ws), N, A,
+                                                  packed.J0, packed.J1, D, K, _stream()), "lipvq_vq_tokenize_train_f32")
+        return idx, zq, ze, pre, ws
     with _on(dev):
         check(lib.lipvq_vq_tokenize_f32(_ptr(x), _ptr(packed.buf), _ptr(codebook), _ptr(prep.buf), _ptr(idx), _ptr(zq), _ptr(usage),
                                         _ptr(ze), _ptr(ws), N, A, packed.J0, packed.J1, D, K, _stream()), "lipvq_vq_tokenize_f32")

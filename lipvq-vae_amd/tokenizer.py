@@ -395,18 +395,23 @@ class VQVAE(_TokenizerBase):
     def fused_shape(self) -> bool:
         return ops.tokenize_supported(self.feature_dim, 64, 128, self.latent_dim, self.num_embeddings)
 
-    def _tokenize_fused(self, x, usage):
+    def _tokenize_fused(self, x, usage, want_pre=False):
         """(idx, z_q, z_e) from ONE persistent launch (lipvq_vq_tokenize_f32: the fused kernel's ReLU instance, per-row fp16
-        scales): encoder + screen, then the exact stage for the rows the screen leaves."""
+        scales): encoder + screen, then the exact stage for the rows the screen leaves.  want_pre: (idx, z_q, z_e, pre) with the
+        three pre-activations a training step saves (lipvq_vq_tokenize_train_f32)."""
         cb = self.embedding.weight.detach()
         prep = self._cb_cache.get((self.embedding.weight,), lambda: ops.nearest_prepare(cb))
         key = (x.shape[0], x.device)
         if self._tok_ws_key != key:
             self._tok_ws, self._tok_ws_key = ops.tokenize_workspace(x.shape[0], self.latent_dim, x.device), key
-        idx, zq, ze, ws = ops.vq_tokenize(x, self._packed_encoder(), cb, prep, usage=usage, workspace=self._tok_ws)
+        pre = None
+        if want_pre:
+            idx, zq, ze, pre, ws = ops.vq_tokenize(x, self._packed_encoder(), cb, prep, usage=usage, workspace=self._tok_ws, want_pre=True)
+        else:
+            idx, zq, ze, ws = ops.vq_tokenize(x, self._packed_encoder(), cb, prep, usage=usage, workspace=self._tok_ws)
         self.last_exact_rows = ws
         self._screen_monitor.record(ws, x.shape[0], ops.screen_is_coarse(cb.shape[0], cb.shape[1]))
-        return idx, zq, ze
+        return (idx, zq, ze, pre) if want_pre else (idx, zq, ze)
 
     @torch.no_grad()
     def tokenize(self, x, count_usage=True):

@@ -19,7 +19,9 @@ if kind == "llfq":
     model = LLFQVAE_V4(A, D, num_codes=K).cuda()
     trained_like_(model, A)
 else:
-    model = VQVAE(A, D, num_embeddings=128).cuda()
+    model = VQVAE(A, D, num_embeddings=int(os.environ.get("VQ_K", "128"))).cuda()
+    if os.environ.get("LIPVQ_VQ_TRAIN_UNFUSED") == "1":
+        VQVAE.fused_shape = lambda self: False
 opt = (torch.optim.AdamW if os.environ.get('LIPVQ_TORCH_ADAMW') == '1' else AdamW)(model.parameters(), lr=1e-3, weight_decay=1e-4)
 x = torch.randn(N, A, device="cuda")
 def step():
@@ -36,4 +38,5 @@ for rep in range(3):
     for _ in range(20): step()
     e1.record(); torch.cuda.synchronize()
     best.append(e0.elapsed_time(e1) / 20)
-print(f"{kind} train step N={N} A={A} D={D} K={K}: " + " / ".join(f"{b:.3f}" for b in best) + " ms" + ("  (separate scaled_diff launches)" if os.environ.get("LIPVQ_NO_FOLD") == "1" else "  (folded terms)"))
+print(f"{kind} train step N={N} A={A} D={D} K={K if kind == 'llfq' else model.num_embeddings}: " + " / ".join(f"{b:.3f}" for b in best) + " ms" + ("  (separate scaled_diff launches)" if os.environ.get("LIPVQ_NO_FOLD") == "1" else "  (folded terms)")
+      + (" unfused training forward" if kind != "llfq" and os.environ.get("LIPVQ_VQ_TRAIN_UNFUSED") == "1" else ""))

@@ -216,6 +216,46 @@ def test_decoder_launch_with_folded_loss_equals_separate_launches(oracle, N, A, 
     assert abs(loss_s.item() - f["loss"]) <= 1e-5 * abs(f["loss"])
 
 
+@pytest.mark.parametrize("screen", ["fine", "coarse"])
+@pytest.mark.parametrize("N,A,D,K", [(5000, 7, 64, 128), (2100, 12, 208, 1024), (3000, 7, 32, 256), (2500, 12, 128, 1000)])
+def test_vq_training_forward_launch_equals_unfused(monkeypatch, N, A, D, K, screen):
+    """lipvq_vq_tokenize_train_f32 (the plain VQVAE's encoder + quantizer + saved pre-activations, one launch) against
+    lipvq_mlp3_f32(relu x 3, saved pre-activations) + the stand-alone quantizer, bit for bit; and the module's gradients at a batch
+    that takes this route equal the ones the unfused route gives."""
+    from lipvq_vae_amd import ops
+    from lipvq_vae_amd.autograd import _RELU3
+    from lipvq_vae_amd.tokenizer import VQVAE
+    monkeypatch.setenv("LIPVQ_SCREEN_MODE", screen)
+    monkeypatch.setenv("LIPVQ_SCREEN_MONITOR", "0")
+    torch.manual_seed(N + D)
+    model = VQVAE(A, D, num_embeddings=K).cuda()
+    with torch.no_grad():
+        model.embedding.weight.uniform_(0.0, 0.5)
+    model.invalidate_caches()
+    xt = torch.from_numpy(O.make_inputs(N + 1, N, A)).cuda()
+    idx, zq, ze, pre = model._tokenize_fused(xt, None, want_pre=True)
+    ze_u, pre_u = ops.mlp3(xt, model._packed_encoder(), _RELU3, save_pre=True)
+    idx_u, zq_u = model._quantize(ze_u, None)
+    assert torch.equal(ze, ze_u) and torch.equal(idx, idx_u) and torch.equal(zq, zq_u)
+    for a, b in zip(pre, pre_u):
+        assert a.shape == b.shape and torch.equal(a, b)
+    assert N > model.EXACT_ROWS_MAX and K >= model.FUSED_MIN_CODES
+    calls = []
+    real = ops.lib.lipvq_vq_tokenize_train_f32
+    monkeypatch.setattr(ops.lib, "lipvq_vq_tokenize_train_f32", lambda *a: (calls.append(1), real(*a))[1])
+    z1, loss = model(xt)
+    loss.backward()
+    assert calls == [1]                                        # the module's training forward took the fused launch
+    g_fused = {k: v.grad.clone() for k, v in model.named_parameters()}
+    model.zero_grad()
+    monkeypatch.setattr(type(model), "fused_shape", lambda self: False)
+    z2, loss2 = model(xt)
+    loss2.backward()
+    assert calls == [1] and torch.equal(z1, z2) and loss.item() == loss2.item()
+    for k, v in model.named_parameters():             # (same inputs to the same backward; the embedding's scatter uses fp32 atomics at this size)
+        assert torch.allclose(g_fused[k], v.grad, rtol=0, atol=1e-5 * max(1e-12, float(v.grad.abs().max()))), k
+
+
 @pytest.mark.parametrize("with_g", [True, False])
 @pytest.mark.parametrize("N,D,K,det", [(70001, 64, 1024, False), (66000, 208, 1000, False), (40000, 64, 128, True), (131072, 32, 37, True)])
 def test_scatter_with_rows_formed_in_kernel_equals_scaled_diff_then_scatter(N, D, K, det, with_g):
