@@ -186,6 +186,31 @@ def test_graphed_training_step_after_eager_training_equals_eager_trajectory(orac
         g.step(xs[0][:40])
 
 
+def test_graphed_training_step_at_a_large_batch_equals_eager(oracle):
+    """The same capture at a batch that takes the large-batch routes (fused training forward with the screened quantizer, the loss
+    summed by the decoder launch, the loss-gradient terms formed inside the backward chain and the counting-sort scatter, workspace
+    memsets as graph nodes): three replays leave the parameters bit-identical to three eager steps of a twin."""
+    import copy
+    from lipvq_vae_amd.icl import GraphedTokenizerStep, VQTokenizerTrainer
+    from lipvq_vae_amd.tokenizer import LLFQVAE_V4
+    A, D, K, N = 7, 64, 1024, 66000
+    p = O.make_params(78, A, D, K, oracle=oracle)
+    model = LLFQVAE_V4(A, D, num_codes=K).cuda()
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in p.items()})
+    twin = copy.deepcopy(model)
+    twin.invalidate_caches()
+    tr, tw = VQTokenizerTrainer(model), VQTokenizerTrainer(twin)
+    xs = [torch.from_numpy(O.make_inputs(400 + i, N, A)).cuda() for i in range(4)]
+    g = GraphedTokenizerStep(model, xs[0], optimizer_state=tr.vq_optimizer.state_dict(), warmup=2)
+    for i in range(1, 4):
+        _, loss = g.step(xs[i])
+        _, ref_loss = tw.train_on_actions(xs[i])
+        assert float(loss) == float(ref_loss), i
+    torch.cuda.synchronize()
+    for (k, a), (_, b) in zip(model.state_dict().items(), twin.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
 def test_backward_refuses_parameters_changed_since_forward(oracle):
     from lipvq_vae_amd.tokenizer import LLFQVAE_V4
     p = O.make_params(5, 7, 32, 128, oracle=oracle)
