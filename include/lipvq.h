@@ -121,6 +121,17 @@ int lipvq_nearest_screened_f32(const float* z, const float* codebook, const void
  * changes every step).  Any D (tuned instances for 32 / 64 / 128 / 208, a generic kernel otherwise). */
 int lipvq_nearest_rows_f32(const float* z, const float* codebook, int64_t* idx, float* zq, int64_t* usage, int64_t N,
                            int K, int D, void* stream);
+
+/* The same decision for SMALL batches (the reference's training step and rollouts: B*T = 1 ... a few hundred rows) with the
+ * whole chip busy: a workgroup scores 4 rows against 64 codes staged in LDS, the grid is (row groups) x (code groups), a row's
+ * partial minima meet behind a counter.  dist: LIPVQ_DIST_NORM | LIPVQ_DIST_SQSUM.  Identical idx / zq / usage.
+ * lipvq_nearest_small_supported: N <= 4096, D a multiple of 4 whose LDS image fits (D <= 240).
+ * workspace: lipvq_nearest_small_workspace_bytes(N, K) bytes, 16-byte aligned, ZERO on entry; the call leaves it zero (one
+ * zero-filled buffer serves every later call on a stream, whatever its shape). */
+int lipvq_nearest_small_supported(int64_t N, int K, int D);
+size_t lipvq_nearest_small_workspace_bytes(int64_t N, int K);
+int lipvq_nearest_small_f32(const float* z, const float* codebook, int64_t* idx, float* zq, int64_t* usage, void* workspace,
+                            int64_t N, int K, int D, int dist, void* stream);
 /* The plain VQVAE's quantizer (reference robomimic/models/vq_vae/backbone.py:55-63: `(z_e.unsqueeze(1) - E).pow(2).sum(-1)`,
  * argmin) through the same two routes: idx / zq / usage exactly as lipvq_nearest_f32(.., LIPVQ_DIST_SQSUM).  The screen is the
  * same certified MFMA screen (its margin covers the sum rule's rounding too); uncertified rows are decided by the exact kernel in

@@ -55,6 +55,9 @@ SIGNATURES = {
     "lipvq_tokenize_fast_supported": (_i, [_i] * 5),
     "lipvq_tokenize_workspace_bytes": (_sz, [_i64, _i]),
     "lipvq_tokenize_f32": (_i, [_vp] * 10 + [_i64] + [_i] * 5 + [_vp]),
+    "lipvq_nearest_small_supported": (_i, [_i64, _i, _i]),
+    "lipvq_nearest_small_workspace_bytes": (_sz, [_i64, _i]),
+    "lipvq_nearest_small_f32": (_i, [_vp] * 6 + [_i64, _i, _i, _i, _vp]),
     "lipvq_vq_tokenize_f32": (_i, [_vp] * 9 + [_i64] + [_i] * 5 + [_vp]),
     "lipvq_vq_tokenize_train_f32": (_i, [_vp] * 12 + [_i64] + [_i] * 5 + [_vp]),
     "lipvq_tokenize_train_f32": (_i, [_vp] * 13 + [_i64] + [_i] * 5 + [_vp]),

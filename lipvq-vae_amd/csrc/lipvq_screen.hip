@@ -817,6 +817,192 @@ __global__ __launch_bounds__(256) void nearest_rows1_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------
+// Small batches (the reference's training step and its rollouts: B*T = 1 ... a few hundred rows), every row decided exactly,
+// spread over the whole chip (round 3).  nearest_rows1_kernel gives a row to ONE workgroup, whose 256 threads each walk their
+// own code rows: every wave-level load touches 64 different lines, the CU's address unit serialises them, and the row's
+// 852 KB of codebook (K = 1024, D = 208) pass through one CU's L1 -- 30 us for 80 rows, the largest node of the graphed step.
+// Here a workgroup owns 4 rows x 64 codes: the 64 code rows are staged ONCE into LDS with coalesced 16-byte loads (row stride
+// D + 1 floats: the column reads of the scoring loop hit 32 different banks), wave w scores row w against them -- lane = code,
+// z read as LDS broadcasts, lq_sqdist8 / lq_sqdist32: torch's orders -- and the grid is (row groups) x (code groups):
+// 20 x 16 = 320 workgroups at N = 80, K = 1024.  A row's code-group minima meet in one 64-bit atomic per row; the workgroup that
+// arrives last at the row group's counter reads the winners, writes idx / z_q, counts the usage and puts keys and counter back to
+// zero (the workspace is zero between launches).  Any width that is a multiple of 4 and fits the LDS image.
+// ------------------------------------------------------------------------------------------
+#define NSM_ROWS 4
+#define NSM_CODES 64
+
+static inline size_t nsm_lds_bytes(int D) { return ((size_t)NSM_CODES * (D + 1) + (size_t)NSM_ROWS * D) * sizeof(float); }
+static inline int nsm_code_groups(int K) { return (K + NSM_CODES - 1) / NSM_CODES; }
+#define NSM_MAX_ROWS 4096
+// the counters take a FIXED 4 KB at the head of the workspace (one int per row group of the largest batch): a buffer that served one
+// shape serves any other -- no call's partial minima ever lie where another call's counters do
+static inline size_t nsm_counter_bytes(int64_t) { return (size_t)(NSM_MAX_ROWS / NSM_ROWS) * sizeof(int); }
+
+// DT: the width at compile time (the scoring loop unrolls: its LDS reads are requested in batches instead of one wait per pair --
+// with a runtime width the kernel was latency-bound, 40 us for 80 rows), or 0 for any other width
+template <int DIST, int DT>
+__global__ __launch_bounds__(256) void nearest_small_kernel(const float* __restrict__ z, const float* __restrict__ cb,
+                                                            int64_t* __restrict__ idx, float* __restrict__ zq,
+                                                            unsigned long long* __restrict__ usage, int count, int K, int D_rt, int CG,
+                                                            int* __restrict__ counters, unsigned long long* __restrict__ keys) {
+    extern __shared__ __attribute__((aligned(16))) float nsm_lds[];
+    __shared__ int s_last;
+    const int D = DT ? DT : D_rt;
+    const int LD = D + 1;
+    float* s_z = nsm_lds;                                     // [NSM_ROWS][D], 16-byte aligned rows (D % 4 == 0)
+    float* s_cb = nsm_lds + NSM_ROWS * D;                     // [NSM_CODES][D + 1]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int rg = blockIdx.x / CG, cg = blockIdx.x - rg * CG;
+    const int D4 = D >> 2;
+    // consecutive threads: consecutive 16-byte pieces of consecutive code rows.  With the width known every piece is REQUESTED before
+    // the first one is written (a loop of load -> LDS write paid one L2 round trip per pass: 13 at D = 208, most of the kernel)
+    float4 zv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < NSM_ROWS * D4) {
+        const int r = tid / D4, q = tid - r * D4;
+        int row = rg * NSM_ROWS + r;
+        row = row < count ? row : count - 1;
+        zv = reinterpret_cast<const float4*>(z + (size_t)row * D)[q];
+    }
+    if constexpr (DT != 0) {
+        constexpr int PIECES = NSM_CODES * (DT / 4), NIT = (PIECES + 255) / 256;
+        float4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + 256 * it;
+            const int c = i / (DT / 4), q = i - c * (DT / 4);
+            const int k = cg * NSM_CODES + c;
+            v[it] = (i < PIECES && k < K) ? reinterpret_cast<const float4*>(cb + (size_t)k * DT)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + 256 * it;
+            const int c = i / (DT / 4), q = i - c * (DT / 4);
+            if (i < PIECES) {
+                float* dst = s_cb + c * LD + 4 * q;
+                dst[0] = v[it].x; dst[1] = v[it].y; dst[2] = v[it].z; dst[3] = v[it].w;
+            }
+        }
+    } else {
+        for (int i = tid; i < NSM_CODES * D4; i += 256) {
+            const int c = i / D4, q = i - c * D4;
+            const int k = cg * NSM_CODES + c;
+            const float4 v = k < K ? reinterpret_cast<const float4*>(cb + (size_t)k * D)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float* dst = s_cb + c * LD + 4 * q;
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+    }
+    if (tid < NSM_ROWS * D4) reinterpret_cast<float4*>(s_z)[tid] = zv;
+    __syncthreads();
+    const int row = rg * NSM_ROWS + w;
+    const bool valid = row < count;
+    int bk = cg * NSM_CODES + lane;
+    float bv = INFINITY;
+    if (bk < K) {
+        const float* zr = s_z + w * D;
+        const float* c = s_cb + lane * LD;
+        float v;
+        if constexpr (DIST == LIPVQ_DIST_NORM && DT != 0) {
+            // lq_sqdist8's order for a multiple of 8 (accumulator j takes the dimensions j mod 8, then ((((((a0+a1)+a2)+a3)+a4)+a5)+a6)+a7),
+            // written out so that it unrolls over the whole width
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+#pragma unroll
+            for (int i = 0; i < DT; i += 8) {
+                const float4 zl = *reinterpret_cast<const float4*>(zr + i), zh = *reinterpret_cast<const float4*>(zr + i + 4);
+                const float d0 = zl.x - c[i + 0], d1 = zl.y - c[i + 1], d2 = zl.z - c[i + 2], d3 = zl.w - c[i + 3];
+                const float d4 = zh.x - c[i + 4], d5 = zh.y - c[i + 5], d6 = zh.z - c[i + 6], d7 = zh.w - c[i + 7];
+                a0 = lq_fma(d0, d0, a0); a1 = lq_fma(d1, d1, a1); a2 = lq_fma(d2, d2, a2); a3 = lq_fma(d3, d3, a3);
+                a4 = lq_fma(d4, d4, a4); a5 = lq_fma(d5, d5, a5); a6 = lq_fma(d6, d6, a6); a7 = lq_fma(d7, d7, a7);
+            }
+            v = lq_sqrt(((((((a0 + a1) + a2) + a3) + a4) + a5) + a6) + a7);
+        } else {
+            v = (DIST == LIPVQ_DIST_NORM) ? lq_sqrt(lq_sqdist8(zr, c, D)) : lq_sqdist32(zr, c, D);
+        }
+        if (v < INFINITY) bv = v;                             // (a NaN or an overflowed distance never wins: the other kernels' `v < best`)
+    } else {
+        bk = K - 1;
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {                  // smallest value, among equal values the lower code
+        const float ov = __shfl_xor(bv, off, 64);
+        const int ok = __shfl_xor(bk, off, 64);
+        if (ov < bv || (ov == bv && ok < bk)) { bv = ov; bk = ok; }
+    }
+    if (CG > 1) {
+        // (value, code) as one 64-bit key whose order is the decision rule -- smaller value first, among equal values the lower code
+        // (values are non-negative floats: their bit patterns order like the numbers) -- kept COMPLEMENTED, so that "nothing yet" is
+        // the zero the workspace rests at.  Device-scope atomics only, no fence: a release/acquire pair at agent scope writes back and
+        // invalidates the XCD's L2 on this chip -- with __threadfence() around plain stores this kernel took 35 us at 80 rows and
+        // 225 us at 500.  The wave waits for its atomic's return before the barrier, so the key is in place before the count.
+        if (lane == 0 && valid) {
+            const unsigned long long key = ~(((unsigned long long)__float_as_uint(bv) << 32) | (unsigned int)bk);
+            const unsigned long long old = atomicMax(&keys[row], key);
+            asm volatile("" ::"v"((unsigned int)old));
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const int old = atomicAdd(&counters[rg], 1);
+            s_last = old == CG - 1;
+        }
+        __syncthreads();
+        if (!s_last) return;                                  // (workgroup-uniform)
+        if (tid == 0) atomicExch(&counters[rg], 0);           // zero between launches
+        unsigned long long fin = 0ull;
+        if (lane == 0 && valid) fin = ~atomicExch(&keys[row], 0ull);
+        bk = __builtin_amdgcn_readfirstlane((int)(unsigned int)(fin & 0xffffffffull));
+    }
+    if (!valid) return;                                       // (wave-uniform)
+    if (lane == 0) {
+        idx[row] = (int64_t)bk;
+        if (usage) atomicAdd(&usage[bk], 1ull);
+    }
+    if (zq)
+        for (int q = lane; q < D4; q += 64)
+            reinterpret_cast<float4*>(zq + (size_t)row * D)[q] = reinterpret_cast<const float4*>(cb + (size_t)bk * D)[q];
+}
+
+extern "C" int lipvq_nearest_small_supported(int64_t N, int K, int D) {
+    return N >= 1 && N <= NSM_MAX_ROWS && K >= 1 && K <= 65536 && D >= 4 && (D & 3) == 0 && nsm_lds_bytes(D) <= 64 * 1024 ? 1 : 0;
+}
+
+extern "C" size_t lipvq_nearest_small_workspace_bytes(int64_t N, int K) {
+    if (N <= 0 || K <= 0) return 0;
+    return nsm_counter_bytes(N) + (size_t)N * sizeof(unsigned long long);
+}
+
+// workspace: lipvq_nearest_small_workspace_bytes(N, K) bytes (4096 of counters + one 64-bit key per row), ZERO on entry; the call
+// leaves it zero, so that one zero-filled buffer serves every later call on the same stream, whatever its shape.
+extern "C" int lipvq_nearest_small_f32(const float* z, const float* codebook, int64_t* idx, float* zq, int64_t* usage, void* workspace,
+                                       int64_t N, int K, int D, int dist, void* stream) {
+    if (N < 0 || K <= 0) return fail(LIPVQ_EINVAL, "nearest_small: bad sizes");
+    if (N == 0) return LIPVQ_OK;
+    if (!z || !codebook || !idx || !workspace) return fail(LIPVQ_EINVAL, "nearest_small: null pointer");
+    if (dist != LIPVQ_DIST_NORM && dist != LIPVQ_DIST_SQSUM) return fail(LIPVQ_EINVAL, "nearest_small: unknown distance rule %d", dist);
+    if (!lipvq_nearest_small_supported(N, K, D))
+        return fail(LIPVQ_EUNSUPPORTED, "nearest_small: N=%lld K=%d D=%d (lipvq_nearest_small_supported)", (long long)N, K, D);
+    if ((((uintptr_t)z | (uintptr_t)codebook | (uintptr_t)zq | (uintptr_t)workspace) & 15) != 0)
+        return fail(LIPVQ_EINVAL, "nearest_small: z, codebook, zq and workspace must be 16-byte aligned");
+    const int CG = nsm_code_groups(K);
+    const int RGn = (int)((N + NSM_ROWS - 1) / NSM_ROWS);
+    int* counters = (int*)workspace;
+    unsigned long long* keys = (unsigned long long*)((unsigned char*)workspace + nsm_counter_bytes(N));
+    const size_t lds = nsm_lds_bytes(D);
+    auto go = [&](auto kfn) {
+        hipLaunchKernelGGL(kfn, dim3((unsigned)(RGn * CG)), dim3(256), lds, (hipStream_t)stream, z, codebook, idx, zq,
+                           (unsigned long long*)usage, (int)N, K, D, CG, counters, keys);
+    };
+#define LQ_NSM(DT_) do { if (dist == LIPVQ_DIST_NORM) go(nearest_small_kernel<LIPVQ_DIST_NORM, DT_>); else go(nearest_small_kernel<LIPVQ_DIST_SQSUM, DT_>); } while (0)
+    switch (D) {
+        case 32: LQ_NSM(32); break;
+        case 64: LQ_NSM(64); break;
+        case 128: LQ_NSM(128); break;
+        case 208: LQ_NSM(208); break;
+        default: LQ_NSM(0); break;
+    }
+#undef LQ_NSM
+    return check_launch("nearest_small");
+}
+
+// ------------------------------------------------------------------------------------------
 // exact decision for listed rows WITHOUT a stored z_e: the workgroup first recomputes z_e of its 4 rows from x
 // (encoder + Lipschitz layer as plain fp32 fmaf chains in natural k order, bias first, odd fan-in padded with one
 // zero term -- the canonical arithmetic, hence the same bits the MFMA path produced), then runs the search above.

@@ -443,9 +443,25 @@ def nearest_prepare(codebook: torch.Tensor) -> PreparedCodebook:
     return PreparedCodebook(buf, K, D)
 
 
-def nearest_rows(z, codebook, usage=None, want_zq=True, dist: int = DIST_NORM):
-    """(idx, zq) exactly as nearest(z, codebook, dist), every row decided by the exact re-scoring kernel (no
-    prepared codebook): the route for small batches."""
+_small_ws: dict = {}          # (device index, stream handle) -> zero-at-rest workspace of lipvq_nearest_small_f32
+
+
+def _nearest_small_workspace(N, K, dev):
+    """The chip-wide small-batch kernel meets a row's partial minima behind per-row-group counters that are zero between
+    launches (the last workgroup resets them): one zero-filled buffer per (device, stream) serves every call -- no fill launch
+    per call, which matters where this route is used (a graphed training step is ~50 nodes of >= 4.6 us)."""
+    need = lib.lipvq_nearest_small_workspace_bytes(N, K)
+    key = (dev.index, _stream())
+    ws = _small_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _small_ws[key] = torch.zeros(max(need, 1 << 16), device=dev, dtype=torch.uint8)
+    return ws
+
+
+def nearest_rows(z, codebook, usage=None, want_zq=True, dist: int = DIST_NORM, route=None):
+    """(idx, zq) exactly as nearest(z, codebook, dist), every row decided by an exact kernel (no prepared codebook): the
+    route for small batches.  Up to 4 096 rows run lipvq_nearest_small_f32 (4 rows x 64 codes per workgroup, the whole chip
+    busy at 80 rows), larger ones the row kernels (route = "small" | "rows" forces one: tests, measurements)."""
     z, codebook = _chk(z, "z"), _chk(codebook, "codebook")
     N, D = z.shape
     K = codebook.shape[0]
@@ -453,8 +469,17 @@ def nearest_rows(z, codebook, usage=None, want_zq=True, dist: int = DIST_NORM):
         raise ValueError("nearest_rows: codebook width does not match")
     if usage is not None:
         usage = _chk(usage, "usage", torch.int64)
+    if dist not in (DIST_NORM, DIST_SQSUM):
+        raise ValueError(f"nearest_rows: unknown distance rule {dist}")
     idx = torch.empty(N, device=z.device, dtype=torch.int64)
     zq = torch.empty_like(z) if want_zq else None
+    small = bool(lib.lipvq_nearest_small_supported(N, K, D)) if route is None else route == "small"
+    if small and N > 0:
+        with _on(z.device):
+            ws = _nearest_small_workspace(N, K, z.device)
+            check(lib.lipvq_nearest_small_f32(_ptr(z), _ptr(codebook), _ptr(idx), _ptr(zq), _ptr(usage), _ptr(ws), N, K, D, int(dist),
+                                              _stream()), "lipvq_nearest_small_f32")
+        return idx, zq
     fn, name = ((lib.lipvq_nearest_rows_f32, "lipvq_nearest_rows_f32") if dist == DIST_NORM else
                 (lib.lipvq_vq_nearest_rows_f32, "lipvq_vq_nearest_rows_f32"))
     if dist not in (DIST_NORM, DIST_SQSUM):

@@ -425,3 +425,37 @@ def test_uncertified_rows_by_list_kind(ops, oracle, K, D):
     assert short >= 32 and lanes >= 32, (short, lanes, full, past)
     assert full == 0, "a finite codebook needs no full scans"
     assert past > 0, "list capacity (N/8 + 64 slots) was meant to be exceeded here"
+
+
+@pytest.mark.parametrize("dist", [O.DIST_NORM, O.DIST_SQSUM])
+@pytest.mark.parametrize("N,D,K", [(1, 64, 1024), (3, 208, 1024), (80, 208, 1024), (500, 208, 1000), (81, 64, 37), (4, 4, 1), (5, 20, 65),
+                                   (2048, 32, 256), (4096, 128, 2048), (77, 100, 8192), (130, 240, 513), (9, 64, 64)])
+def test_small_batch_kernel_equals_all_pairs(N, D, K, dist):
+    """lipvq_nearest_small_f32 (round 3: 4 rows x 64 codes per workgroup, partial minima per code group met behind a self-resetting
+    counter) against the all-pairs exact kernel: indices, z_q and usage, with duplicated codes inside one code group and across
+    code groups (first-minimum rule = the LOWER index), rows sitting on codes, a NaN row -- and a second launch on the same
+    workspace (the counters must be back at zero)."""
+    from lipvq_vae_amd import ops
+    gen = torch.Generator(device="cuda").manual_seed(N * 131 + D + K)
+    cb = torch.rand(K, D, device="cuda", generator=gen)
+    if K > 3:
+        cb[K - 1] = cb[0]                                      # equal codes far apart (different code groups when K > 64) ...
+        cb[2] = cb[1]                                          # ... and next to each other
+    z = torch.rand(N, D, device="cuda", generator=gen)
+    z[0] = cb[K - 1]                                           # sits on a duplicated code: index 0 must win
+    if N > 2:
+        z[1] = cb[min(2, K - 1)]
+        z[2, 0] = float("nan")
+    assert ops.lib.lipvq_nearest_small_supported(N, K, D)
+    ref_i, ref_q, _ = ops.nearest(z, cb, dist=dist)
+    for rep in range(2):
+        usage = torch.zeros(K, dtype=torch.int64, device="cuda")
+        idx, zq = ops.nearest_rows(z, cb, usage=usage, dist=dist, route="small")
+        assert torch.equal(idx, ref_i), rep
+        assert torch.equal(zq, ref_q)
+        assert torch.equal(usage, torch.bincount(ref_i, minlength=K))
+    ws = ops._small_ws[(z.device.index, ops._stream())]
+    assert int(ws.view(torch.int32).abs().sum()) == 0                          # counters and keys are zero at rest
+    idx_r, zq_r = ops.nearest_rows(z, cb, dist=dist, route="rows")              # the row kernels agree too
+    assert torch.equal(idx_r, ref_i) and torch.equal(zq_r, ref_q)
+
