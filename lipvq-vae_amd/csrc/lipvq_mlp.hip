@@ -309,7 +309,8 @@ __global__ __launch_bounds__(256) void mlp3_kernel(Mlp3Args a) {
 #define MLPS_LD 33
 
 #ifndef MLPS_PF
-#define MLPS_PF 8           // k-steps of packed weights in flight ahead of the MFMAs
+#define MLPS_PF 8           // k-steps of packed weights in flight ahead of the MFMAs (16 and 32 measure the same, round 3: at
+                            // N = 80 ... 2 048 the launch is its dependent MFMA chains + barriers, 17.5 us forward whatever the depth)
 #endif
 
 __device__ __forceinline__ void mlps_chain(const float* __restrict__ Pt, int S, const float* __restrict__ bp, f32x16& acc) {
