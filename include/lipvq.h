@@ -227,12 +227,15 @@ int lipvq_mlp3_bwd_f32(const float* gy, const float* pre0, const float* pre1, co
  *   out3[1] = mean((input rows - latent)^2)   latent [N][K0]   (input rows = x, or x[gather_idx[n]]: z_q against z_e)
  *   out3[2] = the loss, as lipvq_mse_pair_loss_f32 forms it from the two means (w, form)
  * summed in double by the kernel itself -- no second pass over the operands.  workspace: lipvq_mse_workspace_bytes().
+ * ste_out [N][K0], optional: the stack then runs on latent + (input rows - latent) -- the plain VQVAE's straight-through value
+ * z_e + (z_q - z_e).detach() of backbone.py:74, lipvq_ste_f32's two roundings -- and stores it there (out3[1] stays the mean over
+ * the rows as given: z_q against z_e).
  * Large batches on the reference's hidden widths only: lipvq_mlp3_loss_supported() (LIPVQ_EUNSUPPORTED otherwise). */
 int lipvq_mlp3_loss_supported(int64_t N, int K0, int J0, int J1, int J2);
 int lipvq_mlp3_loss_f32(const float* x, const int64_t* gather_idx, const float* packed, float* y, float* pre0, float* pre1,
                         float* pre2, int64_t N, int K0, int J0, int J1, int J2, int act0, int act1, int act2,
-                        const float* target, const float* latent, float* out3, float w, int form, void* workspace,
-                        void* stream);
+                        const float* target, const float* latent, float* ste_out, float* out3, float w, int form,
+                        void* workspace, void* stream);
 
 /* The same chain with the VQ losses' gradient terms folded in (what autograd derives from backbone_lfqvae_v5.py:79-83 /
  * backbone.py:69-74 next to the stack's own backward; three lipvq_scaled_diff_f32 launches per step otherwise):

@@ -69,7 +69,7 @@ SIGNATURES = {
     "lipvq_mlp3_pack_bwd2_f32": (_i, [_vp] * 4 + [_i] * 4 + [_vp] * 4 + [_i] * 4 + [_vp]),
     "lipvq_mlp3_bwd_f32": (_i, [_vp] * 9 + [_i64] + [_i] * 7 + [_vp]),
     "lipvq_mlp3_loss_supported": (_i, [_i64, _i, _i, _i, _i]),
-    "lipvq_mlp3_loss_f32": (_i, [_vp] * 7 + [_i64] + [_i] * 7 + [_vp] * 3 + [C.c_float, _i, _vp, _vp]),
+    "lipvq_mlp3_loss_f32": (_i, [_vp] * 7 + [_i64] + [_i] * 7 + [_vp] * 4 + [C.c_float, _i, _vp, _vp]),
     "lipvq_mlp3_bwd_vq_supported": (_i, [_i64, _i, _i, _i, _i]),
     "lipvq_mlp3_bwd_vq_f32": (_i, [_vp] * 9 + [_i64] + [_i] * 7 + [_vp] * 2 + [C.c_float] + [_vp] * 4 + [C.c_float, _vp, _vp]),
     "lipvq_wgrad_workspace_bytes": (_sz, [_i64, _i, _i]),

@@ -135,13 +135,20 @@ class _VQFn(torch.autograd.Function):
         else:
             z_e, pre_e = ops.mlp3(x, enc_packed, _RELU3), None
             idx, z_q = module._quantize(z_e, module.code_usage, screen=screen)
-        z_st = ops.ste(z_e, z_q)                                   # vq:74
-        if need_grad:
-            x_rec, pre_d = ops.mlp3(z_st, dec_packed, _RELU3, save_pre=True)
+        # q_loss = m1 + commitment_cost m1 (vq:69-71); loss = m0 + q_loss (vq:50-51): evaluated on the device
+        if ops.mlp3_loss_supported(x.shape[0], dec_packed):
+            # large batches: the decoder launch forms z_st = z_e + (z_q - z_e) (vq:74) from E[idx] and z_e itself, runs on it, stores
+            # it, and sums both squared errors -- no separate straight-through and mse passes over the [N, D] operands
+            x_rec, pre_d, l3, z_st = ops.mlp3_loss(E, dec_packed, _RELU3, idx, x, z_e, float(module.commitment_cost), ops.LOSS_VQ,
+                                                   save_pre=need_grad, ste=True)
+            loss = l3[2]
         else:
-            x_rec, pre_d = ops.mlp3(z_st, dec_packed, _RELU3), None
-        # q_loss = m1 + commitment_cost m1 (vq:69-71); loss = m0 + q_loss (vq:50-51): evaluated by the mse launch
-        loss = ops.mse_pair_loss(x_rec, x, z_q, z_e, float(module.commitment_cost), ops.LOSS_VQ)[2]
+            z_st = ops.ste(z_e, z_q)                                   # vq:74
+            if need_grad:
+                x_rec, pre_d = ops.mlp3(z_st, dec_packed, _RELU3, save_pre=True)
+            else:
+                x_rec, pre_d = ops.mlp3(z_st, dec_packed, _RELU3), None
+            loss = ops.mse_pair_loss(x_rec, x, z_q, z_e, float(module.commitment_cost), ops.LOSS_VQ)[2]
         module.last_indices = idx
         ctx.module = module
         if need_grad:

@@ -168,6 +168,8 @@ struct Mlp3Args {
     // the forward with the tokenizer's two mean-squared errors folded in (mlp3_lds_kernel<.., 3>; lipvq_mlp3_loss_f32): per-wave
     // double sums of (y - loss_x)^2 and (layer-0 input rows - loss_z)^2 into loss_part[0 / MSE slots + 8 blockIdx.x + wave]
     const float* loss_x; const float* loss_z; double* loss_part;
+    float* ste_out;              // (FUSE 3) non-NULL: the stack's input rows become loss_z + (rows - loss_z), stored here too: the plain
+                                 // VQVAE's straight-through value (backbone.py:74), formed where its two operands already are
 };
 
 template <int T0, int T1, bool BWD>
@@ -561,7 +563,7 @@ __global__ __launch_bounds__(64 * MLPL_WAVES) void mlp3_lds_kernel(Mlp3Args a) {
     auto al16 = [](const void* p, int ld) { return p && ((((uintptr_t)p) & 15) == 0) && (ld & 3) == 0; };
     const bool vecx = al16(a.x, a.K0), vecp = BWD && al16(a.in_pre, a.K0);
     constexpr bool fin = BWD && FUSE == 1, fout = BWD && FUSE == 2, floss = !BWD && FUSE == 3;
-    const bool veclz = floss && al16(a.loss_z, a.K0), veclx = floss && al16(a.loss_x, a.J2);
+    const bool veclz = floss && al16(a.loss_z, a.K0), veclx = floss && al16(a.loss_x, a.J2), vecst = floss && al16(a.ste_out, a.K0);
     double lsum_x = 0.0, lsum_z = 0.0;                                  // (floss) this lane's share, over all of the wave's tiles
     const bool vecib = fin && al16(a.din_b, a.K0);
     const bool vecoa = fout && al16(a.dout_a, a.J2), vecob = fout && al16(a.dout_b, a.J2);
@@ -608,6 +610,11 @@ __global__ __launch_bounds__(64 * MLPL_WAVES) void mlp3_lds_kernel(Mlp3Args a) {
             if (floss && row0 + (lane & 31) < a.N) {            // (features past K0 load as 0 from both operands)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { const double d = (double)xraw[r] - (double)qraw[r]; lsum_z += d * d; }
+            }
+            if (floss && a.ste_out) {                            // z_st = z_e + (z_q - z_e), ste_kernel's two roundings
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = qraw[r] + (xraw[r] - qraw[r]);
+                mlpl_store(a.ste_out, a.K0, row0, a.N, kt, lane, v, a.K0, vecst);
             }
             if (BWD) {
                 if (a.in_pre) mlpl_actgrad16(v, praw, a.act_in);
@@ -891,8 +898,8 @@ extern "C" int lipvq_mlp3_loss_supported(int64_t N, int K0, int J0, int J1, int 
 
 extern "C" int lipvq_mlp3_loss_f32(const float* x, const int64_t* gather_idx, const float* packed, float* y, float* pre0, float* pre1,
                                    float* pre2, int64_t N, int K0, int J0, int J1, int J2, int act0, int act1, int act2,
-                                   const float* target, const float* latent, float* out3, float w, int form, void* workspace,
-                                   void* stream) {
+                                   const float* target, const float* latent, float* ste_out, float* out3, float w, int form,
+                                   void* workspace, void* stream) {
     if (N <= 0) return fail(LIPVQ_EINVAL, "mlp3_loss: N <= 0");
     if (!x || !packed || !y || !target || !latent || !out3 || !workspace) return fail(LIPVQ_EINVAL, "mlp3_loss: null pointer");
     if (form != LIPVQ_LOSS_LLFQ && form != LIPVQ_LOSS_VQ) return fail(LIPVQ_EINVAL, "mlp3_loss: unknown loss form %d", form);
@@ -900,7 +907,7 @@ extern "C" int lipvq_mlp3_loss_f32(const float* x, const int64_t* gather_idx, co
         return fail(LIPVQ_EUNSUPPORTED, "mlp3_loss: N=%lld widths %d,%d,%d,%d (lipvq_mlp3_loss_supported)", (long long)N, K0, J0, J1, J2);
     Mlp3Args a{x, gather_idx, packed, y, pre0, pre1, pre2, nullptr, nullptr, nullptr,
                N, K0, J0, J1, J2, act0, act1, act2, LIPVQ_ACT_NONE};
-    a.loss_x = target; a.loss_z = latent; a.loss_part = (double*)workspace;
+    a.loss_x = target; a.loss_z = latent; a.loss_part = (double*)workspace; a.ste_out = ste_out;
     bool done;
     if (int e = launch_mlp3_lds<false, 3>(a, (hipStream_t)stream, "mlp3_lds_loss", &done)) return e;
     if (!done) return fail(LIPVQ_EUNSUPPORTED, "mlp3_loss: no kernel instance");

@@ -126,9 +126,10 @@ def mlp3_loss_supported(N, packed: PackedMlp3) -> bool:
     return bool(lib.lipvq_mlp3_loss_supported(int(N), packed.K0, packed.J0, packed.J1, packed.J2))
 
 
-def mlp3_loss(x, packed: PackedMlp3, acts, gather_idx, target, latent, w: float, form: int, save_pre: bool = False):
+def mlp3_loss(x, packed: PackedMlp3, acts, gather_idx, target, latent, w: float, form: int, save_pre: bool = False, ste: bool = False):
     """(y, pre or None, out3): mlp3() plus out3 = tensor([mean((y - target)^2), mean((input rows - latent)^2), loss]) as
-    mse_pair_loss() forms it, summed by the stack's own launch (mlp3_loss_supported() must hold)."""
+    mse_pair_loss() forms it, summed by the stack's own launch (mlp3_loss_supported() must hold).  ste=True: the stack runs on
+    latent + (input rows - latent), the plain VQVAE's straight-through value, which is returned as a fourth result."""
     x, target, latent = _chk(x, "x"), _chk(target, "target"), _chk(latent, "latent")
     if x.dim() != 2 or x.shape[1] != packed.K0:
         raise ValueError(f"mlp3_loss: x must be [N,{packed.K0}], got {tuple(x.shape)}")
@@ -144,12 +145,15 @@ def mlp3_loss(x, packed: PackedMlp3, acts, gather_idx, target, latent, w: float,
     pre = [torch.empty((N, J), device=dev, dtype=torch.float32) if save_pre else None
            for J in (packed.J0, packed.J1, packed.J2)]
     out = torch.empty(3, device=dev, dtype=torch.float32)
+    zst = torch.empty((N, packed.K0), device=dev, dtype=torch.float32) if ste else None
     ws = torch.empty(lib.lipvq_mse_workspace_bytes(), device=dev, dtype=torch.uint8)
     with _on(dev):
         check(lib.lipvq_mlp3_loss_f32(_ptr(x), _ptr(gather_idx), _ptr(packed.buf), _ptr(y), _ptr(pre[0]), _ptr(pre[1]), _ptr(pre[2]),
                                       N, packed.K0, packed.J0, packed.J1, packed.J2, int(acts[0]), int(acts[1]), int(acts[2]),
-                                      _ptr(target), _ptr(latent), _ptr(out), float(w), int(form), _ptr(ws), _stream()),
+                                      _ptr(target), _ptr(latent), _ptr(zst), _ptr(out), float(w), int(form), _ptr(ws), _stream()),
               "lipvq_mlp3_loss_f32")
+    if ste:
+        return y, (pre if save_pre else None), out, zst
     return y, (pre if save_pre else None), out
 
 

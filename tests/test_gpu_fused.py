@@ -278,6 +278,38 @@ def test_scatter_with_rows_formed_in_kernel_equals_scaled_diff_then_scatter(N, D
     assert torch.allclose(got.double(), ref, rtol=0, atol=1e-5 * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("N,A,D,K", [(66001, 7, 64, 128), (65536, 12, 208, 1024), (70003, 3, 32, 64)])
+def test_vq_decoder_launch_with_straight_through_and_loss_equals_separate_launches(N, A, D, K):
+    """The plain VQVAE's decoder at large batches (lipvq_mlp3_loss_f32 with ste_out): the launch forms z_st = z_e + (z_q - z_e)
+    from E[idx] and z_e, runs the stack on it, stores it and sums both squared errors -- against lipvq_ste_f32 + lipvq_mlp3_f32 +
+    lipvq_mse_pair_loss_f32: z_st, x_rec and the saved pre-activations bit for bit, the loss to 1e-7; and through the module."""
+    from lipvq_vae_amd import ops
+    from lipvq_vae_amd.autograd import _RELU3
+    from lipvq_vae_amd.tokenizer import VQVAE
+    torch.manual_seed(N)
+    model = VQVAE(A, D, num_embeddings=K).cuda()
+    with torch.no_grad():
+        model.embedding.weight.uniform_(0.0, 0.5)
+    model.invalidate_caches()
+    xt = torch.from_numpy(O.make_inputs(N + 3, N, A)).cuda()
+    E = model.embedding.weight.detach()
+    dec = model._packed_decoder()
+    assert ops.mlp3_loss_supported(N, dec)
+    idx, z_q, z_e = model._tokenize_fused(xt, None)
+    cc = float(model.commitment_cost)
+    y, pre, l3, z_st = ops.mlp3_loss(E, dec, _RELU3, idx, xt, z_e, cc, ops.LOSS_VQ, save_pre=True, ste=True)
+    z_st_u = ops.ste(z_e, z_q)
+    y_u, pre_u = ops.mlp3(z_st_u, dec, _RELU3, save_pre=True)
+    l3_u = ops.mse_pair_loss(y_u, xt, z_q, z_e, cc, ops.LOSS_VQ)
+    assert torch.equal(z_st, z_st_u) and torch.equal(y, y_u)
+    for a, b in zip(pre, pre_u):
+        assert torch.equal(a, b)
+    assert torch.allclose(l3, l3_u, rtol=1e-7, atol=0), (l3, l3_u)
+    with torch.no_grad():
+        z_m, loss_m = model(xt)
+    assert torch.equal(z_m, z_st) and loss_m.item() == l3[2].item()
+
+
 def oracle_grads_cpu(model, xt, kind, gscale):
     """Parameter gradients of gscale * loss by torch autograd on the CPU in float64 (stock ops, the reference's forward as
     oracle/lipvq_oracle.py restates it; float64 so that the comparison sees the launches' rounding only -- a sequential fp32
