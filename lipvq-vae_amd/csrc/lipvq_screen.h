@@ -353,10 +353,11 @@ __device__ __forceinline__ void lq_screen_core_rg(const f16x8 (&ah)[RG][S], cons
             const f16x8 bh = fh[(g + so) % FR];
             f16x8 bl = bh;
             if constexpr (!COARSE) bl = fl[(g + so) % FR];
-#ifndef LQ_ABL_NOLDSB
             // k-step g + FD of this stage, or (g + FD >= NSTEP > MID: the hand-over has passed) of the next stage's first tile.
             // Unconditional: behind the last stage it reads bytes of the ring that nobody uses (no branch in the loop body).
-            {
+            // (LQ_FRAG_BEFORE_MFMA: measurement knob, the placement until round 3 -- in front of the k-step's first MFMA.)
+            auto read_ahead = [&]() {
+#ifndef LQ_ABL_NOLDSB
                 const int g1 = g + FD;
                 const unsigned char* base = (g1 < NSTEP) ? sb : nsb;
                 const int gg = (g1 < NSTEP) ? g1 : g1 - NSTEP;
@@ -367,14 +368,23 @@ __device__ __forceinline__ void lq_screen_core_rg(const f16x8 (&ah)[RG][S], cons
                     e2q[(g1 / S + par) & 1] = reinterpret_cast<const float*>(tb + C::FRAG_BYTES)[ln];   // g1 / S >= TC: next stage
                     if constexpr (COARSE) enq[(g1 / S + par) & 1] = reinterpret_cast<const float*>(tb + C::FRAG_BYTES + 128)[ln];
                 }
-            }
 #endif
-            // pinned order: reads, then (MFMA, its share of the pending tile's bookkeeping) x 3 -- left alone, hipcc lumps the
-            // bookkeeping behind the chain, where nothing hides it
+            };
+#ifdef LQ_FRAG_BEFORE_MFMA
+            read_ahead();
+#endif
+            // pinned order: first MFMA, the read-ahead, then (its share of the pending tile's bookkeeping, MFMA) x 2 -- left alone, hipcc
+            // lumps the bookkeeping behind the chain, where nothing hides it.  The read-ahead sits BEHIND the k-step's first MFMA
+            // (round 3): hipcc guards that MFMA's fragment with `s_waitcnt lgkmcnt(0)`, not a counted wait, so reads issued in front
+            // of it were waited for at once -- a whole LDS round trip exposed per k-step (cfg2 -3.6 %, cfg3 -3 %, same box; a 4-slot
+            // ring on top changes nothing more: profiles/r03_z_frag_read_placement_ab.txt)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g_ = 0; g_ < RG; ++g_) {
                 acc[g_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g_][s], bh, acc[g_], 0, 0, 0);
+#ifndef LQ_FRAG_BEFORE_MFMA
+                if (g_ == 0) { __builtin_amdgcn_sched_barrier(0); read_ahead(); __builtin_amdgcn_sched_barrier(0); }
+#endif
                 lq_track_after_mfma<S, PACK, COARSE>(COARSE ? s : 3 * s + 0, prev[g_], e2_prev, en_prev, frow, znr[g_], code_prev, keep_mask,
                                                      m1[g_], m2[g_], k1[g_]);
                 __builtin_amdgcn_sched_barrier(0);
