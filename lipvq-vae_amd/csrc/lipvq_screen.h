@@ -225,7 +225,11 @@ __device__ __forceinline__ void lq_screen_core_rg(const f16x8 (&ah)[RG][S], cons
                                                   const float (&znr)[RG][16],
                                                   float (&m1)[RG][16], float (&m2)[RG][16], int (&k1)[RG][16]) {
     using C = ScreenCfg<S, TC_, COARSE>;
-    static_assert(NB >= 2 && NB <= 4, "ring of 2..4 stage buffers");
+    // NB = 2 is NOT a ring this loop can run: with one stage in flight (PD = 1) stage st+1 is only ISSUED at the hand-over in the
+    // middle of stage st, and nothing waits for it before the read-ahead crosses into it.  (An experiment build with 2 x 4 tiles
+    // returned the right answers 20x slower -- rows screened against bytes still in flight fail their certificate and go to the
+    // exact stage -- which is luck, not a guarantee: profiles/r03_z_barrier_and_ring_ab.txt.)
+    static_assert(NB >= 3 && NB <= 4, "ring of 3 or 4 stage buffers");
     constexpr int NW = NT / 64;
     constexpr int CHUNKS = (C::STAGE_BYTES + 1023) / 1024;          // 1 KiB = one wave-instruction of the LDS-DMA
     constexpr int CPW = (CHUNKS + NW - 1) / NW;                       // DMA instructions per wave and stage: the SAME for every wave
