@@ -491,7 +491,8 @@ def main():
         "roofline": {"bound": "mfma",
                      "kernel": (("tokenize_kernel, one-product screen (+ nearest_lists_kernel / nearest_rows_kernel: the exact stage over "
                                  "the rows it leaves)" if coarse else
-                                 "tokenize_kernel (+ nearest_rows_encode_kernel for uncertified rows)") if fused else
+                                 "tokenize_kernel (+ nearest_lists_kernel / nearest_rows_kernel: the exact stage over the uncertified rows, read back from "
+                                 "the z_e the launch stored)") if fused else
                                 "mlp3_wg_kernel + screen_kernel (+ nearest_rows_kernel for uncertified rows)"),
                      "screen": "one fp16 product per algorithmic product (11-bit operands, lower-bound bookkeeping)" if coarse else
                                "three fp16 products per algorithmic product (22-bit operands)",
@@ -596,7 +597,11 @@ def main():
         t = json.loads(tfile.read_text())
         if t.get("workload") == args.workload:
             traffic, traffic_src = t.get("bytes_per_launch"), (traffic_src or "") + "committed: " + str(t.get("source"))
-    out["roofline"].update({"traffic": traffic, "traffic_source": traffic_src, "traffic_detail": traffic_detail})
+    out["roofline"].update({"traffic": traffic, "traffic_source": traffic_src, "traffic_detail": traffic_detail,
+                            "traffic_note": "includes N x D x 4 bytes of z_e STORES beyond the algorithmic bytes (134 MB at cfg2): the launch keeps "
+                                            "z_e for its exact stage -- deciding the uncertified rows from stored rows beats re-encoding them from "
+                                            "x by 2.4 % of the whole call (profiles/r03_z_ze_store_ab.txt); the launch is matrix-pipe bound, these "
+                                            "stores are not re-reads and do not bind"})
     failed = False
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], gate = cpu_baseline(model, x, idx_timed)

@@ -994,15 +994,20 @@ static int tokenize_impl(const float* x, const float* packed, const void* packed
     unsigned char* ws = (unsigned char*)workspace;
     int* amb_count = (int*)ws;
     int* amb_list = (int*)(ws + 64);
-    // z_e is written only when the caller wants it (training); otherwise the exact kernel recomputes it for the few
-    // rows it has to decide (saves a 134 MB write per 524 288-row launch at BASELINE config 2)
+    // z_e goes to the caller's buffer when one is given (training), otherwise -- see below -- to a scratch in the workspace
     float* ze_buf = ze_out;
     // the one-product screen (parity instances only): its exact stage reads z_e rows, so one is always written
     const int coarse = !packed16 ? lq_screen_coarse(lq_screen_S(D), K) : 0;
-    // ... and so is one for small batches with either screen (N <= 131 072: shards of a strongly scaled batch): the exact stage
-    // on stored rows (nearest_lists_kernel: a wave per row) is ~8 us where re-encoding the listed rows from x is ~16 us -- a tenth
-    // of a 65 536-row launch; at the full batch the re-encode is kept, because there the z_e write would double the HBM traffic
-    if ((coarse || N <= 131072) && !ze_buf) {
+    // ... and with the three-product screen too (round 3, late): the exact stage on stored rows (nearest_lists_kernel: a wave per
+    // row, ~8 us for cfg2's 1 756 rows) against re-encoding the listed rows from x (nearest_rows_encode_kernel: 32 us behind a
+    // 0.43 ms launch) -- the whole call 0.467 -> 0.456 ms at the metric's batch, same box, for 134 MB of stores the launch does
+    // not feel (it is matrix-pipe bound at 0.4 TB/s of HBM traffic; `traffic` in bench.py's roofline shows them: 171 -> 305 MB).
+    // Until then only batches of <= 131 072 rows stored z_e.  The fast mode keeps that limit: above it its uncertified rows are
+    // re-encoded with the fp32 encoder and get the parity mode's answer.
+    // (LIPVQ_TOK_ZE_ROWS: measurement knob, the batch size up to which a launch stores z_e when nothing else asks for it; per launch)
+    int64_t ze_rows = packed16 ? 131072 : INT64_MAX;
+    if (const char* ev = getenv("LIPVQ_TOK_ZE_ROWS")) ze_rows = atoll(ev);
+    if ((coarse || N <= ze_rows) && !ze_buf) {
         size_t off = 64 + lq_lists_bytes(N) + sizeof(float) * w2q_floats(D);
         off = (off + 255) & ~(size_t)255;
         ze_buf = reinterpret_cast<float*>(ws + off);

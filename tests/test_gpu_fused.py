@@ -19,7 +19,7 @@ def _setup(seed, A, D, K, oracle):
 
 @pytest.mark.parametrize("N,A,D,K", [(5000, 7, 64, 1024), (1024, 7, 32, 256), (777, 12, 128, 1000), (33, 7, 64, 37),
                                      (1, 7, 32, 256), (256 * 300 + 5, 7, 64, 1024), (600, 3, 64, 512)])
-def test_fused_equals_oracle_and_unfused(oracle, N, A, D, K):
+def test_fused_equals_oracle_and_unfused(oracle, monkeypatch, N, A, D, K):
     from lipvq_vae_amd import ops
     p, model = _setup(N + D, A, D, K, oracle)
     assert ops.tokenize_supported(A, 64, 128, D, K)
@@ -34,10 +34,19 @@ def test_fused_equals_oracle_and_unfused(oracle, N, A, D, K):
     prep = ops.nearest_prepare(cb)
     usage = torch.zeros(K, dtype=torch.int64, device="cuda")
     idx, zq, ze, ws = ops.tokenize(xt, packed, raw, cb, prep, usage=usage, want_ze=True)
-    # without ze_out: z_e is never stored, uncertified rows are re-encoded by the exact kernel -- same answers
+    # without ze_out: z_e goes to a scratch in the workspace for the exact stage (the default since round 3) -- same answers
     usage_b = torch.zeros(K, dtype=torch.int64, device="cuda")
     idx_b, zq_b, ze_b, _ = ops.tokenize(xt, packed, raw, cb, prep, usage=usage_b)
     assert ze_b is None and torch.equal(idx_b, idx) and torch.equal(zq_b, zq) and torch.equal(usage_b, usage)
+    # ... and with z_e never stored: uncertified rows are re-encoded from x by the exact kernel (nearest_rows_encode_kernel: what
+    # large fast-mode batches run; LIPVQ_TOK_ZE_ROWS is read per launch; the one-product screen always stores)
+    monkeypatch.setenv("LIPVQ_TOK_ZE_ROWS", "0")
+    monkeypatch.setenv("LIPVQ_SCREEN_MODE", "fine")
+    usage_c = torch.zeros(K, dtype=torch.int64, device="cuda")
+    idx_c, zq_c, _, _ = ops.tokenize(xt, packed, raw, cb, prep, usage=usage_c)
+    monkeypatch.delenv("LIPVQ_TOK_ZE_ROWS")
+    monkeypatch.delenv("LIPVQ_SCREEN_MODE")
+    assert torch.equal(idx_c, idx) and torch.equal(zq_c, zq) and torch.equal(usage_c, usage)
     assert np.array_equal(ze.cpu().numpy(), ze_ref)
     assert np.array_equal(idx.cpu().numpy(), idx_ref)
     assert np.array_equal(zq.cpu().numpy(), zq_ref)
