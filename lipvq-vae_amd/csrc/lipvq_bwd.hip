@@ -368,6 +368,11 @@ __global__ __launch_bounds__(64 * WGW_WAVES) void wgrad_wg5_kernel(const float* 
                         float av[16], bv[16];
 #pragma unroll
                         for (int s2 = 0; s2 < 16; ++s2) { av[s2] = ga[2 * (16 * part + s2) * Jp]; bv[s2] = hb[2 * (16 * part + s2) * Kp]; }
+#ifndef LQ_WG5_NO_PIN
+                        // all 32 operand reads are REQUESTED before the first MFMA (round 3: left alone, hipcc sinks them to two in
+                        // front of each MFMA pair behind `s_waitcnt lgkmcnt(0)` -- an LDS round trip exposed per 128 cycles of MFMA)
+                        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
                         for (int s2 = 0; s2 < 16; ++s2) {
                             acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], bv[s2], acc[q], 0, 0, 0);
