@@ -534,10 +534,18 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                 typedef const __attribute__((address_space(1))) void* glb_ptr_e;
                 const unsigned char* src = reinterpret_cast<const unsigned char*>(a.w2q) + (size_t)t_ * (G2 * 1024);
                 unsigned char* dst = stage0 + (size_t)buf_ * ScreenCfg<S, TCF>::STAGE_BYTES;
+                // the lane offset is made opaque HERE: the 14 source addresses of a row block's slabs do not change from block to
+                // block, hipcc hoisted them out of the block loop as 64-bit VGPR pairs and (S = 13: 190 spilled registers) spilled
+                // eleven of them -- each DMA then sat behind `scratch_load; s_waitcnt vmcnt(0)`, and vmcnt(0) also waits for every
+                // slab copy in flight: the ring ran one memory round trip per KiB.  Two adds per copy instead.
+                unsigned lane16 = (unsigned)lane * 16u;
+#ifndef LQ_SLAB_DMA_HOISTED       /* measurement knob: the addresses as they were */
+                asm volatile("" : "+v"(lane16));
+#endif
 #pragma unroll
                 for (int j = 0; j < G2 * 1024 / 1024 / WAVES; ++j) {
                     const int off = (wave + j * WAVES) * 1024;
-                    __builtin_amdgcn_global_load_lds((glb_ptr_e)(src + off + lane * 16), (lds_ptr_e)(dst + off), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((glb_ptr_e)(src + off + lane16), (lds_ptr_e)(dst + off), 16, 0, 0);
                 }
             };
             if constexpr (STREAM2) {
