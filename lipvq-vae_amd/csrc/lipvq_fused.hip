@@ -530,8 +530,10 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                                         : *reinterpret_cast<const float4*>(w_P2 + ((gidx - T1 * G1) * 64 + lane) * 4);
             };
             auto slab_dma = [&](int t_, int buf_) {             // one 16 KB output-tile slab of layer 2 into a ring buffer: 2 KiB per wave
+#ifdef LQ_SLAB_DMA_BUILTIN
                 typedef __attribute__((address_space(3))) void* lds_ptr_e;
                 typedef const __attribute__((address_space(1))) void* glb_ptr_e;
+#endif
                 const unsigned char* src = reinterpret_cast<const unsigned char*>(a.w2q) + (size_t)t_ * (G2 * 1024);
                 unsigned char* dst = stage0 + (size_t)buf_ * ScreenCfg<S, TCF>::STAGE_BYTES;
                 // the lane offset is made opaque HERE: the 14 source addresses of a row block's slabs do not change from block to
@@ -545,7 +547,19 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
 #pragma unroll
                 for (int j = 0; j < G2 * 1024 / 1024 / WAVES; ++j) {
                     const int off = (wave + j * WAVES) * 1024;
+#ifdef LQ_SLAB_DMA_BUILTIN
                     __builtin_amdgcn_global_load_lds((glb_ptr_e)(src + off + lane16), (lds_ptr_e)(dst + off), 16, 0, 0);
+#else
+                    // issued as inline asm: behind the builtin hipcc guards the tile's first LDS read of the slab ring with
+                    // `s_waitcnt vmcnt(0)` (a DS read may alias an LDS-DMA write) -- the copy of slab t+2, issued two instructions
+                    // earlier, had to LAND before tile t could start: a memory round trip per tile.  Which read needs which copy
+                    // is this loop's own protocol (counted lq_wait_vmcnt + barrier above).
+                    const unsigned long long gaddr = (unsigned long long)(uintptr_t)(src + off) + lane16;
+                    const unsigned ldsaddr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(dst + off));
+                    unsigned m0_keep;                                   // (m0 is handed back: hipcc does not accept it as a clobber)
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(m0_keep) : "v"(gaddr), "s"(ldsaddr) : "memory");
+#endif
                 }
             };
             if constexpr (STREAM2) {
@@ -606,8 +620,13 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                     if (t + 1 < T2) lq_wait_vmcnt<SLAB_CPW>(); else lq_wait_vmcnt<0>();
                     lq_wg_barrier();
                     if (t + 2 < T2) slab_dma(t + 2, (t + 2) % 3);
-                    wslab = reinterpret_cast<const float*>(stage0 + (size_t)(t % 3) * ScreenCfg<S, TCF>::STAGE_BYTES);
-                    wn = *reinterpret_cast<const float4*>(wslab + lane * 4);          // the tile's first group (read after the barrier)
+                    // the lane's LDS address is formed per tile from an opaque lane offset: as a loop invariant hipcc kept it in a
+                    // register from the kernel's first lines and (S = 13) spilled it -- its reload in front of the tile's reads is a
+                    // vector-memory load, and waiting for it (`vmcnt(0)`) waits for the slab copy just issued as well
+                    unsigned lane4 = (unsigned)lane * 4u;
+                    asm volatile("" : "+v"(lane4));
+                    wslab = reinterpret_cast<const float*>(stage0 + (size_t)(t % 3) * ScreenCfg<S, TCF>::STAGE_BYTES) + lane4;
+                    wn = *reinterpret_cast<const float4*>(wslab);                     // the tile's first group (read after the barrier)
                     bnext = bias16(w_B2, t);                                            // (no bias prefetch here: registers)
                 }
                 f32x16 acc = bnext;
@@ -621,7 +640,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                     }
                     const float4 av = wn;
                     if constexpr (STREAM2) {
-                        if (sq + 1 < G2) wn = *reinterpret_cast<const float4*>(wslab + ((sq + 1) * 64 + lane) * 4);
+                        if (sq + 1 < G2) wn = *reinterpret_cast<const float4*>(wslab + (sq + 1) * 256);
                     } else {
                         if (t * G2 + sq + 1 < T2 * G2) wn = wread(T1 * G1 + t * G2 + sq + 1);
                     }
