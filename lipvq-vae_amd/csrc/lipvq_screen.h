@@ -239,7 +239,11 @@ __device__ __forceinline__ void lq_screen_core_rg(const f16x8 (&ah)[RG][S], cons
 #ifndef LQ_FRAG_RING_S4
 #define LQ_FRAG_RING_S4 2      /* measured: 4 slots (reads three k-steps ahead) change nothing */
 #endif
-    constexpr int FR = (S == 4 && NSTEP % LQ_FRAG_RING_S4 == 0) ? LQ_FRAG_RING_S4 : 2;     // fragment ring slots; reads run FR - 1 k-steps ahead
+#ifndef LQ_FRAG_RING_S8
+#define LQ_FRAG_RING_S8 2      /* experiment knob: 4 = reads three k-steps ahead at S = 8 */
+#endif
+    constexpr int FR = (S == 4 && NSTEP % LQ_FRAG_RING_S4 == 0) ? LQ_FRAG_RING_S4
+                     : (S == 8 && NSTEP % LQ_FRAG_RING_S8 == 0) ? LQ_FRAG_RING_S8 : 2;      // fragment ring slots; reads run FR - 1 k-steps ahead
     constexpr int FD = FR - 1;
     constexpr int PERIOD = ((C::TC & 1) || (NSTEP % FR)) ? 2 : 1;     // stages per loop trip: an even number of tiles, whole fragment rings
     static_assert(FR == 2 || NSTEP % FR == 0, "a wider fragment ring needs whole rings per stage");
