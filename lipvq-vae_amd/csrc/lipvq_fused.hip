@@ -56,7 +56,10 @@ constexpr int fused_ring_tc(int S) { return S == 4 ? LQ_EXP_RING_TC : (S <= 2) ?
 constexpr int fused_ring_nb(int S) { return S == 4 ? LQ_EXP_RING_NB : (S <= 4) ? 4 : (S == 8) ? LQ_RING8_NB : 3; }
 #else
 constexpr int fused_ring_tc(int S) { return (S <= 2) ? 4 : (S <= 4) ? 2 : (S == 8) ? LQ_RING8_TC : 1; }
-constexpr int fused_ring_nb(int S) { return (S <= 4) ? 4 : (S == 8) ? LQ_RING8_NB : 3; }
+#ifndef LQ_RING13_NB
+#define LQ_RING13_NB 3
+#endif
+constexpr int fused_ring_nb(int S) { return (S <= 4) ? 4 : (S == 8) ? LQ_RING8_NB : LQ_RING13_NB; }
 #endif
 #ifndef LQ_EXP_WGS_PER_CU
 #define LQ_EXP_WGS_PER_CU 1
