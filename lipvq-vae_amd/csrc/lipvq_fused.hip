@@ -307,6 +307,13 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
       // ---- phase A of row group GC: the round-2 block body, on this group's rows / fragments / pending z_q copy ----
       auto encode_group = [&](auto GC) {
         constexpr int g = decltype(GC)::value;
+        // the lane index the LDS weight reads are addressed with, opaque per row block in the instances that spill (S >= 8): as loop
+        // invariants hipcc kept the lanes' LDS addresses in registers from the kernel's first lines and spilled them -- a reload is a
+        // vector-memory load, and `s_waitcnt vmcnt(0)` in front of its use also waits for every store and copy in flight
+        int lane_w = lane;
+#ifndef LQ_LANE_W_PLAIN          /* measurement knob: the hoistable form */
+        if constexpr (S >= 8) asm volatile("" : "+v"(lane_w));
+#endif
         const int64_t row0 = ((blk * WAVES + wave) * RG + g) * 32;
         const int64_t row = row0 + ln;
         const int64_t rowc = row < a.N ? row : a.N - 1;
@@ -450,7 +457,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                         if (sq < S0q) {                                    // wave-uniform
                             float4 av[T0];
 #pragma unroll
-                            for (int t = 0; t < T0; ++t) av[t] = *reinterpret_cast<const float4*>(w_P0 + ((t * S0q + sq) * 64 + lane) * 4);
+                            for (int t = 0; t < T0; ++t) av[t] = *reinterpret_cast<const float4*>(w_P0 + ((t * S0q + sq) * 64 + lane_w) * 4);
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 const float bv = xq[4 * sq + q];
@@ -469,7 +476,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                         float4 av[T0];
                         float bvv[4];
 #pragma unroll
-                        for (int t = 0; t < T0; ++t) av[t] = *reinterpret_cast<const float4*>(w_P0 + ((t * S0q + sq) * 64 + lane) * 4);
+                        for (int t = 0; t < T0; ++t) av[t] = *reinterpret_cast<const float4*>(w_P0 + ((t * S0q + sq) * 64 + lane_w) * 4);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const int k = 2 * (4 * sq + q) + h;
@@ -529,8 +536,8 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
             constexpr int G1 = S1 / 4, G2 = S2 / 4;             // groups per tile
             auto wread = [&](int gidx) {                        // group gidx of the stream (compile-time after unrolling)
                 if (STREAM2 && gidx >= T1 * G1) gidx = T1 * G1 - 1;             // streamed layer 2: its groups are read from the slab ring
-                return (gidx < T1 * G1) ? *reinterpret_cast<const float4*>(w_P1 + (gidx * 64 + lane) * 4)
-                                        : *reinterpret_cast<const float4*>(w_P2 + ((gidx - T1 * G1) * 64 + lane) * 4);
+                return (gidx < T1 * G1) ? *reinterpret_cast<const float4*>(w_P1 + (gidx * 64 + lane_w) * 4)
+                                        : *reinterpret_cast<const float4*>(w_P2 + ((gidx - T1 * G1) * 64 + lane_w) * 4);
             };
             auto slab_dma = [&](int t_, int buf_) {             // one 16 KB output-tile slab of layer 2 into a ring buffer: 2 KiB per wave
 #ifdef LQ_SLAB_DMA_BUILTIN
