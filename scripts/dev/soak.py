@@ -15,6 +15,7 @@ from bench import trained_like_
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(12345)
 t0, cases, rows, unc = time.time(), 0, 0, 0
+last_note = t0
 while time.time() - t0 < budget:
     D = int(rng.choice([32, 64, 128, 208])) if rng.random() < 0.6 else int(rng.integers(1, 209))
     K = int(rng.choice([37, 256, 1000, 1024, 2048, 8192])) if D <= 128 else int(rng.choice([128, 1024, 4096]))
@@ -69,4 +70,6 @@ while time.time() - t0 < budget:
         assert torch.equal(idx_v, ref_v), ("vq fused", N, A, D, K, os.environ["LIPVQ_SCREEN_MODE"])
         assert torch.equal(zst_v, ops.ste(ze_v, zq_v))
     cases += 1; rows += N
+    if time.time() - last_note > 60:                          # (a silent GPU run is taken to be hung after 7 minutes)
+        last_note = time.time(); print(f"... {cases} cases so far", flush=True)
 print(f"soak: {cases} random cases, {rows} rows, {unc} uncertified rows through the lists -- every route equals the all-pairs exact kernel")

@@ -16,6 +16,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(2024)
 real_sup, real_loss_sup, real_sc = ops.mlp3_bwd_vq_supported, ops.mlp3_loss_supported, ops.scatter_add_vq
 t0, cases, rows = time.time(), 0, 0
+last_note = t0
 os.environ["LIPVQ_SCREEN_MONITOR"] = "0"
 while time.time() - t0 < budget:
     kind = "llfq" if rng.random() < 0.6 else "vq"
@@ -52,5 +53,7 @@ while time.time() - t0 < budget:
     for k, v in model.named_parameters():
         assert torch.equal(g1[k], v.grad), (k,) + tag
     cases += 1; rows += N
+    if time.time() - last_note > 60:                          # (a silent GPU run is taken to be hung after 7 minutes)
+        last_note = time.time(); print(f"... {cases} cases so far", flush=True)
     del model, x, g1
 print(f"soak_train: {cases} random cases, {rows} rows -- folded routes equal the separate launches bit for bit")
