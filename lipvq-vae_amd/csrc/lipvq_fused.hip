@@ -311,9 +311,10 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
         // invariants hipcc kept the lanes' LDS addresses in registers from the kernel's first lines and spilled them -- a reload is a
         // vector-memory load, and `s_waitcnt vmcnt(0)` in front of its use also waits for every store and copy in flight
         int lane_w = lane;
-#ifndef LQ_LANE_W_PLAIN          /* measurement knob: the hoistable form */
-        if constexpr (S >= 8) asm volatile("" : "+v"(lane_w));
+#ifndef LQ_LANE_W_MIN_S
+#define LQ_LANE_W_MIN_S 8        /* measurement knob: the instances that re-form the addresses (99: none); at S = 4 nothing spills */
 #endif
+        if constexpr (S >= LQ_LANE_W_MIN_S) asm volatile("" : "+v"(lane_w));
         const int64_t row0 = ((blk * WAVES + wave) * RG + g) * 32;
         const int64_t row = row0 + ln;
         const int64_t rowc = row < a.N ? row : a.N - 1;
