@@ -577,6 +577,14 @@ __global__ __launch_bounds__(64 * MLPL_WAVES) void mlp3_lds_kernel(Mlp3Args a) {
 
     for (int64_t tile = (int64_t)blockIdx.x * MLPL_WAVES + wave; tile < ntiles; tile += nwaves) {
         const int64_t row0 = tile * 32;
+        // FUSE 1 (the one instance that spills): the lane index the tile's global addresses are formed with is opaque per tile.  As
+        // loop invariants hipcc kept `base + lane offset` pairs from the kernel's first lines and spilled them; each reload in front
+        // of a store or load is a vector-memory load whose `s_waitcnt vmcnt(0)` also waits for every multiplier tile requested ahead.
+        int lane_tile = lane;
+#ifndef LQ_MLPL_LANE_PLAIN
+        if constexpr (FUSE == 1) asm volatile("" : "+v"(lane_tile));
+#endif
+        const int lane = lane_tile;      // (shadows the kernel's: everything below addresses with this one)
         // one 32-feature slice of the input rows as a B operand; backward: act2'(pre2) folded in and g2 saved
         // (forward: requesting the NEXT tile's first slice under this tile's second and third layer changed nothing -- decoder
         // forward with the loss 284 -> 280 us, plain 204 -> 204)
