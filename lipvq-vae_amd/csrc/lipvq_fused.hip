@@ -268,13 +268,20 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
     constexpr int XPF = 8;                                   // fan-in up to 16 is prefetched; wider inputs load at block start
     const bool x_pref = !FAST && a.A <= 2 * XPF;
     float xqg[RG][XPF];
+#ifndef LQ_LANE_W_MIN_S
+#define LQ_LANE_W_MIN_S 8        /* measurement knob: the instances that re-form lane-dependent addresses per use (99: none); at S = 4 nothing spills */
+#endif
     auto load_x = [&](int64_t blk_, const int g_, float (&xq)[XPF]) {
         int64_t r_ = ((blk_ * WAVES + wave) * RG + g_) * 32 + ln;
         r_ = r_ < a.N ? r_ : a.N - 1;
         const int64_t last = a.N * a.A - 1;
+        // (S >= 8: the lane half is opaque here -- hipcc had hoisted the XPF partial addresses `x + 4 k` out of the block loop and
+        // spilled them; each reload's `vmcnt(0)` sat behind the x load issued just before it: XPF global loads in series per block)
+        int h_x = h;
+        if constexpr (S >= LQ_LANE_W_MIN_S) asm volatile("" : "+v"(h_x));
 #pragma unroll
         for (int q = 0; q < XPF; ++q) {
-            const int k = 2 * q + h;
+            const int k = 2 * q + h_x;
             int64_t i_ = r_ * a.A + k;
             i_ = i_ < last ? i_ : last;                      // always a valid address; masked below (no divergent branch)
             const float v = a.x[i_];
@@ -311,10 +318,8 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
         // invariants hipcc kept the lanes' LDS addresses in registers from the kernel's first lines and spilled them -- a reload is a
         // vector-memory load, and `s_waitcnt vmcnt(0)` in front of its use also waits for every store and copy in flight
         int lane_w = lane;
-#ifndef LQ_LANE_W_MIN_S
-#define LQ_LANE_W_MIN_S 8        /* measurement knob: the instances that re-form the addresses (99: none); at S = 4 nothing spills */
-#endif
         if constexpr (S >= LQ_LANE_W_MIN_S) asm volatile("" : "+v"(lane_w));
+        const int h_w = lane_w >> 5;                         // (the centring vector's LDS reads: not hoisted out of the block loop either)
         const int64_t row0 = ((blk * WAVES + wave) * RG + g) * 32;
         const int64_t row = row0 + ln;
         const int64_t rowc = row < a.N ? row : a.N - 1;
@@ -335,7 +340,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                 if (2 * t + (r >> 3) >= S) { zt[t][r] = 0.0f; continue; }
                 const float zv = acc[r] > 0.0f ? acc[r] : 0.0f;      // the canonical ReLU (lq_act_apply)
                 acc[r] = zv;
-                const float v = zv - w_mu[32 * t + 2 * r + h];
+                const float v = zv - w_mu[32 * t + 2 * r + h_w];
                 zt[t][r] = v;
                 n2 = lq_fma(v, v, n2);
                 amax = fmaxf(amax, lq_abs(v));
@@ -372,7 +377,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                                       : FUSED_SIGMOID(acc[r]);
 #endif
                 acc[r] = zv;
-                const float v = zv - w_mu[32 * t + 2 * r + h];
+                const float v = zv - w_mu[32 * t + 2 * r + h_w];
                 n2 = lq_fma(v, v, n2);
                 // register r of tile t is feature 32t + 2r + h = screen slot (step 2t + (r >> 3), element r & 7): scaled by the
                 // kernel-wide power of two fz and split into fp16 hi + lo right here (nothing of z_e is kept in fp32)
