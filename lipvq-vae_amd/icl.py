@@ -1,6 +1,6 @@
 """Host glue around the tokenizer, restating the few lines of the reference that drive it.
 
-* ``ICLActionBranch``      -- the action branch of ``ICLObservationGroupEncoder`` when ``vq_vae_enabled``
+* ``build_action_network`` / ``ICLActionBranch`` -- the action branch of ``ICLObservationGroupEncoder`` when ``vq_vae_enabled``
                              (robomimic/models/obs_nets.py:1219-1227 construction, :1335-1337 call) or
                              ``bin_enabled`` (:1214-1217, :1343-1344) or neither (:1244-1260, the default branch):
                              owns ``action_network``, stashes ``_vq_vae_loss``.
@@ -12,8 +12,8 @@
                              ``ICL_MIMO_Transformer.forward`` calls on the group encoder (obs_nets.py:2571).
 * ``ICLObservationGroupEncoder`` -- the group encoder as a whole object (obs_nets.py:1120-1383): observation encoders are
                              handed in and passed through untouched (they are outside this path), ``prompt["action"]`` goes
-                             to ``ICLActionBranch``; ``forward(**inputs)`` returns the reference's triple and exposes
-                             ``action_network`` / ``_vq_vae_loss`` under the reference's names.
+                             to ``action_network`` -- registered under that name, so ``state_dict()`` has the reference's
+                             keys; ``forward(**inputs)`` returns the reference's triple, ``_vq_vae_loss`` holds the loss.
 * ``VQTokenizerTrainer``   -- the optimiser choreography of ``ICLTransformer_GMM``
                              (robomimic/algo/icl.py:885-889 AdamW(lr=1e-3, wd=1e-4); :913-914 zero_grad;
                              :968-970 loss.backward(), step()), optionally data parallel
@@ -31,30 +31,43 @@ from .default_branch import DefaultActionNetwork
 from .tokenizer import LLFQVAE_V4, VQVAE
 
 
+def build_action_network(action_input_shape: int, action_output_shape: int, vq_vae_enabled: bool = True,
+                         variant: str = "lipvq", bin_enabled: bool = False) -> nn.Module:
+    """The reference's ``if bin_enabled / elif vq_vae_enabled / else`` chain (obs_nets.py:1213-1260) for the branches this
+    library builds; the result is what the reference registers as ``self.action_network``."""
+    if bin_enabled:                  # obs_nets.py:1214-1217: the binning tokenizer of the paper's ablation
+        return AdaptiveBinActionEmbedding(action_dim=action_input_shape, output_dim=action_output_shape)
+    if not vq_vae_enabled:           # obs_nets.py:1244-1260: spectral-norm MLP + TransformerEncoder + Linear
+        return DefaultActionNetwork(action_input_shape, action_output_shape)
+    if variant == "lipvq":           # obs_nets.py:1225: the paper's tokenizer
+        return LLFQVAE_V4(feature_dim=action_input_shape, latent_dim=action_output_shape)
+    if variant == "vqvae":           # obs_nets.py:1220-1222 (commented-out alternative)
+        return VQVAE(feature_dim=action_input_shape, latent_dim=action_output_shape)
+    raise ValueError(variant)
+
+
+def _encode_actions(owner, prompt_actions: torch.Tensor) -> torch.Tensor:
+    """obs_nets.py:1335-1344 on ``owner.action_network``; the tokenizer's loss is stashed on the owner."""
+    if owner.bin_enabled or not owner.vq_vae_enabled:
+        return owner.action_network(prompt_actions)                       # obs_nets.py:1343-1344 (no tokenizer loss)
+    context_actions, loss = owner.action_network(prompt_actions)         # obs_nets.py:1336
+    owner._vq_vae_loss = loss                                             # obs_nets.py:1337
+    return context_actions
+
+
 class ICLActionBranch(nn.Module):
+    """The action branch alone (no observation encoders): ``action_network`` + ``_vq_vae_loss``."""
+
     def __init__(self, action_input_shape: int = 12, action_output_shape: int = 208, vq_vae_enabled: bool = True,
                  variant: str = "lipvq", bin_enabled: bool = False):
         super().__init__()
         self.bin_enabled = bool(bin_enabled)
         self.vq_vae_enabled = bool(vq_vae_enabled) and not self.bin_enabled      # the reference's elif order
-        if self.bin_enabled:             # obs_nets.py:1214-1217: the binning tokenizer of the paper's ablation
-            self.action_network = AdaptiveBinActionEmbedding(action_dim=action_input_shape, output_dim=action_output_shape)
-        elif not vq_vae_enabled:         # obs_nets.py:1244-1260: spectral-norm MLP + TransformerEncoder + Linear
-            self.action_network = DefaultActionNetwork(action_input_shape, action_output_shape)
-        elif variant == "lipvq":         # obs_nets.py:1225: the paper's tokenizer
-            self.action_network = LLFQVAE_V4(feature_dim=action_input_shape, latent_dim=action_output_shape)
-        elif variant == "vqvae":         # obs_nets.py:1220-1222 (commented-out alternative)
-            self.action_network = VQVAE(feature_dim=action_input_shape, latent_dim=action_output_shape)
-        else:
-            raise ValueError(variant)
+        self.action_network = build_action_network(action_input_shape, action_output_shape, vq_vae_enabled, variant, bin_enabled)
         self._vq_vae_loss = None
 
     def forward(self, prompt_actions: torch.Tensor) -> torch.Tensor:
-        if self.bin_enabled or not self.vq_vae_enabled:
-            return self.action_network(prompt_actions)                    # obs_nets.py:1343-1344 (no tokenizer loss)
-        context_actions, loss = self.action_network(prompt_actions)      # obs_nets.py:1336
-        self._vq_vae_loss = loss                                          # obs_nets.py:1337
-        return context_actions
+        return _encode_actions(self, prompt_actions)
 
 
 def time_distributed(actions: torch.Tensor, op) -> torch.Tensor:
@@ -124,7 +137,7 @@ class ICLObservationGroupEncoder(nn.Module):
     The reference builds one ``ObservationEncoder`` per observation group itself (``obs_encoder_factory``: CNNs, randomisers,
     ... -- outside this path); here they are handed in ready-made as ``obs_encoders`` (any modules with
     ``forward(obs_dict) -> [N, F]`` and ``output_shape() -> [F]``) and called exactly where the reference calls them.  The
-    action branch is ``ICLActionBranch`` with ``latent_dim = sum of the groups' feature widths`` (obs_nets.py:1193), selected by
+    action branch is ``build_action_network`` with ``latent_dim = sum of the groups' feature widths`` (obs_nets.py:1193), selected by
     the reference's switches; ``fast_enabled`` / ``ln_act_enabled`` need the FAST tokenizer + CLIP / Mamba packages and are
     refused.  ``forward(**inputs)`` = obs_nets.py:1264-1345: returns ``(obs, context_obs, context_actions)`` on [B*T, ...] rows and
     stashes the tokenizer's loss in ``_vq_vae_loss``."""
@@ -138,16 +151,12 @@ class ICLObservationGroupEncoder(nn.Module):
         self.observation_group_shapes = {k: None for k in self.nets}     # the reference iterates this mapping's keys
         self.fast_enabled, self.ln_act_enabled = False, False
         self.bin_enabled, self.vq_vae_enabled = bool(bin_enabled), bool(vq_vae_enabled)
-        self.action_branch = ICLActionBranch(int(action_input_shape), self.output_shape()[0], vq_vae_enabled=vq_vae_enabled,
-                                             variant=variant, bin_enabled=bin_enabled)
-
-    @property
-    def action_network(self):                                            # obs_nets.py:2420-2422 aliases this attribute
-        return self.action_branch.action_network
-
-    @property
-    def _vq_vae_loss(self):                                              # obs_nets.py:2576-2577
-        return self.action_branch._vq_vae_loss
+        # registered under the reference's own attribute name (obs_nets.py:1214-1260), so that ``state_dict()`` yields
+        # ``nets.<group>.*`` + ``action_network.*`` -- the keys a reference checkpoint holds (algo.py:323-337)
+        self.action_network = build_action_network(int(action_input_shape), self.output_shape()[0], vq_vae_enabled=vq_vae_enabled,
+                                                   variant=variant, bin_enabled=bin_enabled)
+        self.vq_vae_enabled = self.vq_vae_enabled and not self.bin_enabled       # the reference's elif order
+        self._vq_vae_loss = None                                         # read by obs_nets.py:2576-2577
 
     def output_shape(self):
         return [sum(int(self.nets[g].output_shape()[0]) for g in self.nets)]      # obs_nets.py:1347-1355
@@ -160,7 +169,7 @@ class ICLObservationGroupEncoder(nn.Module):
         outputs = [self.nets[g](inputs[g]) for g in self.nets]           # :1293-1296
         obs = torch.cat(outputs, dim=-1)                                 # :1302
         context_obs = torch.cat([self.nets["obs"](prompt_obs)], dim=-1)  # :1303-1304
-        context_actions = self.action_branch(prompt_actions)             # :1335-1344 (loss stashed by the branch)
+        context_actions = _encode_actions(self, prompt_actions)          # :1335-1344 (loss stashed on this module)
         return obs, context_obs, context_actions
 
 

@@ -87,7 +87,7 @@ def test_group_encoder_shim_routes_like_the_reference(monkeypatch):
         def forward(self, a):
             return a[:, :4].detach() * 3.0, a.pow(2).mean()
 
-    monkeypatch.setattr(enc.action_branch, "action_network", _Tok())
+    monkeypatch.setattr(enc, "action_network", _Tok())
     inp = _inputs(B, T)
     obs, cobs, cact = icl.icl_time_distributed(inp, enc, inputs_as_kwargs=True)        # the call of obs_nets.py:2571
     assert obs.shape == (B, T, 16) and cobs.shape == (B, T, 16) and cact.shape == (B, T, 4)
@@ -103,3 +103,64 @@ def test_group_encoder_shim_routes_like_the_reference(monkeypatch):
     # the other switches build the sibling branches (obs_nets.py:1214-1217, 1244-1260)
     assert type(icl.ICLObservationGroupEncoder(encs, A, bin_enabled=True).action_network).__name__ == "AdaptiveBinActionEmbedding"
     assert type(icl.ICLObservationGroupEncoder(encs, A).action_network).__name__ == "DefaultActionNetwork"
+
+
+# The keys a reference checkpoint holds for the group encoder (algo.py:323-337 saves nets.state_dict(); the encoder's own
+# attributes are `nets` and `action_network`, obs_nets.py:1182-1260).  Restated here key by key -- shapes for A = 12, D = 16.
+_A, _D = 12, 16
+REF_KEYS_LLFQ = {"encoder.0.weight": (64, _A), "encoder.0.bias": (64,), "encoder.2.weight": (128, 64), "encoder.2.bias": (128,),
+                 "to_latent.W": (_D, 128), "to_latent.b": (_D,), "to_latent.ci": (_D,), "quantizer.codebook": (1024, _D),
+                 "decoder.0.weight": (64, _D), "decoder.0.bias": (64,), "decoder.2.weight": (128, 64), "decoder.2.bias": (128,),
+                 "to_output.weight": (_A, 128), "to_output.bias": (_A,)}
+REF_KEYS_VQ = {"encoder.0.weight": (64, _A), "encoder.0.bias": (64,), "encoder.2.weight": (128, 64), "encoder.2.bias": (128,),
+               "encoder.4.weight": (_D, 128), "encoder.4.bias": (_D,), "decoder.0.weight": (128, _D), "decoder.0.bias": (128,),
+               "decoder.2.weight": (64, 128), "decoder.2.bias": (64,), "decoder.4.weight": (_A, 64), "decoder.4.bias": (_A,),
+               "embedding.weight": (128, _D)}
+REF_KEYS_BIN = {"running_min": (_A,), "running_max": (_A,), **{f"embedding_layers.{i}.weight": (20, 64) for i in range(_A)},
+                "output_layer.0.weight": (32 * _A, 64 * _A), "output_layer.0.bias": (32 * _A,),
+                "output_layer.2.weight": (_D, 32 * _A), "output_layer.2.bias": (_D,)}
+
+
+def _ref_keys_default():
+    k = {}
+    for i, (o, n) in zip((0, 2, 4), ((64, _A), (128, 64), (_D, 128))):         # spectral_norm(Linear): obs_nets.py:1252-1256
+        k.update({f"{i}.bias": (o,), f"{i}.weight_orig": (o, n), f"{i}.weight_u": (o,), f"{i}.weight_v": (n,)})
+    for l in range(4):                                                          # TransformerEncoder(num_layers=4): :1257
+        p = f"5.layers.{l}."
+        k.update({p + "self_attn.in_proj_weight": (3 * _D, _D), p + "self_attn.in_proj_bias": (3 * _D,),
+                  p + "self_attn.out_proj.weight": (_D, _D), p + "self_attn.out_proj.bias": (_D,),
+                  p + "linear1.weight": (256, _D), p + "linear1.bias": (256,), p + "linear2.weight": (_D, 256),
+                  p + "linear2.bias": (_D,), p + "norm1.weight": (_D,), p + "norm1.bias": (_D,), p + "norm2.weight": (_D,),
+                  p + "norm2.bias": (_D,)})
+    k.update({"6.weight": (_D, _D), "6.bias": (_D,)})                           # :1258
+    return k
+
+
+@pytest.mark.parametrize("switches, ref_keys", [
+    (dict(vq_vae_enabled=True), REF_KEYS_LLFQ), (dict(vq_vae_enabled=True, variant="vqvae"), REF_KEYS_VQ),
+    (dict(bin_enabled=True), REF_KEYS_BIN), (dict(), None)], ids=["lipvq", "vqvae", "bin", "default"])
+def test_group_encoder_loads_a_reference_shaped_checkpoint(switches, ref_keys):
+    """the shim's state_dict must be `nets.<group>.*` + `action_network.*` so that the encoder part of a
+    reference checkpoint loads with strict=True, and `checkpoint.insert_tokenizer_state` round-trips through it."""
+    from lipvq_vae_amd import checkpoint
+    ref_keys = _ref_keys_default() if ref_keys is None else ref_keys
+    encs = OrderedDict(obs=_ObsEnc({"eef": 3, "joint": 7}, _D))
+    enc = icl.ICLObservationGroupEncoder(encs, action_input_shape=_A, **switches)
+    g = torch.Generator().manual_seed(5)
+    ckpt = OrderedDict((f"nets.obs.{k}", torch.randn(v.shape, generator=g)) for k, v in encs["obs"].state_dict().items())
+    for k, shape in ref_keys.items():
+        ckpt["action_network." + k] = torch.randn(shape, generator=g)
+    assert list(enc.state_dict().keys()) == list(ckpt.keys())                  # same keys, same order
+    enc.load_state_dict(ckpt, strict=True)
+    for k, v in ckpt.items():
+        assert torch.equal(enc.state_dict()[k], v), k
+    if "vq_vae_enabled" in switches:                                            # the tokenizers: checkpoint.py's round trip
+        full = OrderedDict(("policy.nets.encoder." + k, v.clone()) for k, v in ckpt.items())
+        variant, state, prefix = checkpoint.extract_tokenizer_state({"model": full})
+        assert prefix == "policy.nets.encoder.action_network." and variant == switches.get("variant", "lipvq")
+        enc2 = icl.ICLObservationGroupEncoder(OrderedDict(obs=_ObsEnc({"eef": 3, "joint": 7}, _D)), _A, **switches)
+        enc2.action_network.load_state_dict(state, strict=True)
+        back = checkpoint.insert_tokenizer_state(OrderedDict(), enc2.action_network, prefix=prefix)
+        assert list(back.keys()) == [k for k in full if k.startswith(prefix)]
+        for k, v in back.items():
+            assert torch.equal(v, full[k]), k
