@@ -155,13 +155,17 @@ int lipvq_screen_debug_f32(const float* z, const float* codebook, const void* pr
  * (the reference's widths), D in {32, 64, 128, 208} (208 = the width the reference itself runs, v5:89-92 / obs_nets.py:1225-1227:
  * its 112 KB of Lipschitz-layer weights are streamed through LDS), A <= 64.  raw6 = host array of the six device pointers {W0, b0, W1, b1,
  * W2 (normalised), b2}: the exact kernel re-encodes the few uncertified rows from x with them, so z_e is written to
- * HBM only when ze_out is given.  After the call the first int of `workspace` holds the number of rows decided by the
- * exact kernel.  Shapes that run the one-product screen (lipvq_screen_is_coarse) leave 10-20 % of the rows to the exact stage,
+ * HBM only when ze_out is given.  After the call the first int of `workspace` holds the number of rows the screen left to an
+ * exact decision.  WORKSPACE CONTRACT (round 4): the first 64 bytes are a header whose counters are zero between calls -- zero a
+ * fresh workspace ONCE with lipvq_tokenize_workspace_init (or a 64-byte memset); every lipvq_tokenize_* / lipvq_vq_tokenize_*
+ * call leaves them at zero (its last kernel does that: no fill launch per call), and one that returns an error re-zeroes the
+ * header.  One workspace serves one stream at a time.  Shapes that run the one-product screen (lipvq_screen_is_coarse) leave 10-20 % of the rows to the exact stage,
  * which then reads z_e rows: z_e is written to ze_out if given, else to a scratch inside the workspace -- which is why
  * lipvq_tokenize_workspace_bytes(N, D) always includes N x D floats (plus 72 bytes of row / candidate lists per row). */
 int lipvq_tokenize_supported(int A, int J0, int J1, int D, int K);
 int lipvq_tokenize_fast_supported(int A, int J0, int J1, int D, int K);      /* lipvq_tokenize_fast_f32: D in {32, 64, 128} */
 size_t lipvq_tokenize_workspace_bytes(int64_t N, int D);
+int lipvq_tokenize_workspace_init(void* workspace, void* stream);
 int lipvq_tokenize_f32(const float* x, const float* packed, const float* const* raw6, const float* codebook,
                        const void* prep, int64_t* idx, float* zq, int64_t* usage, float* ze_out, void* workspace,
                        int64_t N, int A, int J0, int J1, int D, int K, void* stream);

@@ -54,6 +54,7 @@ SIGNATURES = {
     "lipvq_tokenize_supported": (_i, [_i] * 5),
     "lipvq_tokenize_fast_supported": (_i, [_i] * 5),
     "lipvq_tokenize_workspace_bytes": (_sz, [_i64, _i]),
+    "lipvq_tokenize_workspace_init": (_i, [_vp, _vp]),
     "lipvq_tokenize_f32": (_i, [_vp] * 10 + [_i64] + [_i] * 5 + [_vp]),
     "lipvq_nearest_small_supported": (_i, [_i64, _i, _i]),
     "lipvq_nearest_small_workspace_bytes": (_sz, [_i64, _i]),

@@ -59,6 +59,9 @@ __device__ __forceinline__ void lq_usage_add(unsigned long long* __restrict__ us
 }
 #endif
 
+// measurement / test knobs: ONE place reads them (lipvq_misc.hip)
+const char* lq_knob(const char* name);
+
 // error plumbing (defined in lipvq_misc.hip)
 int lipvq_fail(int code, const char* fmt, ...);
 int lipvq_check_launch(const char* what);

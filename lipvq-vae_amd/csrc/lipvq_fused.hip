@@ -162,6 +162,10 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
     constexpr bool STREAM2 = !FAST && S >= LQ_STREAM2_MIN_S;
     static_assert(!FAST || (S % 2 == 0 && S <= 8), "fast mode: D in {32, 64, 128}");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+#ifdef LQ_STAMPS
+    const long long st_top = __builtin_amdgcn_s_memtime();            // kernel entry: the prologue is [st_top, st_begin)
+    const long long st_top_rt = (long long)__builtin_amdgcn_s_memrealtime();      // (100 MHz, the same clock on every CU)
+#endif
 
     const PackedLayout PL = packed_layout(a.A, 32 * T0, 32 * T1, 16 * S);
     const PrepLayout L = prep_layout(a.K, a.D);
@@ -191,47 +195,8 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform (scalar row/address arithmetic)
     const int ln = lane & 31, h = lane >> 5;
 
-    // ---- once per workgroup: weights (re-laid out 4 k-steps per 16-byte LDS read), biases, mu --------
-    {
-        if (FAST) {
-            // packed16 = [P0h | P1h | P2h], each already [t][s][lane][8 halfs] = 4 floats per (t, s, lane)
-            const float* src = reinterpret_cast<const float*>(a.packed16);
-            const int n0 = T0 * S0h * 256, n1 = T1 * (2 * T0) * 256, n2 = T2 * (2 * T1) * 256;
-            for (int i = tid; i < n0; i += THREADS) w_P0[i] = src[i];
-            for (int i = tid; i < n1; i += THREADS) w_P1[i] = src[n0 + i];
-            for (int i = tid; i < n2; i += THREADS) w_P2[i] = src[n0 + n1 + i];
-        } else {
-            const float* P0 = a.packed + PL.oP0;
-            for (int i = tid; i < T0 * S0q * 256; i += THREADS) {
-                const int q = i & 3, l = (i >> 2) & 63, sq = (i >> 8) % S0q, t = (i >> 8) / S0q;
-                const int s = 4 * sq + q;
-                w_P0[i] = (s < S0) ? P0[((size_t)t * S0 + s) * 64 + l] : 0.0f;
-            }
-            const float* P1 = a.packed + PL.oP1;
-            for (int i = tid; i < T1 * (S1 / 4) * 256; i += THREADS) {
-                const int q = i & 3, l = (i >> 2) & 63, sq = (i >> 8) % (S1 / 4), t = (i >> 8) / (S1 / 4);
-                w_P1[i] = P1[((size_t)t * S1 + 4 * sq + q) * 64 + l];
-            }
-            if constexpr (!STREAM2) {
-                const float* P2 = a.packed + PL.oP2;
-                for (int i = tid; i < T2 * (S2 / 4) * 256; i += THREADS) {
-                    const int q = i & 3, l = (i >> 2) & 63, sq = (i >> 8) % (S2 / 4), t = (i >> 8) / (S2 / 4);
-                    w_P2[i] = P2[((size_t)t * S2 + 4 * sq + q) * 64 + l];
-                }
-            }
-        }
-        // biases re-laid out [t][h][r] = b[32 t + 2 r + h]: the 16 values of a lane's accumulator tile are 64 contiguous bytes
-        // (four 16-byte LDS reads, broadcast within the half-wave) instead of sixteen 4-byte reads
-        for (int i = tid; i < 32 * T0; i += THREADS) w_B0[i] = a.packed[PL.oB0 + 32 * (i >> 5) + 2 * (i & 15) + ((i >> 4) & 1)];
-        for (int i = tid; i < 32 * T1; i += THREADS) w_B1[i] = a.packed[PL.oB1 + 32 * (i >> 5) + 2 * (i & 15) + ((i >> 4) & 1)];
-        for (int i = tid; i < 32 * T2; i += THREADS) w_B2[i] = a.packed[PL.oB2 + 32 * (i >> 5) + 2 * (i & 15) + ((i >> 4) & 1)];
-        const float* mu = reinterpret_cast<const float*>(a.prep + L.o_mu);
-        for (int i = tid; i < 16 * S; i += THREADS) w_mu[i] = mu[i];
-        if (use_hist)
-            for (int i = tid; i < a.K; i += THREADS) hist[i] = 0u;
-    }
-    __syncthreads();
-
+    // (round 4: the launch-wide scalars and the first row block's inputs are requested BEFORE the weight copy -- their scalar /
+    // HBM round trips used to start behind the prologue's barrier, in front of the first layer-0 MFMA)
     const unsigned* hdr = reinterpret_cast<const unsigned*>(a.prep);
     const unsigned char* tiles = a.prep + (COARSE ? L.o_tiles_hi : L.o_tiles);     // (the one-product screen stages hi-only tiles)
     const size_t tile_bytes = COARSE ? L.tile_bytes_hi : L.tile_bytes;
@@ -247,22 +212,6 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
     const float fown = lq_pow2f(sz + (int)hdr[3]);
     const float tiny2 = (float)(16 * S) * lq_pow2f(-10 - 2 * sz);
     const int64_t nblk = (a.N + WAVES * RG * 32 - 1) / (WAVES * RG * 32);
-#ifdef LQ_EXP_STAGGER             /* experiment: the workgroup in the SIMDs' odd wave slots starts LQ_EXP_STAGGER cycles late */
-    if (__builtin_amdgcn_s_getreg(6148) & 1) {
-        const long long t0_ = __builtin_amdgcn_s_memtime();
-        while (__builtin_amdgcn_s_memtime() - t0_ < LQ_EXP_STAGGER) __builtin_amdgcn_s_sleep(8);
-    }
-#endif
-
-#ifdef LQ_STAMPS
-    // diagnostic build only (scripts/stamps.py): per-wave cycles per segment, accumulated over the row blocks and written to
-    // the unused upper half of the row list; no output value depends on them
-    long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
-    const long long st_begin = __builtin_amdgcn_s_memtime();
-#define LQ_STAMP(i) do { const long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_prev; st_prev = t_; } while (0)
-#else
-#define LQ_STAMP(i) do { } while (0)
-#endif
     // this lane's inputs of the NEXT row block (k = 2 q + h, q < XPF), fetched a whole screening phase ahead: the first version
     // loaded each x value right in front of the MFMA that consumed it (four serialised HBM round trips per block)
     constexpr int XPF = 8;                                   // fan-in up to 16 is prefetched; wider inputs load at block start
@@ -292,6 +241,113 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
 #pragma unroll
         for (int g_ = 0; g_ < RG; ++g_) load_x(blockIdx.x, g_, xqg[g_]);
     }
+    lq_ws_begin(a.amb_count);
+    // ---- once per workgroup: weights (re-laid out 4 k-steps per 16-byte LDS read), biases, mu --------
+    {
+        // the small vectors first (one element per thread each, clamped index: unconditional loads, all in flight together with
+        // the weight loads below; round 4 -- each used to be its own load / wait / store round trip)
+        static_assert(32 * T1 <= THREADS && 32 * T2 <= THREADS && 16 * S <= THREADS, "one element per thread");
+        const float* mu = reinterpret_cast<const float*>(a.prep + L.o_mu);
+        auto bias_src = [&](size_t o, int n) { const int i = tid < n ? tid : n - 1; return a.packed[o + 32 * (i >> 5) + 2 * (i & 15) + ((i >> 4) & 1)]; };
+        const float vb0 = bias_src(PL.oB0, 32 * T0), vb1 = bias_src(PL.oB1, 32 * T1), vb2 = bias_src(PL.oB2, 32 * T2);
+        const float vmu = mu[tid < 16 * S ? tid : 16 * S - 1];
+        if (FAST) {
+            // packed16 = [P0h | P1h | P2h], each already [t][s][lane][8 halfs] = 4 floats per (t, s, lane)
+            const float* src = reinterpret_cast<const float*>(a.packed16);
+            const int n0 = T0 * S0h * 256, n1 = T1 * (2 * T0) * 256, n2 = T2 * (2 * T1) * 256;
+            // 16-byte pieces, four loads in flight per thread and round (the element loop was one L2 round trip per float)
+            auto copy16 = [&](float* dst, const float* from, int nfl) {
+                const float4* s4 = reinterpret_cast<const float4*>(from);
+                float4* d4 = reinterpret_cast<float4*>(dst);
+                const int nv = nfl / 4;
+                for (int v0 = tid; v0 < nv; v0 += 4 * THREADS) {
+                    float4 r[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const int v = v0 + q * THREADS; r[q] = s4[v < nv ? v : nv - 1]; }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const int v = v0 + q * THREADS; if (v < nv) d4[v] = r[q]; }
+                }
+            };
+            copy16(w_P0, src, n0);
+            copy16(w_P1, src + n0, n1);
+            copy16(w_P2, src + n0 + n1, n2);
+        } else {
+            // Round 4: every load of the prologue is issued before the first LDS store.  The first version copied element by
+            // element (`w[i] = P[..]`: hipcc emits load, s_waitcnt vmcnt(0), ds_write_b32 per iteration -- 16 + 16 dependent L2
+            // round trips per thread, then five more for biases, mu and the histogram): 22 k cycles = 11 us of a 65 536-row
+            // shard's 62 us launch (profiles/r04_a_stamps_shards.txt).  The packed stack is [t][s][64 lanes]; the LDS image is
+            // [t][s / 4][64 lanes][4 k-steps], so one image entry (16 bytes) = four loads 64 floats apart, whole 256-byte
+            // lines per wave-instruction.
+            constexpr int NV1 = T1 * (S1 / 4) * 64, NV2 = STREAM2 ? 0 : T2 * (S2 / 4) * 64;      // 16-byte entries
+            constexpr int R1 = (NV1 + THREADS - 1) / THREADS, R2 = (NV2 + THREADS - 1) / THREADS;
+            const float* P0 = a.packed + PL.oP0;
+            const float* P1 = a.packed + PL.oP1;
+            const float* P2 = a.packed + PL.oP2;
+            float4 r1[R1], r2[R2 > 0 ? R2 : 1];
+#pragma unroll
+            for (int it = 0; it < R1; ++it) {
+                int v = tid + it * THREADS;
+                v = v < NV1 ? v : NV1 - 1;
+                const float* src = P1 + ((size_t)(v >> 6) * 4) * 64 + (v & 63);
+                r1[it] = make_float4(src[0], src[64], src[128], src[192]);
+            }
+#pragma unroll
+            for (int it = 0; it < R2; ++it) {
+                int v = tid + it * THREADS;
+                v = v < NV2 ? v : NV2 - 1;
+                const float* src = P2 + ((size_t)(v >> 6) * 4) * 64 + (v & 63);
+                r2[it] = make_float4(src[0], src[64], src[128], src[192]);
+            }
+            // layer 0 (fan-in A: S0 k-steps, padded to whole groups of four with zeros), entry v = (t * S0q + sq) * 64 + l
+            const int NV0 = T0 * S0q * 64;
+            for (int v0 = tid; v0 < NV0; v0 += THREADS) {
+                const int l = v0 & 63, sq = (v0 >> 6) % S0q, t = (v0 >> 6) / S0q;
+                float e[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int s = 4 * sq + q;
+                    e[q] = (s < S0) ? P0[((size_t)t * S0 + s) * 64 + l] : 0.0f;
+                }
+                *reinterpret_cast<float4*>(w_P0 + (size_t)v0 * 4) = make_float4(e[0], e[1], e[2], e[3]);
+            }
+#pragma unroll
+            for (int it = 0; it < R1; ++it) {
+                const int v = tid + it * THREADS;
+                if (v < NV1) *reinterpret_cast<float4*>(w_P1 + (size_t)v * 4) = r1[it];
+            }
+#pragma unroll
+            for (int it = 0; it < R2; ++it) {
+                const int v = tid + it * THREADS;
+                if (v < NV2) *reinterpret_cast<float4*>(w_P2 + (size_t)v * 4) = r2[it];
+            }
+        }
+        // biases re-laid out [t][h][r] = b[32 t + 2 r + h]: the 16 values of a lane's accumulator tile are 64 contiguous bytes
+        // (four 16-byte LDS reads, broadcast within the half-wave) instead of sixteen 4-byte reads
+        if (tid < 32 * T0) w_B0[tid] = vb0;
+        if (tid < 32 * T1) w_B1[tid] = vb1;
+        if (tid < 32 * T2) w_B2[tid] = vb2;
+        if (tid < 16 * S) w_mu[tid] = vmu;
+        if (use_hist)
+            for (int i = tid; i < a.K; i += THREADS) hist[i] = 0u;
+    }
+    __syncthreads();
+
+#ifdef LQ_EXP_STAGGER             /* experiment: the workgroup in the SIMDs' odd wave slots starts LQ_EXP_STAGGER cycles late */
+    if (__builtin_amdgcn_s_getreg(6148) & 1) {
+        const long long t0_ = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0_ < LQ_EXP_STAGGER) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
+
+#ifdef LQ_STAMPS
+    // diagnostic build only (scripts/stamps.py): per-wave cycles per segment, accumulated over the row blocks and written to
+    // the unused upper half of the row list; no output value depends on them
+    long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
+    const long long st_begin = __builtin_amdgcn_s_memtime();
+#define LQ_STAMP(i) do { const long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_prev; st_prev = t_; } while (0)
+#else
+#define LQ_STAMP(i) do { } while (0)
+#endif
     // the z_q copy of a row block is deferred to the start of the NEXT block (parity kernel) and routed through LDS (lq_gather_dma):
     // its first round overlaps layer 0, further rounds (wider latents) follow
 #ifdef LQ_NO_DEFER_GATHER
@@ -842,10 +898,15 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
         dbg[7] = 0;
         dbg[8] = __builtin_amdgcn_s_memtime() - st_begin;
         dbg[9] = st_begin;
+        dbg[10] = st_begin - st_top;
+        dbg[11] = (long long)__builtin_amdgcn_s_memrealtime();          // 100 MHz wall clock at this wave's end
+        dbg[12] = st_top_rt;
     }
 #endif
+    // the grid's last workgroup publishes the number of listed rows and zeroes the live counters (lipvq_screen.h); its barrier is
+    // the one the histogram flush needs, and the arrival's round trip flies beside the flush's atomics
+    lq_ws_publish(a.amb_count);
     if (use_hist) {
-        __syncthreads();
         for (int i = tid; i < a.K; i += THREADS) {
             const unsigned c = hist[i];
             if (c) atomicAdd(&a.usage[i], (unsigned long long)c);
@@ -1005,6 +1066,15 @@ __global__ void w2q_pack_kernel(const float* __restrict__ P2, float* __restrict_
     out[i] = P2[((size_t)t * S2 + 4 * sq + q) * 64 + l];
 }
 
+// Zero the header of a workspace of lipvq_tokenize_workspace_bytes / lipvq_nearest_workspace_bytes: ONCE, before its first use by
+// lipvq_tokenize_f32 / _fast / _train / lipvq_vq_tokenize*_f32.  Those calls leave the header's counters at zero themselves.
+extern "C" int lipvq_tokenize_workspace_init(void* workspace, void* stream) {
+    if (!workspace) return fail(LIPVQ_EINVAL, "tokenize_workspace_init: null pointer");
+    hipError_t e = hipMemsetAsync(workspace, 0, 64, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(LIPVQ_EHIP, "tokenize_workspace_init: %s", hipGetErrorString(e));
+    return LIPVQ_OK;
+}
+
 extern "C" size_t lipvq_tokenize_workspace_bytes(int64_t N, int D) {
     if (N <= 0 || D <= 0) return 0;
     // uncertified-row counter, row list, best-candidate list, short lists, then (D = 208) the streamed layer-2 weights, then a z_e
@@ -1035,7 +1105,7 @@ static int tokenize_impl(const float* x, const float* packed, const void* packed
         return fail(LIPVQ_EINVAL, "tokenize: codebook, zq, ze_out, workspace and packed16 must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     unsigned char* ws = (unsigned char*)workspace;
-    int* amb_count = (int*)ws;
+    int* amb_count = (int*)ws + LQ_WS_LIVE;           // the header's live counters (lipvq_screen.h: zero between calls)
     int* amb_list = (int*)(ws + 64);
     // z_e goes to the caller's buffer when one is given (training), otherwise -- see below -- to a scratch in the workspace
     float* ze_buf = ze_out;
@@ -1055,8 +1125,8 @@ static int tokenize_impl(const float* x, const float* packed, const void* packed
         off = (off + 255) & ~(size_t)255;
         ze_buf = reinterpret_cast<float*>(ws + off);
     }
-    hipError_t e = hipMemsetAsync(amb_count, 0, 64, st);
-    if (e != hipSuccess) return fail(LIPVQ_EHIP, "tokenize: %s", hipGetErrorString(e));
+    // (no fill of the header here since round 4: the call's last kernel leaves the live counters at zero, lq_ws_finish;
+    // lipvq_tokenize_workspace_init zeroes a fresh workspace once)
     float* w2q = nullptr;
     if (w2q_floats(D)) {
         // the streamed instance: re-lay out layer 2's packed weights into the workspace (one small launch; the weights may have
@@ -1093,10 +1163,13 @@ static int tokenize_impl(const float* x, const float* packed, const void* packed
             default: rc = launch_tokenize<13, false>(a, st); break;
         }
     }
-    if (rc) return rc;
-    // uncertified rows (count on the device): exact decision, from the stored z_e rows or from x
-    if (ze_buf) return lipvq_launch_rows(ze_buf, 0, codebook, idx, zq, usage, amb_list, amb_count, N, K, D, st);
-    return lipvq_launch_rows_encode(x, raw6, A, codebook, idx, zq, usage, amb_list, amb_count, N, K, D, st);
+    if (!rc) {
+        // uncertified rows (count on the device): exact decision, from the stored z_e rows or from x
+        if (ze_buf) rc = lipvq_launch_rows(ze_buf, 0, codebook, idx, zq, usage, amb_list, amb_count, N, K, D, st);
+        else rc = lipvq_launch_rows_encode(x, raw6, A, codebook, idx, zq, usage, amb_list, amb_count, N, K, D, st);
+    }
+    if (rc) (void)hipMemsetAsync(ws, 0, 64, st);     // a failed call must not leave counters behind for the next one
+    return rc;
 }
 
 extern "C" int lipvq_tokenize_f32(const float* x, const float* packed, const float* const* raw6, const float* codebook,
@@ -1134,10 +1207,8 @@ static int vq_tokenize_impl(const float* x, const float* packed, const float* co
         return fail(LIPVQ_EINVAL, "vq_tokenize: codebook, zq, ze_out and workspace must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     unsigned char* ws = (unsigned char*)workspace;
-    int* amb_count = (int*)ws;
+    int* amb_count = (int*)ws + LQ_WS_LIVE;           // the header's live counters: zero between calls (lq_ws_finish)
     int* amb_list = (int*)(ws + 64);
-    hipError_t e = hipMemsetAsync(amb_count, 0, 64, st);
-    if (e != hipSuccess) return fail(LIPVQ_EHIP, "vq_tokenize: %s", hipGetErrorString(e));
     float* w2q = nullptr;
     if (w2q_floats(D)) {
         w2q = reinterpret_cast<float*>(ws + 64 + lq_lists_bytes(N));
@@ -1155,8 +1226,9 @@ static int vq_tokenize_impl(const float* x, const float* packed, const float* co
         case 128: rc = launch_tokenize_vq<8>(a, st); break;
         default: rc = launch_tokenize_vq<13>(a, st); break;
     }
-    if (rc) return rc;
-    return lipvq_launch_rows(ze_out, 0, codebook, idx, zq, usage, amb_list, amb_count, N, K, D, st, LIPVQ_DIST_SQSUM);
+    if (!rc) rc = lipvq_launch_rows(ze_out, 0, codebook, idx, zq, usage, amb_list, amb_count, N, K, D, st, LIPVQ_DIST_SQSUM);
+    if (rc) (void)hipMemsetAsync(ws, 0, 64, st);     // a failed call must not leave counters behind for the next one
+    return rc;
 }
 
 extern "C" int lipvq_vq_tokenize_f32(const float* x, const float* packed, const float* codebook, const void* prep, int64_t* idx,

@@ -1,5 +1,7 @@
 // lipvq_misc.hip -- error plumbing, Lipschitz normalisation, straight-through value, mse reductions
 // ABI and reference citations: include/lipvq.h.  Arithmetic contract: lipvq_math.h.
+#include <stdlib.h>
+
 #include "lipvq_common.h"
 
 #undef fail
@@ -22,6 +24,8 @@ int lipvq_check_launch(const char* what) {
     if (e != hipSuccess) return lipvq_fail(LIPVQ_EHIP, "%s: %s", what, hipGetErrorString(e));
     return LIPVQ_OK;
 }
+
+const char* lq_knob(const char* name) { return getenv(name); }
 
 extern "C" int lipvq_abi_version(void) { return LIPVQ_ABI_VERSION; }
 extern "C" const char* lipvq_last_error(void) { return g_err; }

@@ -623,20 +623,52 @@ __host__ __device__ static inline size_t lq_list_ints(int64_t N);
 // the rows to the exact kernel -- each with its two or three candidates -- where the three-product screen left a fraction of a percent
 __host__ __device__ static inline size_t lq_cand_cap(int64_t N) { return (size_t)N + 64; }
 
+// Workspace header of the screened routes (16 ints), round 4.  PUBLISHED by the screening launch before it ends (what the
+// kernels behind it and the host read): [0] rows the screen left to an exact decision (listed + decided in the launch's tail),
+// [1] listed rows (slots).  LIVE counters at [LQ_WS_LIVE ...], zero between calls:
+//   +0/+1 one 64-bit word: low half = listed rows (slot reservations add to it), high half = workgroups of the screening launch
+//         that have arrived at its end.  The workgroup whose arrival completes the grid gets both halves back from its own
+//         atomic: it publishes [0] and [1] and zeroes the word -- every other workgroup's reservations returned before that
+//         workgroup arrived, so the low half is final;
+//   +2    slots the list kernel left to the scanning kernel -- zeroed by the NEXT screening launch's first workgroup (nothing
+//         reads or writes it between the scanning kernel of one call and the list kernel of the next);
+// No fill launch per call (it was a 4.7 us launch of its own, a twelfth of a 65 536-row shard's time), no finishing pass in the
+// kernels behind the launch (their grids are thousands of workgroups: that many arrivals on one word serialise for tens of
+// microseconds).  lipvq_tokenize_workspace_init zeroes a fresh workspace once.
+#define LQ_WS_LIVE 8
+#define LQ_WS_SLOT2 2
+// host side: the published number of listed rows, given the pointer to the live counters
+static inline const int* lq_ws_listed(const int* live) { return live - LQ_WS_LIVE + 1; }
+#if defined(__HIPCC__)
+__device__ __forceinline__ void lq_ws_begin(int* __restrict__ live) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) live[LQ_WS_SLOT2] = 0;
+}
+// every thread of every workgroup of the screening launch calls this once, last thing
+__device__ __forceinline__ void lq_ws_publish(int* __restrict__ live) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's reservations and list stores have reached L2
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(live), 1ull << 32);
+        if ((unsigned)(old >> 32) == gridDim.x - 1u) {                   // the last workgroup of the grid
+            const int listed = (int)(unsigned)old;
+            live[-LQ_WS_LIVE] = listed;
+            live[-LQ_WS_LIVE + 1] = listed;
+            *reinterpret_cast<unsigned long long*>(live) = 0ull;
+        }
+    }
+}
+// a wave reserves n slots of the row list: the base slot (the low half of the live word)
+__device__ __forceinline__ int lq_ws_reserve(int* __restrict__ live, int n) {
+    return (int)(unsigned)atomicAdd(reinterpret_cast<unsigned long long*>(live), (unsigned long long)(unsigned)n);
+}
+#endif
+
+// What a listed half-row hands over: head = n / -2 / -1 (see above), the lane mask, up to LQ_CAND_MAX codes.
 template <bool PACK>
-__device__ __forceinline__ void lq_screen_emit(const LqDecision& dec, bool certified, bool lists_ok, int my_k, int64_t row,
-                                               bool row_valid, int* __restrict__ amb_count, int* __restrict__ amb_list, int64_t N,
-                                               int K, int lane, unsigned keep_mask, const unsigned char* wave_lds) {
-    const bool need = row_valid && !certified;                          // the same in both halves of the row
-    if (__builtin_amdgcn_ballot_w64(need) == 0ull) return;              // wave-uniform: most waves have nothing to list
+__device__ __forceinline__ void lq_emit_candidates(const LqDecision& dec, bool lists_ok, int K, int lane, unsigned keep_mask,
+                                                   const unsigned char* wave_lds, int& head, unsigned& mask_out,
+                                                   int (&codes)[LQ_CAND_MAX]) {
     const int ln = lane & 31, h = lane >> 5;
-    // ONE atomic per wave for all its listed rows (the one-product screen lists several rows per wave and block; a slot per row by
-    // its own atomicAdd serialised them on one address): the first listed lane reserves popcount slots.  It is issued FIRST and its
-    // result used LAST: the candidates are worked out into registers while the reservation travels to L2 and back.
-    const unsigned long long lm = __builtin_amdgcn_ballot_w64(h == 0 && need);            // (bits 0 .. 31 only)
-    const int leader = __builtin_ctzll(lm);
-    int base = 0;
-    if (lane == leader) base = atomicAdd(amb_count, __builtin_popcountll(lm));
     const float ab = lq_abs(dec.best);
     // vmax, rounded up generously (the two roundings of the quotient are far below the 2^-20 slack)
     const float vmax0 = (dec.best + dec.t0 + dec.p * ab) / (1.0f - dec.p);
@@ -645,7 +677,6 @@ __device__ __forceinline__ void lq_screen_emit(const LqDecision& dec, bool certi
     unsigned mask = 0u;
     bool nothing = !lists_ok || !dec.screen_ok || !(vmax == vmax);
     const bool second_in = !(dec.m2min - dec.best > dec.t0 + dec.p * (ab + lq_abs(dec.m2min)));
-    int codes[LQ_CAND_MAX];
 #pragma unroll
     for (int q = 0; q < LQ_CAND_MAX; ++q) codes[q] = 0;
 #pragma unroll
@@ -663,24 +694,53 @@ __device__ __forceinline__ void lq_screen_emit(const LqDecision& dec, bool certi
             ++n;
         }
     }
-    // ---- now the slot ----
-    base = __shfl(base, leader, 64);
-    int slot = base + __builtin_popcountll(lm & ((1ull << lane) - 1ull));
+    head = nothing ? -1 : ((second_in || n > LQ_CAND_MAX) ? -2 : n);
+    mask_out = mask;
+}
+
+// the slot of a listed row: the row and the screen's best candidate (half 0), the part's eight ints (both halves)
+__device__ __forceinline__ void lq_emit_store(bool need, int slot /* valid in both halves */, int head, unsigned mask,
+                                              const int (&codes)[LQ_CAND_MAX], int my_k, int64_t row, int* __restrict__ amb_list,
+                                              int64_t N, int lane) {
+    const int h = lane >> 5;
     if (h == 0 && need) {
         amb_list[slot] = (int)row;
         amb_list[lq_list_ints(N) + slot] = my_k;                        // the screen's best candidate: bounds the exact scan
     }
-    slot = __shfl(slot, ln, 64);                                        // the row's other half learns the slot
     if (!need || (size_t)slot >= lq_cand_cap(N)) return;
     int* out = amb_list + 2 * lq_list_ints(N) + (size_t)slot * 16 + 8 * h;
     // the part's eight ints {n, mask, c0 .. c5} as TWO 16-byte stores (the slot is 64-byte aligned, the part 32): eight scattered
     // dword stores per listed half-row kept the wave's vmcnt busy well into the next block (its z_q copy waits for vmcnt(0))
     static_assert(LQ_CAND_MAX == 6, "a part is {n, mask, six codes}");
-    const int head = nothing ? -1 : ((second_in || n > LQ_CAND_MAX) ? -2 : n);
     typedef int lq_i4 __attribute__((ext_vector_type(4)));
     lq_i4* out4 = reinterpret_cast<lq_i4*>(out);
     out4[0] = lq_i4{head, (int)mask, codes[0], codes[1]};
     out4[1] = lq_i4{codes[2], codes[3], codes[4], codes[5]};
+}
+
+template <bool PACK>
+__device__ __forceinline__ void lq_screen_emit(const LqDecision& dec, bool certified, bool lists_ok, int my_k, int64_t row,
+                                               bool row_valid, int* __restrict__ amb_count, int* __restrict__ amb_list, int64_t N,
+                                               int K, int lane, unsigned keep_mask, const unsigned char* wave_lds) {
+    const bool need = row_valid && !certified;                          // the same in both halves of the row
+    if (__builtin_amdgcn_ballot_w64(need) == 0ull) return;              // wave-uniform: most waves have nothing to list
+    const int ln = lane & 31, h = lane >> 5;
+    // ONE atomic per wave for all its listed rows (the one-product screen lists several rows per wave and block; a slot per row by
+    // its own atomicAdd serialised them on one address): the first listed lane reserves popcount slots.  It is issued FIRST and its
+    // result used LAST: the candidates are worked out into registers while the reservation travels to L2 and back.
+    const unsigned long long lm = __builtin_amdgcn_ballot_w64(h == 0 && need);            // (bits 0 .. 31 only)
+    const int leader = __builtin_ctzll(lm);
+    int base = 0;
+    if (lane == leader) base = lq_ws_reserve(amb_count, __builtin_popcountll(lm));
+    int head;
+    unsigned mask;
+    int codes[LQ_CAND_MAX];
+    lq_emit_candidates<PACK>(dec, lists_ok, K, lane, keep_mask, wave_lds, head, mask, codes);
+    // ---- now the slot ----
+    base = __shfl(base, leader, 64);
+    int slot = base + __builtin_popcountll(lm & ((1ull << lane) - 1ull));
+    slot = __shfl(slot, ln, 64);                                        // the row's other half learns the slot
+    lq_emit_store(need, slot, head, mask, codes, my_k, row, amb_list, N, lane);
 }
 
 // z_q rows of certified rows: 16 lanes copy one codebook row (16 B each), 4 rows per pass

@@ -207,6 +207,7 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
     const int64_t row0 = ((int64_t)blockIdx.x * SCREEN_WAVES + wave) * 32;
     const int64_t row = row0 + ln;
     const int64_t rowc = row < N ? row : N - 1;
+    lq_ws_begin(amb_count);
 
     // this wave's 32 rows -> centred, row-scaled fp16 hi/lo A fragments (slot (h, j) of step s = feature 16s + 2j + h)
     f16x8 ah[S], al[S];
@@ -312,6 +313,7 @@ __global__ __launch_bounds__(SCREEN_WAVES * 64) void screen_kernel(
     if (h == 0 && row < N && certified) idx[row] = (int64_t)my_k;
     if (usage) lq_usage_add(usage, my_k, h == 0 && row < N && certified);
     if (zq) lq_screen_gather(cb, zq, my_k, certified, row0, N, D, lane);
+    lq_ws_publish(amb_count);                        // the grid's last workgroup publishes the number of listed rows (lipvq_screen.h)
 }
 
 // Exact scan of codes [kb, ke) for one row held in registers: torch's 8-accumulator order, sqrt comparison, first minimum.
@@ -597,12 +599,15 @@ __global__ __launch_bounds__(256) void nearest_rows_kernel(
 // screen's rows; popcount(mask) x K/32 candidates) take the same loop while that is at most 128 candidates; longer scans and rows
 // with no list at all (n = -1: a meaningless screen) are appended to slot2_list for the scanning kernel.
 // ------------------------------------------------------------------------------------------
+#ifndef LQ_LISTS_ALL_K
+#define LQ_LISTS_ALL_K 2048       /* codebooks up to this size: the list kernel decides every listed row (no scanning-kernel launch) */
+#endif
 template <int DCH, int DIST>
 __global__ __launch_bounds__(256) void nearest_lists_kernel(
     const float* __restrict__ z, const float* __restrict__ cb, int64_t* __restrict__ idx, float* __restrict__ zq,
     unsigned long long* __restrict__ usage, const int* __restrict__ row_list, const int* __restrict__ row_count,
     int K, int z_by_slot, const int* __restrict__ cand_list, size_t cand_cap, int* __restrict__ slot2_list,
-    int* __restrict__ slot2_count) {
+    int* __restrict__ slot2_count, int all_here) {
     constexpr int D = DCH * 8;
     const int lane = threadIdx.x & 63, g = lane >> 3, j = lane & 7;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
@@ -619,24 +624,34 @@ __global__ __launch_bounds__(256) void nearest_lists_kernel(
         // ... as long as that is a few rounds of eight: a long scan would hold this wave for hundreds of dependent rounds while
         // the scanning kernel spreads a row over 64 slices (measured at K = 8192: 4.6 k such rows, 256 codes per flagged lane:
         // 290 us here against 101 us there)
-        const bool scan_here = lanescan && lmask != 0u && __builtin_popcount(lmask) * ((K + 31) / 32) <= 128;
+        bool scan_here = lanescan && lmask != 0u && __builtin_popcount(lmask) * ((K + 31) / 32) <= 128;
+        // all_here (round 4; codebooks of <= LQ_LISTS_ALL_K codes): this kernel is the call's last -- whatever the row came with
+        // (a long lane scan, no list at all: every lane flagged) is scanned by this wave, eight codes a round.  Such rows are a
+        // few per ten thousand, and a launch of the scanning kernel for them (usually for nothing: the count lives on the device)
+        // cost every call 4.5 us.
+        unsigned lm_eff = lmask;
         if (!shortlist && !scan_here) {
-            if (lane == 0) slot2_list[atomicAdd(slot2_count, 1)] = slot;      // long lane scans, no list at all: the scanning kernel
-            continue;
+            if (!all_here) {
+                if (lane == 0) slot2_list[atomicAdd(slot2_count, 1)] = slot;      // long lane scans, no list at all: the scanning kernel
+                continue;
+            }
+            scan_here = true;
+            lm_eff = (lanescan && lmask != 0u) ? lmask : 0xffffffffu;
         }
+        const bool scanning = !shortlist;                                    // (wave-uniform; shortlist rows read their list)
         const int64_t row = row_list[slot];
         const float* zr = z + (size_t)(z_by_slot ? (int64_t)slot : row) * D;
-        const int P = lanescan ? __builtin_popcount(lmask) : 0;
-        const int nc = lanescan ? P * ((K + 31) / 32) : n0 + n1;
+        const int P = scanning ? __builtin_popcount(lm_eff) : 0;
+        const int nc = scanning ? P * ((K + 31) / 32) : n0 + n1;
         float best_v = INFINITY;
         int best_k = 0x7fffffff;
         for (int c0 = 0; c0 < nc; c0 += 8) {
             const int ci = c0 + g;
             bool live = ci < nc;
             int code;
-            if (lanescan) {
+            if (scanning) {
                 const int t = ci / P, w = ci - t * P;                          // the w-th flagged lane of tile t
-                unsigned m = lmask;
+                unsigned m = lm_eff;
                 for (int q = 0; q < w; ++q) m &= m - 1;
                 code = 32 * t + __builtin_ctz(m | 0x80000000u);
                 live = live && code < K;
@@ -678,7 +693,7 @@ __global__ __launch_bounds__(256) void nearest_lists_kernel(
             if (ov < best_v || (ov == best_v && ok < best_k)) { best_v = ov; best_k = ok; }
         }
         if (best_k < 0 || best_k >= K) {                                     // every value NaN: any valid code of the list
-            const int fb = lanescan ? __builtin_ctz(lmask) : cl[n0 > 0 ? 2 : 10];
+            const int fb = scanning ? __builtin_ctz(lm_eff) : cl[n0 > 0 ? 2 : 10];
             best_k = (fb >= 0 && fb < K) ? fb : 0;
         }
         if (lane == 0) {
@@ -1169,7 +1184,8 @@ int lipvq_launch_rows_encode(const float* x, const float* const* raw6, int A, co
     if (blocks > grid_cap) blocks = grid_cap;
     auto go = [&](auto kfn) {
         hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(256), 0, st, x, w, A, cb, idx, zq,
-                           (unsigned long long*)usage, amb_list, amb_count, K, amb_seed, amb_list + 2 * lq_list_ints(N), lq_cand_cap(N));
+                           (unsigned long long*)usage, amb_list, lq_ws_listed(amb_count), K, amb_seed, amb_list + 2 * lq_list_ints(N),
+                           lq_cand_cap(N));
     };
     switch (D) {
         case 32: go(nearest_rows_encode_kernel<4>); break;
@@ -1238,17 +1254,22 @@ static int launch_rows_t(const float* z, int z_by_slot, const float* cb, int64_t
     // the count lives on the device: a bounded grid strides over however many rows were listed
     int64_t blocks = (N + 3) / 4;
     if (blocks > 4096) blocks = 4096;
+    // counts on the device (lipvq_screen.h, workspace header): the screening launch PUBLISHED the number of listed rows before it
+    // ended (lq_ws_publish); the list kernel appends what it leaves to the slot-2 list behind the header's slot-2 counter
+    const int* listed = amb_list ? lq_ws_listed(amb_count) : nullptr;
     if (amb_list) {
         // rows with short candidate lists (95 % and more of the listed rows): one wave per row, eight candidates at a time;
         // what it leaves (lane masks, no list) goes through slot2 to the scanning kernel
         int* slot2_list = const_cast<int*>(amb_list) + lq_slot2_offset_ints(N);
-        int* slot2_count = const_cast<int*>(amb_count) + 1;                 // zeroed with the header by the caller's memset
+        int* slot2_count = const_cast<int*>(amb_count) + LQ_WS_SLOT2;       // zeroed by the screening launch's first workgroup
         int64_t lb = (N + 3) / 4;
         if (lb > 2048) lb = 2048;
+        const int all_here = K <= LQ_LISTS_ALL_K ? 1 : 0;
         hipLaunchKernelGGL((nearest_lists_kernel<DCH, DIST>), dim3((unsigned)lb), dim3(256), 0, st, z, cb, idx, zq,
-                           (unsigned long long*)usage, amb_list, amb_count, K, z_by_slot, amb_list + 2 * lq_list_ints(N),
-                           lq_cand_cap(N), slot2_list, slot2_count);
+                           (unsigned long long*)usage, amb_list, listed, K, z_by_slot, amb_list + 2 * lq_list_ints(N),
+                           lq_cand_cap(N), slot2_list, slot2_count, all_here);
         if (int rc = check_launch("nearest_lists")) return rc;
+        if (all_here) return LIPVQ_OK;                                       // nothing was left to the scanning kernel
         hipLaunchKernelGGL((nearest_rows_kernel<DCH, DIST>), dim3((unsigned)blocks), dim3(256), 0, st, z, cb, idx, zq,
                            (unsigned long long*)usage, amb_list, slot2_count, K, z_by_slot, 0, amb_list + lq_list_ints(N),
                            amb_list + 2 * lq_list_ints(N), lq_cand_cap(N), slot2_list);
@@ -1266,8 +1287,9 @@ static int launch_rows_any(const float* z, int z_by_slot, const float* cb, int64
     int64_t blocks = (N + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL((nearest_rows_any_kernel<DIST>), dim3((unsigned)blocks), dim3(256), 0, st, z, cb, idx, zq,
-                       (unsigned long long*)usage, amb_list, amb_count, K, D, z_by_slot, amb_list ? 0 : (int)N,
-                       amb_list ? amb_list + 2 * lq_list_ints(N) : nullptr, amb_list ? lq_cand_cap(N) : (size_t)0);
+                       (unsigned long long*)usage, amb_list, amb_list ? lq_ws_listed(amb_count) : nullptr, K, D, z_by_slot,
+                       amb_list ? 0 : (int)N, amb_list ? amb_list + 2 * lq_list_ints(N) : nullptr,
+                       amb_list ? lq_cand_cap(N) : (size_t)0);
     return check_launch("nearest_rows_any");
 }
 
@@ -1294,9 +1316,10 @@ int lipvq_launch_rows(const float* z, int z_by_slot, const float* cb, int64_t* i
 static int screened_impl(const float* z, const float* cb, const void* prep, int64_t* idx, float* zq,
                          int64_t* usage, void* workspace, float* dbg, int64_t N, int K, int D, float gamma,
                          hipStream_t st, int dist = LIPVQ_DIST_NORM) {
-    int* amb_count = (int*)workspace;
+    int* amb_count = (int*)workspace + LQ_WS_LIVE;          // the header's live counters (lipvq_screen.h); [0] = the reported count
     int* amb_list = (int*)((unsigned char*)workspace + 64);
-    hipError_t e = hipMemsetAsync(amb_count, 0, 64, st);
+    // (this entry point takes a workspace in any state, hence the fill; the fused launches keep theirs clean: lq_ws_finish)
+    hipError_t e = hipMemsetAsync(workspace, 0, 64, st);
     if (e != hipSuccess) return fail(LIPVQ_EHIP, "nearest_screened: %s", hipGetErrorString(e));
     const unsigned char* p = (const unsigned char*)prep;
     int rc;

@@ -246,6 +246,10 @@ class GraphedTokenizerStep:
         saved_params = [p.detach().clone() for p in params]
         saved_state = {id(p): {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in self.vq_optimizer.state.get(p, {}).items()}
                        for p in params}
+        # ... and so is everything else a step writes on the module: its buffers (code_usage -- warm-up counts would skew
+        # perplexity() and, sharded, every rank's all-reduced histogram), last_indices, the screen monitor's reading
+        saved_buffers = [(b, b.detach().clone()) for b in vq_vae_model.buffers()]
+        saved_last = getattr(vq_vae_model, "last_indices", None)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -263,12 +267,24 @@ class GraphedTokenizerStep:
                             v.copy_(old)
                         else:
                             v.zero_()
+            for b, sb in saved_buffers:
+                b.copy_(sb)
+        if hasattr(vq_vae_model, "last_indices"):
+            vq_vae_model.last_indices = saved_last
+        mon = getattr(vq_vae_model, "_screen_monitor", None)
+        if mon is not None:
+            mon.__init__()
         torch.cuda.synchronize()
         self.model.invalidate_caches()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self._loss = self._eager_step()
         self.model.invalidate_caches()
+        # the capture ran the forward once more (recording only): its index tensor is the graph's static one -- what a replay
+        # fills -- and becomes `last_indices` with the first step(); until then the module shows what it showed before
+        self._static_last = getattr(vq_vae_model, "last_indices", None)
+        if hasattr(vq_vae_model, "last_indices"):
+            vq_vae_model.last_indices = saved_last
 
     def _eager_step(self):
         z, loss, params, grads = self._fb(self.model, self.static_x)
@@ -286,4 +302,6 @@ class GraphedTokenizerStep:
         self.static_x.copy_(prompt_actions)
         self.graph.replay()
         self.model.invalidate_caches()
+        if hasattr(self.model, "last_indices"):
+            self.model.last_indices = self._static_last
         return self._z, self._loss

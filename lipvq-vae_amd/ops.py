@@ -452,9 +452,14 @@ _small_ws: dict = {}          # (device index, stream handle) -> zero-at-rest wo
 
 def _nearest_small_workspace(N, K, dev):
     """The chip-wide small-batch kernel meets a row's partial minima behind per-row-group counters that are zero between
-    launches (the last workgroup resets them): one zero-filled buffer per (device, stream) serves every call -- no fill launch
-    per call, which matters where this route is used (a graphed training step is ~50 nodes of >= 4.6 us)."""
+    launches (the last workgroup resets them): one zero-filled buffer per (device, stream) serves every EAGER call -- no fill
+    launch per call.  Under stream capture every call gets its own zeroed buffer (one memset node)."""
     need = lib.lipvq_nearest_small_workspace_bytes(N, K)
+    if torch.cuda.is_current_stream_capturing():
+        # Never shared across captures: a cached buffer's zero fill would be a node of the FIRST graph that used it only (a
+        # second graph replayed first, or two graphs on two streams, would meet on uninitialised or shared counters).  A fresh
+        # zeroed buffer per call puts the fill into this graph and the buffer into this graph's private pool.
+        return torch.zeros(need, device=dev, dtype=torch.uint8)
     key = (dev.index, _stream())
     ws = _small_ws.get(key)
     if ws is None or ws.numel() < need:
@@ -547,8 +552,12 @@ def tokenize_fast_supported(A, J0, J1, D, K) -> bool:
 
 
 def tokenize_workspace(N: int, D: int, device) -> torch.Tensor:
-    """int32 workspace of lipvq_tokenize_f32 (row list + z_e scratch); callers may keep and reuse it."""
-    return torch.empty(max(16, (lib.lipvq_tokenize_workspace_bytes(N, D) + 3) // 4), device=device, dtype=torch.int32)
+    """int32 workspace of lipvq_tokenize_f32 (row list + z_e scratch) with its header zeroed (lipvq_tokenize_workspace_init: the
+    fused calls keep the header's counters at zero themselves); callers may keep and reuse it -- on one stream at a time."""
+    ws = torch.empty(max(16, (lib.lipvq_tokenize_workspace_bytes(N, D) + 3) // 4), device=device, dtype=torch.int32)
+    with _on(ws.device):
+        check(lib.lipvq_tokenize_workspace_init(_ptr(ws), _stream()), "lipvq_tokenize_workspace_init")
+    return ws
 
 
 def mlp3_pack_f16(W0, W1, W2):

@@ -408,3 +408,38 @@ def test_other_kernel_shapes_give_the_same_results(oracle, monkeypatch, shape, N
     idx, zq = model.tokenize(xt)
     assert np.array_equal(idx.cpu().numpy(), idx_ref) and np.array_equal(zq.cpu().numpy(), zq_ref)
     assert np.array_equal(model.code_usage.cpu().numpy(), usage_ref)
+
+
+@pytest.mark.parametrize("N,A,D,K", [(65536, 7, 64, 1024), (40000, 7, 32, 256), (30011, 12, 208, 1024), (50000, 7, 128, 8192),
+                                     (70000, 7, 64, 4096), (3000, 7, 64, 37)])
+def test_workspace_header_is_kept_clean_by_the_launch_itself(oracle, N, A, D, K):
+    """Round 4: nothing fills the workspace header per call.  The screening launch's last workgroup publishes the number of listed
+    rows ([0], [1]) and zeroes the live word ([8], [9]); the slot-2 counter ([10]) is zeroed by the NEXT launch's first workgroup.
+    Call after call on ONE workspace: same indices / z_q / usage as the all-pairs exact kernel on the same z_e, the same published
+    count every time (three- and one-product screens; codebooks on both sides of LQ_LISTS_ALL_K = 2048, above which the scanning
+    kernel runs behind the list kernel)."""
+    from lipvq_vae_amd import ops
+    p, model = _setup(N % 1000 + D, A, D, K, oracle)
+    xt = torch.from_numpy(O.make_inputs(N % 977, N, A)).cuda()
+    packed, _, Wn = model._packed_encoder()
+    w0, b0, w1, b1, _, b2, _ = (t.detach() for t in model._enc_params())
+    raw = (w0, b0, w1, b1, Wn, b2)
+    cb = model.quantizer.codebook.detach()
+    prep = ops.nearest_prepare(cb)
+    ws = ops.tokenize_workspace(N, D, xt.device)
+    assert int(ws[:16].abs().sum()) == 0                                       # lipvq_tokenize_workspace_init
+    ref_i, ref_q, _ = ops.nearest(model.encode(xt), cb)
+    ref_u = torch.bincount(ref_i, minlength=K)
+    counts = []
+    for call in range(4):
+        usage = torch.zeros(K, dtype=torch.int64, device="cuda")
+        idx, zq, _, ws_out = ops.tokenize(xt, packed, raw, cb, prep, usage=usage, workspace=ws)
+        assert ws_out is ws and torch.equal(idx, ref_i), call
+        assert torch.equal(zq, ref_q) and torch.equal(usage, ref_u)
+        hdr = ws[:16].cpu()
+        assert int(hdr[8]) == 0 and int(hdr[9]) == 0, (call, hdr.tolist())    # the live word is back at zero
+        assert int(hdr[0]) == int(hdr[1])
+        counts.append(int(hdr[0]))
+    assert len(set(counts)) == 1 and 0 <= counts[0] <= N, counts              # the same rows are left to an exact decision
+    if K >= 256:
+        assert counts[0] > 0, "meant to exercise uncertified rows"

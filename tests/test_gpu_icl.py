@@ -165,9 +165,15 @@ def test_graphed_training_step_after_eager_training_equals_eager_trajectory(orac
     # capture: two warm-up steps on xs[3] (real steps whose effect on parameters and optimizer state is undone: constructing the
     # graphed step must not train the model), then the graph
     before = {k: v.clone() for k, v in model.state_dict().items()}
+    usage_before, last_before = model.code_usage.clone(), model.last_indices
     g = GraphedTokenizerStep(model, xs[3], optimizer_state=tr.vq_optimizer.state_dict(), warmup=2)
     for k, v in model.state_dict().items():
         assert torch.equal(v, before[k]), f"construction changed {k}"
+    # ... nor count the warm-up batches into the usage histogram: buffers, last_indices and the screen monitor
+    # are what they were before the construction
+    assert torch.equal(model.code_usage, usage_before) and int(usage_before.sum()) == 3 * N
+    assert model.last_indices is last_before
+    assert model._screen_monitor._pending is None and model._screen_monitor.bypass_calls == 0
     losses = []
     for i in range(4, 7):
         _, loss = g.step(xs[i])

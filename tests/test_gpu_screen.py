@@ -459,3 +459,41 @@ def test_small_batch_kernel_equals_all_pairs(N, D, K, dist):
     idx_r, zq_r = ops.nearest_rows(z, cb, dist=dist, route="rows")              # the row kernels agree too
     assert torch.equal(idx_r, ref_i) and torch.equal(zq_r, ref_q)
 
+
+
+def test_small_batch_kernel_in_two_graphs_replayed_in_either_order():
+    """the zero-at-rest workspace of lipvq_nearest_small_f32 must not be shared between captures.  Graph A
+    and graph B are captured one after the other; B is replayed FIRST (its counters must have been zeroed by a node of B, not
+    of A), then A, then both again after A's objects are gone."""
+    from lipvq_vae_amd import ops
+    gen = torch.Generator(device="cuda").manual_seed(77)
+    N, D, K = 80, 208, 1024
+    cb = torch.rand(K, D, device="cuda", generator=gen)
+    za, zb = torch.rand(N, D, device="cuda", generator=gen), torch.rand(N, D, device="cuda", generator=gen)
+    ref_a, ref_b = ops.nearest(za, cb)[0], ops.nearest(zb, cb)[0]
+    ops.nearest_rows(za, cb, route="small")                                    # one-time work outside the captures
+    torch.cuda.synchronize()
+    graphs, outs = [], []
+    for z in (za, zb):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            idx, zq = ops.nearest_rows(z, cb, route="small")
+        graphs.append(g)
+        outs.append((idx, zq))
+    for i in (0, 1):
+        outs[i][0].fill_(-1)
+    graphs[1].replay()
+    torch.cuda.synchronize()
+    assert torch.equal(outs[1][0], ref_b)
+    graphs[0].replay()
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], ref_a) and torch.equal(outs[0][1], cb[ref_a])
+    idx_b = outs[1][0]
+    del graphs[0], outs[0]
+    torch.cuda.empty_cache()
+    idx_b.fill_(-1)
+    graphs[0].replay()                                                         # what is left is graph B
+    torch.cuda.synchronize()
+    assert torch.equal(idx_b, ref_b)
+    idx_e, _ = ops.nearest_rows(za, cb, route="small")                         # and the eager cache is untouched by all this
+    assert torch.equal(idx_e, ref_a)
