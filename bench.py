@@ -136,11 +136,12 @@ def cpu_baseline(model, x_dev, idx_dev, budget_s=10.0):
     return base, gate
 
 
-def measure_traffic_live(workload, kernels, timeout_s=150):
-    """HBM bytes per launch of the metric's kernels, measured NOW: two child runs of this file under `rocprofv3 --pmc`
-    (FETCH_SIZE and WRITE_SIZE in separate passes, counters only -- no trace domain), after the timed region so that the
-    profiler never touches `value`.  Unit and gfx950 correction as MI355X_MICROARCH.md's HBM section prescribes: both counters
-    are in KiB; FETCH_SIZE under-reports wide reads by 2x on gfx950.  Returns (bytes_per_launch, source, detail) or raises."""
+def pmc_child_runs(workload, passes, child_steps=5, sustained=200, timeout_s=150):
+    """Counter passes of the metric's kernels, measured NOW: one child run of this file under `rocprofv3 --pmc <counters>` per pass
+    (counters only -- no trace domain -- and the program directly behind `--`), after the timed region so that the profiler never
+    touches `value`.  The child warms the chip the way the headline run does (a sustained loop, then warm-up), and only the LAST
+    `child_steps` dispatches of each kernel -- its timed steps -- are read.  Returns {pass name: {kernel: {counter: mean value,
+    "_ns": mean dispatch duration, "_n": dispatches read}}}."""
     import collections
     import csv
     import glob
@@ -155,15 +156,15 @@ def measure_traffic_live(workload, kernels, timeout_s=150):
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    child = [sys.executable, str(ROOT / "bench.py"), "--workload", workload, "--steps", "5", "--warmup", "2",
-             "--no-cpu-baseline", "--sustained", "0", "--metric-only", "--traffic", "off"]
-    means = {}
+    child = [sys.executable, str(ROOT / "bench.py"), "--workload", workload, "--steps", str(child_steps), "--warmup", "2",
+             "--no-cpu-baseline", "--sustained", str(sustained), "--metric-only", "--traffic", "off"]
+    result = {}
     try:
-        for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-            d = os.path.join(tmp, kind)
+        for name, counters in passes:
+            d = os.path.join(tmp, name)
             # the profiler and the bench child it starts run in a process group of their own: on a timeout the whole
             # group is killed and reaped, so no orphan keeps the GPU busy after this function returns
-            pr = subprocess.Popen([rp, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
+            pr = subprocess.Popen([rp, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
             try:
                 out_b, _ = pr.communicate(timeout=timeout_s)
@@ -174,31 +175,66 @@ def measure_traffic_live(workload, kernels, timeout_s=150):
                 except ProcessLookupError:
                     pass
                 pr.communicate()
-                raise RuntimeError(f"rocprofv3 --pmc {counter} timed out after {timeout_s} s (process group killed)")
+                raise RuntimeError(f"rocprofv3 --pmc {' '.join(counters)} timed out after {timeout_s} s (process group killed)")
             if pr.returncode != 0:
-                raise RuntimeError(f"rocprofv3 --pmc {counter} exited {pr.returncode}: {out_b.decode(errors='replace')[-300:]}")
-            acc = collections.defaultdict(list)
+                raise RuntimeError(f"rocprofv3 --pmc {' '.join(counters)} exited {pr.returncode}: {out_b.decode(errors='replace')[-300:]}")
+            acc = collections.defaultdict(lambda: collections.defaultdict(list))      # kernel -> counter -> [(start, value, ns)]
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for row in csv.DictReader(fh):
-                        if row["Counter_Name"] == counter:
-                            acc[row["Kernel_Name"].split("(")[0]].append(float(row["Counter_Value"]))
-            means[kind] = {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+                        if row["Counter_Name"] in counters:
+                            t0_, t1_ = int(row["Start_Timestamp"]), int(row["End_Timestamp"])
+                            acc[row["Kernel_Name"].split("(")[0]][row["Counter_Name"]].append((t0_, float(row["Counter_Value"]), t1_ - t0_))
+            res = {}
+            for k, byc in acc.items():
+                res[k] = {}
+                for cn, v in byc.items():
+                    v.sort()
+                    last = v[-child_steps:]
+                    res[k][cn] = sum(x[1] for x in last) / len(last)
+                    res[k]["_ns"] = sum(x[2] for x in last) / len(last)
+                    res[k]["_n"] = len(last)
+            result[name] = res
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+    return result
+
+
+def measure_traffic_live(workload, kernels, timeout_s=150):
+    """HBM bytes per launch of the metric's kernels (FETCH_SIZE and WRITE_SIZE in separate passes) and, in a third pass, the SQ /
+    GRBM counters the roofline is read against: matrix-pipe busy cycles and the shader clock the launch actually held.  Unit and
+    gfx950 correction as MI355X_MICROARCH.md's HBM section prescribes: both size counters are in KiB; FETCH_SIZE under-reports wide
+    reads by 2x on gfx950.  Returns (bytes_per_launch, source, detail, sq) or raises."""
+    runs = pmc_child_runs(workload, (("fetch", ("FETCH_SIZE",)), ("write", ("WRITE_SIZE",)),
+                                     ("sq", ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_MFMA", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"))),
+                          timeout_s=timeout_s)
     detail, total = {}, 0.0
-    for k in sorted(set(means["fetch"]) | set(means["write"])):
+    for k in sorted(set(runs["fetch"]) | set(runs["write"])):
         if not any(t in k for t in kernels):
             continue
-        f, w = means["fetch"].get(k, (0.0, 0)), means["write"].get(k, (0.0, 0))
-        rb, wb = 2.0 * f[0] * 1024.0, w[0] * 1024.0
-        detail[k] = {"dispatches": max(f[1], w[1]), "read_bytes": rb, "write_bytes": wb}
+        f, w = runs["fetch"].get(k, {}), runs["write"].get(k, {})
+        rb, wb = 2.0 * f.get("FETCH_SIZE", 0.0) * 1024.0, w.get("WRITE_SIZE", 0.0) * 1024.0
+        detail[k] = {"dispatches": max(f.get("_n", 0), w.get("_n", 0)), "read_bytes": rb, "write_bytes": wb}
         total += rb + wb
     if not detail:
         raise RuntimeError("no dispatch of the metric's kernels in the counter output")
-    return total, ("live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate child runs of bench.py --steps 5 --metric-only "
-                   "on this GPU, after the timed region); mean per dispatch, summed over the launch's kernels; reads x2 "
-                   "(gfx950 FETCH_SIZE correction)"), detail
+    sq = None
+    dom = [k for k in runs["sq"] if kernels[0] in k]
+    if dom:
+        c = runs["sq"][max(dom, key=lambda k: runs["sq"][k].get("_ns", 0.0))]
+        gui, ns = c.get("GRBM_GUI_ACTIVE", 0.0), c.get("_ns", 0.0)
+        if gui > 0 and ns > 0:
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_VALU_MFMA_BUSY_CYCLES over the 1 024 SIMDs (MI355X_MICROARCH.md, DVFS give-back)
+            sq = {"kernel": max(dom, key=lambda k: runs["sq"][k].get("_ns", 0.0)), "dispatches": c.get("_n"),
+                  "ns_per_dispatch_profiled": ns, "shader_clock_mhz": gui / 8.0 / ns * 1e3,
+                  "mfma_busy_frac": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) * 8.0 / (1024.0 * gui),
+                  "insts_mfma": c.get("SQ_INSTS_MFMA"), "sq_busy_cycles": c.get("SQ_BUSY_CYCLES"), "grbm_gui_active": gui,
+                  "how": "third --pmc pass of the same child run (sustained loop first; the last 5 dispatches = its timed steps): clock = "
+                         "GRBM_GUI_ACTIVE / 8 XCDs / dispatch duration, mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x "
+                         "GRBM_GUI_ACTIVE / 8)"}
+    return total, ("live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate child runs of bench.py --sustained 200 --steps 5 "
+                   "--metric-only on this GPU, after the timed region); mean over the child's timed steps, summed over the launch's "
+                   "kernels; reads x2 (gfx950 FETCH_SIZE correction)"), detail, sq
 
 
 def self_launch(args):
@@ -481,7 +517,7 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: B={B} T={T} action_dim={A} codebook K={K} d={D}, "
-                               f"fp32 encoder + fp32 argmin (parity mode), "
+                               f"fp32 encoder + fp32 argmin (parity mode; distance screen on fp16 MFMA, exact fp32 re-scoring), "
                                + (f"global batch fixed: {B} sequences sharded {b_hi - b_lo} per GPU" if strong else
                                   f"per-GPU batch fixed at {B} sequences (global {world * B})"),
                    "rows_per_gpu": N, "global_rows": N_global,
@@ -584,10 +620,10 @@ def main():
                                               "+ the screen's 3 split products at 2500 TF/s"}}
     # HBM traffic LAST among the GPU readings: the profiler children run after every timed side reading (and are reaped before
     # this process goes on), so nothing of them can overlap a measurement
-    traffic, traffic_src, traffic_detail = None, None, None
+    traffic, traffic_src, traffic_detail, sq = None, None, None, None
     if args.traffic == "live" and world == 1 and not args.metric_only:
         try:
-            traffic, traffic_src, traffic_detail = measure_traffic_live(
+            traffic, traffic_src, traffic_detail, sq = measure_traffic_live(
                 args.workload, ("tokenize_kernel", "nearest_rows", "nearest_lists") if ops.tokenize_supported(A, 64, model.hidden_dim, D, K)
                 else ("mlp3_wg_kernel", "mlp3_lds_kernel", "screen_kernel", "nearest_rows", "nearest_lists"))
         except Exception as e:  # noqa: BLE001 -- the profiler is optional equipment; the committed measurement stands in
@@ -597,6 +633,12 @@ def main():
         t = json.loads(tfile.read_text())
         if t.get("workload") == args.workload:
             traffic, traffic_src = t.get("bytes_per_launch"), (traffic_src or "") + "committed: " + str(t.get("source"))
+    if sq is not None:
+        # the same fraction against peaks scaled to the clock the launch held (the datasheet peaks are 2.4 GHz figures)
+        out["roofline"].update({"mfma_busy_frac": sq["mfma_busy_frac"], "shader_clock_mhz": sq["shader_clock_mhz"],
+                                "frac_at_measured_clock": out["roofline"]["frac"] * 2400.0 / sq["shader_clock_mhz"],
+                                "frac_algorithmic_floor_at_measured_clock": out["roofline"]["frac_algorithmic_floor"] * 2400.0 / sq["shader_clock_mhz"],
+                                "sq_counters": sq})
     out["roofline"].update({"traffic": traffic, "traffic_source": traffic_src, "traffic_detail": traffic_detail,
                             "traffic_note": "includes N x D x 4 bytes of z_e STORES beyond the algorithmic bytes (134 MB at cfg2): the launch keeps "
                                             "z_e for its exact stage -- deciding the uncertified rows from stored rows beats re-encoding them from "

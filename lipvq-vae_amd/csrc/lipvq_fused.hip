@@ -595,6 +595,13 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
             // 16 x 17-instruction block behind each chain.
             f32x16 h1[T1];
             f32x16 pend;                      // pre-activations of the previous tile, GELU pending
+            // LUMPED (round 4): a tile's GELU as ONE block behind its MFMA chain instead of staged between the MFMAs of the next
+            // tile's chain (rounds 2-3).  scripts/probe/probe_roles.hip: fp32 MFMAs and fp32 vector work share the SIMD's lanes -- a
+            // pair of tiles on a SIMD's two waves takes the SUM of both (5 340 cycles) however the instructions are arranged -- but
+            // the interleaved stream loses another 9 % to issue arbitration between the two waves (5 843).  Same values either way:
+            // cfg2 0.4095 -> 0.3997 ms per launch, same box (profiles/r04_b_lumped_gelu_ab.txt).  Not where every output tile of
+            // layer 2 waits at a workgroup barrier for its streamed weights (S = 13: 0.934 -> 1.00 ms lumped) -- there the staging stays.
+            constexpr bool LUMPED = !VQ && !STREAM2;
             constexpr int G1 = S1 / 4, G2 = S2 / 4;             // groups per tile
             auto wread = [&](int gidx) {                        // group gidx of the stream (compile-time after unrolling)
                 if (STREAM2 && gidx >= T1 * G1) gidx = T1 * G1 - 1;             // streamed layer 2: its groups are read from the slab ring
@@ -654,13 +661,13 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                     __builtin_amdgcn_sched_barrier(0x6);         // reads stay in front of this group's MFMAs (VALU/SALU may move)
                     ActStage<VQ> g;
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, h0[(4 * sq + 0) / 16][(4 * sq + 0) % 16], acc, 0, 0, 0);
-                    if (t > 0) g.stage0(pend[2 * sq], pend[2 * sq + 1]);
+                    if (t > 0 && !LUMPED) g.stage0(pend[2 * sq], pend[2 * sq + 1]);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, h0[(4 * sq + 1) / 16][(4 * sq + 1) % 16], acc, 0, 0, 0);
-                    if (t > 0) g.stage1();
+                    if (t > 0 && !LUMPED) g.stage1();
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, h0[(4 * sq + 2) / 16][(4 * sq + 2) % 16], acc, 0, 0, 0);
-                    if (t > 0) g.stage2();
+                    if (t > 0 && !LUMPED) g.stage2();
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, h0[(4 * sq + 3) / 16][(4 * sq + 3) % 16], acc, 0, 0, 0);
-                    if (t > 0) {
+                    if (t > 0 && !LUMPED) {
 #ifndef LQ_ABL_NOGELU
                         float o0, o1;
                         g.stage3(o0, o1);
@@ -672,8 +679,20 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                     __builtin_amdgcn_sched_barrier(0x6);
                 }
 #ifndef LQ_ABL_NOGELU
-                if constexpr (!VQ) { if (t > 0) gelu_fixup(h1[t - 1], pend); }
+                if constexpr (!VQ) { if (t > 0 && !LUMPED) gelu_fixup(h1[t - 1], pend); }
 #endif
+                if constexpr (LUMPED) {
+#ifndef LQ_ABL_NOGELU
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const lq_v2f g2 = lq_gelu_poly2((lq_v2f){acc[r], acc[r + 1]});
+                        h1[t][r] = g2.x; h1[t][r + 1] = g2.y;
+                    }
+                    gelu_fixup(h1[t], acc);
+#else
+                    h1[t] = acc;
+#endif
+                }
                 pend = acc;
                 if constexpr (TRAIN) lq_tile_store16(a.pre1, 32 * T1, row, row < a.N, t, h, acc, 32 * T1, true);
             }
@@ -707,7 +726,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                     if (t == 0 && sq == 3 * (S2 / 16)) {
                         // h1[T1-1] is needed from here on (k-steps 48..63 of a 128-wide layer): finish its GELU
 #ifndef LQ_ABL_NOGELU
-                        if constexpr (!VQ) gelu_fixup(h1[T1 - 1], pend);
+                        if constexpr (!VQ && !LUMPED) gelu_fixup(h1[T1 - 1], pend);
 #endif
                     }
                     const float4 av = wn;
@@ -718,7 +737,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                     }
                     if (!STREAM2 && sq == G2 - 1 && t + 1 < T2) bnext = bias16(w_B2, t + 1);
                     __builtin_amdgcn_sched_barrier(0x6);
-                    const bool pg = (t == 0 && sq < 8);          // the 16 pending GELUs ride on groups 0..7 (< 12: they only read h1[0..2])
+                    const bool pg = (t == 0 && sq < 8 && !LUMPED);   // the 16 pending GELUs ride on groups 0..7 (< 12: they only read h1[0..2])
                     ActStage<VQ> g;
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, h1[(4 * sq + 0) / 16][(4 * sq + 0) % 16], acc, 0, 0, 0);
                     if (pg) g.stage0(pend[(2 * sq) & 15], pend[(2 * sq + 1) & 15]);
@@ -968,7 +987,10 @@ static int launch_tokenize_as(KFN kfn, LqLdsReserve& reserved, const TokArgs& a,
     if (int rc = lipvq_reserve_lds(reserved, (const void*)kfn, lds, "tokenize")) return rc;
     const int64_t unit = (int64_t)waves * rg * 32;
     const int64_t nblk = (a.N + unit - 1) / unit;
-    const int64_t blocks = nblk < 256 * LQ_EXP_WGS_PER_CU ? nblk : 256 * LQ_EXP_WGS_PER_CU;      // one persistent workgroup per CU
+    int64_t cap = 256 * LQ_EXP_WGS_PER_CU;                                                        // one persistent workgroup per CU
+    // (LIPVQ_TOK_GRID: measurement knob -- e.g. 252 leaves four CUs to a collective's kernel, scripts/dev/rccl_contention.py)
+    if (const char* e = lq_knob("LIPVQ_TOK_GRID")) { const int64_t g_ = atoll(e); if (g_ > 0) cap = g_; }
+    const int64_t blocks = nblk < cap ? nblk : cap;
     hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(waves * 64), lds, st, a);
     return check_launch("tokenize");
 }

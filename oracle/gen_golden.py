@@ -157,10 +157,11 @@ def run_llfq_big(ref, name, seed, N, A, D, K, chunk, oracle=None):
           f"rows with gap < 1e-6: {int((rel < 1e-6).sum())}")
 
 
-def run_nearties(ref, name, seed, N, K, D, chunk):
-    """The reference quantizer (LFQQuantizer.forward, v5:37-48) on adversarial near-tie rows (oracle.make_neartie_case);
+def run_nearties(ref, name, seed, N, K, D, chunk, case=None):
+    """The reference quantizer (LFQQuantizer.forward, v5:37-48) on adversarial near-tie rows (oracle.make_neartie_case, or
+    make_neartie3_case: a third code within the one-product screen's margin);
     inputs are re-drawn from the seed by the tests, the fixture keeps the reference's indices and top-2 distances."""
-    z, cb = O.make_neartie_case(seed, N, K, D)
+    z, cb = (case or O.make_neartie_case)(seed, N, K, D)
     q = ref.LFQQuantizer(K, D)
     idxs, d1s, d2s = [], [], []
     with torch.no_grad():
@@ -277,6 +278,15 @@ def run_big_all(v5, orc):
     run_llfq_big(v5, "llfq_cfg2_big", 501, 65536, 7, 64, 1024, chunk=256, oracle=orc)        # BASELINE config 2's widths
     run_llfq_big(v5, "llfq_cfg3_big", 502, 4096, 7, 128, 8192, chunk=32, oracle=orc)         # BASELINE config 3's widths
     run_llfq_big(v5, "llfq_icrt_big", 503, 16384, 12, 208, 1024, chunk=128, oracle=orc)      # the reference's own widths (v5:89-92)
+
+
+def run_round4_all(v5, orc):
+    """Round 4: BASELINE config 3's widths pinned to the reference at volume -- 32 768 rows instead of 4 096 --
+    and near-tie fixtures built for the one-product screen (three candidates per row)."""
+    run_nearties(v5, "llfq_neartri_d128_k8192", 641, 1024, 8192, 128, chunk=32, case=O.make_neartie3_case)
+    run_nearties(v5, "llfq_neartri_d208_k1024", 642, 512, 1024, 208, chunk=128, case=O.make_neartie3_case)
+    torch.set_num_threads(8)       # (the chunked distance is the same arithmetic at any thread count: reductions run along D only)
+    run_llfq_big(v5, "llfq_cfg3_big", 502, 32768, 7, 128, 8192, chunk=32, oracle=orc)
 
 
 def run_vq(ref, name, seed, N, A, D, K, regime="trained", oracle=None):
@@ -536,6 +546,7 @@ def main():
     ap.add_argument("--only-bin", action="store_true")
     ap.add_argument("--only-big", action="store_true")
     ap.add_argument("--only-odd", action="store_true", help="only the near-tie fixtures at latent widths that are not multiples of 8")
+    ap.add_argument("--only-round4", action="store_true", help="only llfq_cfg3_big at 32 768 rows and the three-candidate near-tie fixtures")
     args = ap.parse_args()
     if args.only_embed:
         GOLD.mkdir(parents=True, exist_ok=True)
@@ -559,6 +570,8 @@ def main():
         return run_big_all(v5, O.CanonicalOracle())
     if args.only_odd:
         return run_odd_width_all(v5, vq)
+    if args.only_round4:
+        return run_round4_all(v5, O.CanonicalOracle())
     torch.set_num_threads(1)       # what the reference's train() sets (scripts/train.py:57)
     orc = O.CanonicalOracle()
     # BASELINE config 1 (CPU plumbing case), full fwd + bwd + AdamW

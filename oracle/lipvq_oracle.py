@@ -638,6 +638,27 @@ def make_neartie_case(seed, N, K, D):
     return z, cb
 
 
+def make_neartie3_case(seed, N, K, D):
+    """Near-ties with a THIRD code close by (round 4, for the one-product screen): row i sits on the bisector of codes a_i, b_i as in
+    make_neartie_case, and code c_i = K - 1 - i is moved onto the sphere around the row through a_i, off by a relative
+    1e-5 ... 2e-3 in radius -- inside the one-product screen's margin (about 2^-9 of the cross term), mostly outside the
+    three-product screen's.  So the coarse screen must list THREE candidates (its 2nd and 3rd both within its bound) and the
+    exact stage must pick the reference's.  N <= K / 2; numpy PCG64 only."""
+    assert 2 * N <= K
+    rng = np.random.Generator(np.random.PCG64(seed))
+    cb = rng.uniform(0.0, 1.0, (K, D)).astype(np.float32)
+    a = rng.integers(0, K - N, N)
+    b = (a + 1 + rng.integers(0, K - N - 1, N)) % (K - N)
+    t = (np.float32(0.5) + ((np.arange(N) % 9) - 4).astype(np.float32) * np.float32(1e-8)).astype(np.float32)[:, None]
+    z = (cb[a] * t + cb[b] * (np.float32(1.0) - t)).astype(np.float32)
+    u = rng.standard_normal((N, D))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    r = np.linalg.norm(z.astype(np.float64) - cb[a].astype(np.float64), axis=1, keepdims=True)
+    delta = (np.array([1e-5, -1e-5, 1e-4, -1e-4, 5e-4, -5e-4, 2e-3, -2e-3])[np.arange(N) % 8])[:, None]
+    cb[K - 1 - np.arange(N)] = (z.astype(np.float64) + r * (1.0 + delta) * u).astype(np.float32)
+    return z, cb
+
+
 def params_digest(p):
     h = hashlib.sha256()
     for k in sorted(p):

@@ -1,6 +1,7 @@
 """Dev measurement (GPU box): the compute-side ceiling of BASELINE config 4 (cfg2's global batch sharded B/G per GPU)
 on ONE GPU: LLFQVAE_V4.tokenize at the shard sizes of G = 1, 2, 4, 8, 16, 32 (524 288 ... 16 384 rows).
-   python scripts/dev/shard_sweep.py [workload] [--fast]"""
+   python scripts/dev/shard_sweep.py [workload] [--fast]        (SWEEP_G=1,8: only those shard counts)"""
+import os
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
@@ -20,7 +21,7 @@ xfull = torch.randn(N, A, generator=torch.Generator(device="cpu").manual_seed(12
 idx_full, _ = model.tokenize(xfull, mode=mode)
 print(f"{wl} ({mode}): A={A} D={D} K={K}; one GPU, shard = first N/G rows of the global batch")
 print(f"{'G':>3} {'rows':>8} {'ms/launch':>10} {'M actions/s':>12} {'G x rate (ideal 1->G)':>22} {'exact rows':>10} {'== full-batch idx':>18}")
-for G in (1, 2, 4, 8, 16, 32):
+for G in tuple(int(g) for g in os.environ.get("SWEEP_G", "1,2,4,8,16,32").split(",")):
     n = N // G
     x = xfull[:n].contiguous()
     for _ in range(200):

@@ -78,6 +78,46 @@ def main():
         torch.cuda.synchronize()
         assert torch.equal(g, torch.full_like(g, world * (world + 1) / 2))
         rc.close()
+    # (c) bench.py's pattern (round 4, VERDICT r3 #4a): per-step histograms in two sets of M rows [M][K]; after M steps ONE
+    # asynchronous all-reduce covers the set while the next M tokenize launches fill the other one -- through torch.distributed
+    # and (nccl only) through lipvq_allreduce_counts on its side stream.  Every step's row must come back as the GLOBAL histogram.
+    M, steps = 4, 24
+    xs = xg[s:e].reshape(-1, A).contiguous()
+    routes = ["torch"] + (["capi"] if backend == "nccl" else [])
+    for route in routes:
+        rc2 = RcclCounts() if route == "capi" else None
+        ubuf = [torch.zeros(M, K, dtype=torch.int64, device=dev) for _ in range(2)]
+        pending, checked = [None, None], 0
+
+        def wait_set(b):
+            nonlocal checked
+            if pending[b] is None:
+                return
+            if rc2 is not None:
+                rc2.wait(pending[b])
+            else:
+                pending[b].wait()
+            pending[b] = None
+            torch.cuda.current_stream().synchronize()
+            for m in range(M):
+                assert torch.equal(ubuf[b][m], usage_full), f"{route}: bucket row {m} is not the global histogram"
+                checked += 1
+
+        for st_ in range(steps):
+            b, m = (st_ // M) & 1, st_ % M
+            if m == 0:
+                wait_set(b)                                    # that set's reduction is done before its rows are reused
+            row = ubuf[b][m]
+            row.zero_()
+            model.code_usage = row
+            model.tokenize(xs)                                 # launch k+1 in flight ...
+            if m == M - 1:                                     # ... while the set just filled is reduced
+                pending[b] = rc2.all_reduce(ubuf[b].view(-1)) if rc2 is not None else dist.all_reduce(ubuf[b], async_op=True)
+        for b in (0, 1):
+            wait_set(b)
+        assert checked == steps, (route, checked)
+        if rc2 is not None:
+            rc2.close()
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank}/{world} {backend}: ok", flush=True)

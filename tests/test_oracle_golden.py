@@ -17,8 +17,8 @@ from oracle import lipvq_oracle as O
 GOLD = Path(__file__).resolve().parent / "golden"
 TOL = 1e-5
 LLFQ = sorted(Path(p).stem for p in glob.glob(str(GOLD / "llfq_*.npz"))
-              if "nearest_edge" not in p and "nearties" not in p and "_train_" not in p and not p.endswith("_big.npz"))
-NEARTIES = sorted(Path(p).stem for p in glob.glob(str(GOLD / "llfq_nearties_*.npz")))
+              if "nearest_edge" not in p and "nearties" not in p and "neartri" not in p and "_train_" not in p and not p.endswith("_big.npz"))
+NEARTIES = sorted(Path(p).stem for p in glob.glob(str(GOLD / "llfq_nearties_*.npz")) + glob.glob(str(GOLD / "llfq_neartri_*.npz")))
 VQ_NEARTIES = sorted(Path(p).stem for p in glob.glob(str(GOLD / "vq_nearties_*.npz")))
 BIG = sorted(Path(p).stem for p in glob.glob(str(GOLD / "llfq_*_big.npz")))
 NEAR_TIE = 1e-6      # relative top-2 distance gap (in the reference's own fp32 distances) below which an index may differ
@@ -164,7 +164,9 @@ def test_adversarial_near_ties_exact(name, oracle):
     exact fp32 ties), so only the reference's exact arithmetic -- 8-accumulator sum, sqrt, first minimum -- decides them.
     The canonical quantizer must reproduce the REFERENCE's index on every row."""
     g = np.load(GOLD / f"{name}.npz")
-    z, cb = O.make_neartie_case(int(g["seed"]), int(g["N"]), int(g["K"]), int(g["D"]))
+    # (llfq_neartri_*: round 4 -- a third code within the one-product screen's margin, oracle.make_neartie3_case)
+    make = O.make_neartie3_case if "neartri" in name else O.make_neartie_case
+    z, cb = make(int(g["seed"]), int(g["N"]), int(g["K"]), int(g["D"]))
     idx, _, _ = oracle.nearest(z, cb)
     assert np.array_equal(idx, g["indices"].astype(np.int64))
     # ... and its two smallest distances are the reference's, bit for bit (a wrong summation order shows here first)
