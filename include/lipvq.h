@@ -46,6 +46,20 @@ enum {
 int lipvq_abi_version(void);
 const char* lipvq_last_error(void);
 
+/* Options: process-global switches for tests and measurements, set EXPLICITLY -- the library reads no environment variable.
+ * Results are identical under every setting (the parity suites run both screens and every kernel shape); only speed changes.
+ * value = NULL restores the default.  Unknown name: LIPVQ_EINVAL.  Read per launch unless noted.
+ *   screen_mode       "coarse" | "fine": force the one-product / three-product screen (default: the shape's measured winner,
+ *                     lipvq_screen_is_coarse)
+ *   tok_shape         "w8rg1" | "w8rg2" | "w4rg2" | "w4rg1": (waves per workgroup, row groups per wave) of the fused launch
+ *   tok_ze_rows       batch size up to which a fused launch stores z_e for its exact stage when nothing else asks for it
+ *   tok_grid          workgroups of the fused launch's persistent grid (default 256 = one per CU)
+ *   rows_grid, wgrad_chunk, wgrad_per_tile, wgrad_no_wg5, wgrad_rows, embed_bwd_grid, mlp3_small_tiles, mlp3_sub, mlp3_lds_rows
+ *                     grid / route choices of the exact-rows, weight-gradient, embedding-backward and MLP kernels (read ONCE, at the
+ *                     first launch of that kind: set them before it) */
+int lipvq_set_option(const char* name, const char* value);
+const char* lipvq_get_option(const char* name);        /* NULL = default */
+
 /* v5:6-12 normalization():  scale[i] = min(1, softplus(ci[i]) / sum_j |W[i][j]|),  Wn = W * scale.
  * W [D][H], ci [D]; scale [D] and Wn [D][H] are outputs (either may be NULL). */
 int lipvq_lipschitz_scale_f32(const float* W, const float* ci, float* scale, float* Wn, int D, int H,

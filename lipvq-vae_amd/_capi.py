@@ -32,6 +32,8 @@ _vp, _i, _i64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
 SIGNATURES = {
     "lipvq_abi_version": (_i, []),
     "lipvq_last_error": (C.c_char_p, []),
+    "lipvq_set_option": (_i, [C.c_char_p, C.c_char_p]),
+    "lipvq_get_option": (C.c_char_p, [C.c_char_p]),
     "lipvq_lipschitz_scale_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "lipvq_mlp3_packed_floats": (_sz, [_i, _i, _i, _i]),
     "lipvq_mlp3_pack_f32": (_i, [_vp] * 7 + [_i] * 4 + [_vp]),
@@ -133,6 +135,33 @@ def _load():
 
 
 lib = _load()
+
+
+OPTIONS = ("screen_mode", "tok_shape", "tok_ze_rows", "tok_grid", "rows_grid", "wgrad_chunk", "wgrad_per_tile", "wgrad_no_wg5",
+           "wgrad_rows", "embed_bwd_grid", "mlp3_small_tiles", "mlp3_sub", "mlp3_lds_rows")
+
+
+def set_option(name: str, value=None) -> None:
+    """lipvq_set_option (include/lipvq.h): a process-global switch for tests and measurements; value None = the default.
+    Results are the same under every setting."""
+    v = None if value is None else str(value).encode()
+    if lib.lipvq_set_option(name.encode(), v) != 0:
+        raise LipvqLibraryError(lib.lipvq_last_error().decode(errors="replace"))
+
+
+def get_option(name: str):
+    v = lib.lipvq_get_option(name.encode())
+    return None if v is None else v.decode()
+
+
+# Development hook: with LIPVQ_DEV_KNOBS=1 in the environment, LIPVQ_<OPTION> variables are forwarded ONCE, here, through
+# lipvq_set_option (scripts/dev/*: one-off measurements without touching code).  Without it the environment is ignored: the
+# library itself reads none.
+if _os.environ.get("LIPVQ_DEV_KNOBS") == "1":
+    for _o in OPTIONS:
+        _v = _os.environ.get("LIPVQ_" + _o.upper())
+        if _v is not None:
+            set_option(_o, _v)
 
 
 def check(status: int, what: str) -> None:

@@ -16,7 +16,7 @@
 static inline int wgrad_chunk_rows(int64_t N) {
     static int forced = -1;                      // LIPVQ_WGRAD_CHUNK: measurement knob
     if (forced < 0) {
-        const char* e = getenv("LIPVQ_WGRAD_CHUNK");
+        const char* e = lq_knob("LIPVQ_WGRAD_CHUNK");
         forced = e ? atoi(e) : 0;
     }
     if (forced > 0) return forced;
@@ -466,9 +466,9 @@ extern "C" int lipvq_wgrad_f32(const float* G, const float* H, const int64_t* hi
     float* partB = partW + (size_t)nch * J * Kd;
     const size_t lds = (size_t)32 * 32 * (TI + TJ) * sizeof(float);
     static int use_wg = -1;                     // LIPVQ_WGRAD_PER_TILE=1 forces the one-wave-per-tile kernel (measurement knob)
-    if (use_wg < 0) use_wg = getenv("LIPVQ_WGRAD_PER_TILE") ? 0 : 1;
+    if (use_wg < 0) use_wg = lq_knob("LIPVQ_WGRAD_PER_TILE") ? 0 : 1;
     static int use_wg5 = -1;                    // LIPVQ_WGRAD_NO_WG5=1: the single-buffered kernels (measurement knob)
-    if (use_wg5 < 0) use_wg5 = getenv("LIPVQ_WGRAD_NO_WG5") ? 0 : 1;
+    if (use_wg5 < 0) use_wg5 = lq_knob("LIPVQ_WGRAD_NO_WG5") ? 0 : 1;
     // one chunk (training-step batches of <= 128 rows): the kernel's slab IS the result, no reduce launch
     const bool direct = nch == 1;
     if (direct) { partW = gW; if (gb) partB = gb; }
@@ -488,7 +488,7 @@ extern "C" int lipvq_wgrad_f32(const float* G, const float* H, const int64_t* hi
         // pairs lose 5-15 % at 32 rows; a deeper register prefetch instead of occupancy changed nothing).
         // LIPVQ_WGRAD_ROWS=32|64 forces one size (measurement knob).
         static int rows_knob = -1;
-        if (rows_knob < 0) { const char* e = getenv("LIPVQ_WGRAD_ROWS"); rows_knob = e ? atoi(e) : 0; }
+        if (rows_knob < 0) { const char* e = lq_knob("LIPVQ_WGRAD_ROWS"); rows_knob = e ? atoi(e) : 0; }
         const bool r64 = TIk + TJ <= 10 && (rows_knob == 64 || (rows_knob != 32 && TIk + TJ < 6));
 #define LQ_W5(TI_, TJ_) if (TIk == TI_ && TJ == TJ_) kfn = r64 ? (wg5_fn)wgrad_wg5_kernel<TI_, TJ_, (TI_ + TJ_ <= 10 ? 64 : 32)> : (wg5_fn)wgrad_wg5_kernel<TI_, TJ_, 32>;
         LQ_W5(1, 1) LQ_W5(1, 2) LQ_W5(1, 4) LQ_W5(1, 7) LQ_W5(2, 1) LQ_W5(2, 2) LQ_W5(2, 4) LQ_W5(2, 7)

@@ -706,7 +706,7 @@ int lipvq_embed_rows_bwd_ws_f32(const float* gout, const float* src, const int64
     EmbedBwdArgs a{gout, src, idx, pos, stats, ln_w, g_src, g_pos, g_lnw, g_lnb, N, src_rows,
                    out_batch_stride, out_t_stride, out_offset, T, E, gv, idx_clean};
     static int grid_knob = -1;                                 // LIPVQ_EMBED_BWD_GRID: measurement knob
-    if (grid_knob < 0) { const char* e = getenv("LIPVQ_EMBED_BWD_GRID"); grid_knob = e ? atoi(e) : 1024; }
+    if (grid_knob < 0) { const char* e = lq_knob("LIPVQ_EMBED_BWD_GRID"); grid_knob = e ? atoi(e) : 1024; }
     const dim3 grid(grid_knob < T ? T : grid_knob), block(256);   // >= one workgroup per time step (T <= 1024)
     hipStream_t st = (hipStream_t)stream;
     switch ((E + 255) / 256) {

@@ -466,8 +466,13 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                 // high lanes: lo8[j] = feat 16+2j (from the low lane, even), hi8[j] = feat 16+2j+1 (own) -> base 32t+16
                 if (row < a.N && 2 * t + h < S) {                // (the high lanes' 16 features of a half-used last tile do not exist)
                     float4* dst = reinterpret_cast<float4*>(a.ze_out + (size_t)row * a.D + 32 * t + 16 * h);
+                    // nontemporal (round 4): written once, read back for a fraction of a percent of the rows -- the stream should not
+                    // displace the codebook tiles and weights every workgroup re-reads from L2 (with the z_q rows the same way:
+                    // cfg2 -2.4 %, icrt -2.9 %, same box, profiles/r04_e_nt_stores_ab.txt)
+                    typedef float lq_f4v __attribute__((ext_vector_type(4)));
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) dst[q] = make_float4(lo8[2 * q], hi8[2 * q], lo8[2 * q + 1], hi8[2 * q + 1]);
+                    for (int q = 0; q < 4; ++q)
+                        __builtin_nontemporal_store((lq_f4v){lo8[2 * q], hi8[2 * q], lo8[2 * q + 1], hi8[2 * q + 1]}, reinterpret_cast<lq_f4v*>(dst) + q);
                 }
             }
 #endif
@@ -938,9 +943,9 @@ template <int S, bool FAST, bool TRAIN = false, int RG = 1, bool COARSE = false,
 __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
     tokenize_body<S, FAST, TRAIN, RG, FUSED_WAVES, COARSE, VQ>(a);
 }
-template <int S, bool FAST, bool TRAIN, int RG>
+template <int S, bool FAST, bool TRAIN, int RG, bool COARSE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void tokenize_kernel_w4(TokArgs a) {
-    tokenize_body<S, FAST, TRAIN, RG, 4>(a);
+    tokenize_body<S, FAST, TRAIN, RG, 4, COARSE>(a);
 }
 
 template <int S, bool FAST>
@@ -963,7 +968,7 @@ static size_t fused_lds_bytes(int A, int K) {
 // (LIPVQ_TOK_SHAPE=w8rg1|w8rg2|w4rg2|w4rg1: measurement knob; results identical).
 struct TokShape { int waves, rg; };
 static TokShape tok_shape_env() {              // read per launch (a getenv: nanoseconds), so that a test can switch shapes in-process
-    const char* e = getenv("LIPVQ_TOK_SHAPE");
+    const char* e = lq_knob("LIPVQ_TOK_SHAPE");
     TokShape t{0, 0};
     if (e && !strcmp(e, "w8rg1")) t = {8, 1};
     if (e && !strcmp(e, "w8rg2")) t = {8, 2};
@@ -1000,7 +1005,11 @@ static int launch_tokenize(const TokArgs& a, hipStream_t st) {
     const size_t lds = fused_lds_bytes<S, FAST>(a.A, a.K);
     if (lds > 160 * 1024) return fail(LIPVQ_EUNSUPPORTED, "tokenize: %zu B of LDS needed", lds);
     const TokShape sh = tok_shape<S, FAST, TRAIN>(a.N);
-    static LqLdsReserve reserved[5];            // per instantiation and shape: per-device, thread-safe (lipvq_common.h)
+    static LqLdsReserve reserved[6];            // per instantiation and shape: per-device, thread-safe (lipvq_common.h)
+    if constexpr (!FAST && !TRAIN && S >= 8) {  // (one wave per SIMD with the whole register file: the instances that spill at two)
+        if (a.coarse && sh.waves == 4 && sh.rg == 1)
+            return launch_tokenize_as(tokenize_kernel_w4<S, FAST, TRAIN, 1, true>, reserved[5], a, lds, 4, 1, st);
+    }
     if constexpr (!FAST) {                      // (parity and training instances; the training forward writes z_e anyway)
         if (a.coarse) return launch_tokenize_as(tokenize_kernel<S, FAST, TRAIN, 1, true>, reserved[4], a, lds, 8, 1, st);
     }
@@ -1141,7 +1150,7 @@ static int tokenize_impl(const float* x, const float* packed, const void* packed
     // re-encoded with the fp32 encoder and get the parity mode's answer.
     // (LIPVQ_TOK_ZE_ROWS: measurement knob, the batch size up to which a launch stores z_e when nothing else asks for it; per launch)
     int64_t ze_rows = packed16 ? 131072 : INT64_MAX;
-    if (const char* ev = getenv("LIPVQ_TOK_ZE_ROWS")) ze_rows = atoll(ev);
+    if (const char* ev = lq_knob("LIPVQ_TOK_ZE_ROWS")) ze_rows = atoll(ev);
     if ((coarse || N <= ze_rows) && !ze_buf) {
         size_t off = 64 + lq_lists_bytes(N) + sizeof(float) * w2q_floats(D);
         off = (off + 255) & ~(size_t)255;

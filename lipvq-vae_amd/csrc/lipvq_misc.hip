@@ -25,7 +25,54 @@ int lipvq_check_launch(const char* what) {
     return LIPVQ_OK;
 }
 
-const char* lq_knob(const char* name) { return getenv(name); }
+// ------------------------------------------------------------------------------------------
+// options (include/lipvq.h): process-global, set EXPLICITLY through the ABI.  The shipped library reads no environment
+// variable (round 3's thirteen getenv sites meant a stray variable silently changed the product's speed); a development build
+// (-DLIPVQ_ENV_KNOBS, scripts/dev/ab_one.sh) falls back to LIPVQ_<NAME> in the environment for an option that was not set.
+// ------------------------------------------------------------------------------------------
+static const char* const g_opt_names[] = {"screen_mode", "tok_shape", "tok_ze_rows", "tok_grid", "rows_grid", "wgrad_chunk",
+                                          "wgrad_per_tile", "wgrad_no_wg5", "wgrad_rows", "embed_bwd_grid", "mlp3_small_tiles",
+                                          "mlp3_sub", "mlp3_lds_rows"};
+constexpr int kNumOpts = (int)(sizeof(g_opt_names) / sizeof(g_opt_names[0]));
+static char g_opt_vals[kNumOpts][32];
+static bool g_opt_set[kNumOpts];
+
+static int opt_index(const char* name) {          // "screen_mode" or "LIPVQ_SCREEN_MODE"
+    if (!name) return -1;
+    if (!strncmp(name, "LIPVQ_", 6)) name += 6;
+    for (int i = 0; i < kNumOpts; ++i) {
+        const char* a = g_opt_names[i];
+        const char* b = name;
+        while (*a && *b && (*a == *b || *a == (*b | 0x20))) { ++a; ++b; }
+        if (!*a && !*b) return i;
+    }
+    return -1;
+}
+
+const char* lq_knob(const char* name) {
+    const int i = opt_index(name);
+    if (i >= 0 && g_opt_set[i]) return g_opt_vals[i];
+#ifdef LIPVQ_ENV_KNOBS
+    return getenv(name);
+#else
+    return nullptr;
+#endif
+}
+
+extern "C" int lipvq_set_option(const char* name, const char* value) {
+    const int i = opt_index(name);
+    if (i < 0) return lipvq_fail(LIPVQ_EINVAL, "set_option: unknown option '%s'", name ? name : "(null)");
+    if (!value) { g_opt_set[i] = false; return LIPVQ_OK; }
+    if (strlen(value) >= sizeof(g_opt_vals[i])) return lipvq_fail(LIPVQ_EINVAL, "set_option: value too long");
+    strcpy(g_opt_vals[i], value);
+    g_opt_set[i] = true;
+    return LIPVQ_OK;
+}
+
+extern "C" const char* lipvq_get_option(const char* name) {
+    const int i = opt_index(name);
+    return (i >= 0 && g_opt_set[i]) ? g_opt_vals[i] : nullptr;
+}
 
 extern "C" int lipvq_abi_version(void) { return LIPVQ_ABI_VERSION; }
 extern "C" const char* lipvq_last_error(void) { return g_err; }

@@ -763,7 +763,7 @@ static mlp3_fn mlp3_select(int T0, int T1) {
 static int64_t mlp3_small_tiles() {
     static int64_t v = -1;
     if (v < 0) {
-        const char* e = getenv("LIPVQ_MLP3_SMALL_TILES");
+        const char* e = lq_knob("LIPVQ_MLP3_SMALL_TILES");
         v = e ? atoll(e) : INT64_MAX;
     }
     return v;
@@ -776,7 +776,7 @@ static int launch_mlp3_wg(const Mlp3Args& a, hipStream_t st, const char* what, b
     // two 32-row sub-tiles per workgroup from 4 096 rows on (more waves busy per layer, barriers shared by 64 rows); training-step
     // batches keep one, so that N = 80 still spreads over three workgroups.  LIPVQ_MLP3_SUB=1|2: measurement knob.
     static int forced = -1;
-    if (forced < 0) { const char* e = getenv("LIPVQ_MLP3_SUB"); forced = e ? atoi(e) : 0; }
+    if (forced < 0) { const char* e = lq_knob("LIPVQ_MLP3_SUB"); forced = e ? atoi(e) : 0; }
     // (two only while two such workgroups still share a CU's LDS: the 208-wide decoder input is faster with one; four is slower
     // everywhere: 3.75 -> 4.25 ms for the cfg2 training step)
     int nsub = (forced == 1 || forced == 2 || forced == 4) ? forced : ((a.N >= 4096 && 2 * plane <= 80 * 1024) ? 2 : 1);
@@ -798,7 +798,7 @@ static int launch_mlp3_wg(const Mlp3Args& a, hipStream_t st, const char* what, b
 static int64_t mlp3_lds_rows() {
     static int64_t v = -1;
     if (v < 0) {
-        const char* e = getenv("LIPVQ_MLP3_LDS_ROWS");
+        const char* e = lq_knob("LIPVQ_MLP3_LDS_ROWS");
         v = e ? atoll(e) : 65536;              // crossover with mlp3_wg_kernel (backward: 35 vs 56 us at 32 768, 67 vs 65 at 65 536, 145 vs 117 at 131 072)
         if (v == 0) v = INT64_MAX;
     }

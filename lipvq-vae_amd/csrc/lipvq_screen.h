@@ -805,7 +805,9 @@ __device__ __forceinline__ void lq_gather_flush(const unsigned char* wave_stage,
         const int src_lane = 4 * (p0 + p) + (lane >> 4);
         const bool ok = (__shfl((int)row_ok, src_lane, 64) != 0) && (row0 + src_lane < N) && (v < nvec);
         const float4 val = *reinterpret_cast<const float4*>(wave_stage + p * 1024 + lane * 16);
-        if (ok) reinterpret_cast<float4*>(zq + (size_t)(row0 + src_lane) * D)[v] = val;
+        // (nontemporal: an output stream of N x D floats that this launch never reads back; see the z_e stores in lipvq_fused.hip)
+        typedef float lq_f4v __attribute__((ext_vector_type(4)));
+        if (ok) __builtin_nontemporal_store((lq_f4v){val.x, val.y, val.z, val.w}, reinterpret_cast<lq_f4v*>(zq + (size_t)(row0 + src_lane) * D) + v);
     }
 }
 __device__ __forceinline__ void lq_screen_gather(const float* __restrict__ cb, float* __restrict__ zq, int my_k,

@@ -1180,7 +1180,7 @@ int lipvq_launch_rows_encode(const float* x, const float* const* raw6, int A, co
     RawEncoder w{raw6[0], raw6[1], raw6[2], raw6[3], raw6[4], raw6[5]};
     int64_t blocks = (N + 3) / 4;
     static int grid_cap = -1;                   // LIPVQ_ROWS_GRID: measurement knob
-    if (grid_cap < 0) { const char* e = getenv("LIPVQ_ROWS_GRID"); grid_cap = e ? atoi(e) : 1024; }      // (the count lives on the device; the grid strides)
+    if (grid_cap < 0) { const char* e = lq_knob("LIPVQ_ROWS_GRID"); grid_cap = e ? atoi(e) : 1024; }      // (the count lives on the device; the grid strides)
     if (blocks > grid_cap) blocks = grid_cap;
     auto go = [&](auto kfn) {
         hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(256), 0, st, x, w, A, cb, idx, zq,
@@ -1208,7 +1208,7 @@ extern "C" size_t lipvq_nearest_workspace_bytes(int64_t N) {
 // One-product ("coarse") or three-product screen.  LIPVQ_SCREEN_MODE=coarse|fine (read per launch; measurement knob --
 // identical results): the default is the shape's measured winner (lq_screen_coarse_default).
 int lq_screen_coarse(int S, int K) {
-    const char* e = getenv("LIPVQ_SCREEN_MODE");
+    const char* e = lq_knob("LIPVQ_SCREEN_MODE");
     if (e && !strcmp(e, "coarse")) return 1;
     if (e && !strcmp(e, "fine")) return 0;
     return lq_screen_coarse_default(S, K);

@@ -12,7 +12,7 @@ import ctypes as _C
 import torch
 
 from . import _capi
-from ._capi import (ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, DIST_NORM, DIST_SQSUM, check, lib)
+from ._capi import (ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, DIST_NORM, DIST_SQSUM, check, get_option, lib, set_option)  # noqa: F401
 
 __all__ = ["lipschitz_scale", "mlp3_pack", "mlp3", "nearest", "ste", "mse_pair", "ACT_NONE", "ACT_GELU",
            "ACT_SIGMOID", "ACT_RELU", "DIST_NORM", "DIST_SQSUM"]

@@ -21,8 +21,6 @@ only: the BASELINE metric's path) and ``perplexity()``.
 """
 from __future__ import annotations
 
-import os
-
 import torch
 import torch.nn as nn
 
@@ -108,8 +106,10 @@ class _ScreenMonitor:
         self.bypass_calls = 0
         self.last_fraction = None
 
+    ENABLED = True                # tests / measurements: False = always the screen (class attribute; no environment variable)
+
     def use_screen(self) -> bool:
-        if os.environ.get("LIPVQ_SCREEN_MONITOR", "1") == "0":      # measurement knob: always the screen
+        if not _ScreenMonitor.ENABLED:
             return True
         if torch.cuda.is_current_stream_capturing():
             return True                                  # a graph capture records one route; no host decisions inside it

@@ -1,13 +1,14 @@
-"""Dev measurement (GPU): LLFQVAE_V4.tokenize under the three-product and the one-product screen (LIPVQ_SCREEN_MODE, read per
-launch) over (D, K) -- the data behind lq_screen_coarse_default (lipvq_screen.h).   python scripts/dev/coarse_sweep.py"""
+"""Dev measurement (GPU): LLFQVAE_V4.tokenize under the three-product and the one-product screen (lipvq_set_option("screen_mode"),
+read per launch) over (D, K) -- the data behind lq_screen_coarse_default (lipvq_screen.h).   python scripts/dev/coarse_sweep.py"""
 import os
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
-os.environ["LIPVQ_SCREEN_MONITOR"] = "0"
 import torch
 import lipvq_vae_amd  # noqa: F401
-from lipvq_vae_amd.tokenizer import LLFQVAE_V4
+from lipvq_vae_amd import _capi
+from lipvq_vae_amd.tokenizer import LLFQVAE_V4, _ScreenMonitor
+_ScreenMonitor.ENABLED = False
 from bench import trained_like_
 
 N = 4096 * 128
@@ -21,7 +22,7 @@ for A, D, Ks in ((7, 64, (1024, 4096, 8192)), (7, 128, (1024, 2048, 4096, 8192))
         out = {}
         ref = None
         for mode in ("fine", "coarse"):
-            os.environ["LIPVQ_SCREEN_MODE"] = mode
+            _capi.set_option("screen_mode", mode)
             for _ in range(30):
                 idx, _ = model.tokenize(x, count_usage=False)
             torch.cuda.synchronize()
@@ -34,6 +35,6 @@ for A, D, Ks in ((7, 64, (1024, 4096, 8192)), (7, 128, (1024, 2048, 4096, 8192))
             out[mode] = (e0.elapsed_time(e1) / 60, int(model.last_exact_rows[0]))
             ref = idx if ref is None else ref
             assert torch.equal(idx, ref), "the two screens disagree"
-        del os.environ["LIPVQ_SCREEN_MODE"]
+        _capi.set_option("screen_mode", None)
         print(f"A={A:2d} D={D:3d} K={K:5d}: fine {out['fine'][0]:7.3f} ms ({out['fine'][1]:6d} rows)   coarse {out['coarse'][0]:7.3f} ms "
               f"({out['coarse'][1]:6d} rows)   coarse/fine {out['coarse'][0] / out['fine'][0]:.2f}", flush=True)

@@ -7,7 +7,7 @@ is in flight -- exactly the bench's pattern -- and the tokenizer grid at 256 wor
    side = torch     torch.distributed all_reduce(async_op=True) on a world-1 nccl group
    side = kernel    a stand-in that surely launches a kernel on a side stream: an in-place add over the [M][K] int64 bucket (32 KiB)
 A world-1 RCCL all-reduce may be a no-op; `kernel` is the conservative reading of what a real collective kernel would face.
-   python scripts/dev/rccl_contention.py [workload] [launches]      (library needs the LIPVQ_TOK_GRID knob)"""
+   python scripts/dev/rccl_contention.py [workload] [launches]      (the grid is set through lipvq_set_option("tok_grid"))"""
 import os
 import sys
 from pathlib import Path
@@ -17,6 +17,7 @@ os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
 import torch
 import torch.distributed as dist
 import lipvq_vae_amd  # noqa: F401
+from lipvq_vae_amd import _capi
 from lipvq_vae_amd.sharded import RcclCounts
 from lipvq_vae_amd.tokenizer import LLFQVAE_V4
 from bench import WORKLOADS, trained_like_
@@ -41,10 +42,7 @@ side_stream = torch.cuda.Stream()
 
 
 def run(side, grid):
-    if grid:
-        os.environ["LIPVQ_TOK_GRID"] = str(grid)
-    else:
-        os.environ.pop("LIPVQ_TOK_GRID", None)
+    _capi.set_option("tok_grid", str(grid) if grid else None)
     pending = [None, None]
 
     def wait(b):

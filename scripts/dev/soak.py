@@ -8,7 +8,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import numpy as np, torch
 import lipvq_vae_amd
 from lipvq_vae_amd import ops
-from lipvq_vae_amd.tokenizer import LLFQVAE_V4, VQVAE
+from lipvq_vae_amd.tokenizer import LLFQVAE_V4, VQVAE, _ScreenMonitor
 from lipvq_vae_amd.ops import ACT_RELU
 from bench import trained_like_
 
@@ -19,9 +19,9 @@ last_note = t0
 while time.time() - t0 < budget:
     D = int(rng.choice([32, 64, 128, 208])) if rng.random() < 0.6 else int(rng.integers(1, 209))
     K = int(rng.choice([37, 256, 1000, 1024, 2048, 8192])) if D <= 128 else int(rng.choice([128, 1024, 4096]))
-    os.environ["LIPVQ_SCREEN_MODE"] = str(rng.choice(["fine", "coarse"]))              # read per launch by the library
-    os.environ["LIPVQ_TOK_SHAPE"] = str(rng.choice(["w8rg1", "w8rg1", "w8rg2", "w4rg2", "w4rg1"]))
-    os.environ["LIPVQ_SCREEN_MONITOR"] = "0"
+    ops.set_option("screen_mode", str(rng.choice(["fine", "coarse"])))              # read per launch by the library
+    ops.set_option("tok_shape", str(rng.choice(["w8rg1", "w8rg1", "w8rg2", "w4rg2", "w4rg1"])))
+    _ScreenMonitor.ENABLED = False
     A = int(rng.choice([3, 7, 12]))
     N = int(rng.choice([1, 33, 257, 2049, 4100, 30000, 100001]))
     torch.manual_seed(int(rng.integers(1 << 30)))

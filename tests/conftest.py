@@ -52,3 +52,30 @@ def oracle():
 @pytest.fixture(scope="session")
 def golden_dir():
     return ROOT / "tests" / "golden"
+
+
+@pytest.fixture
+def lipvq_option():
+    """Set library options (lipvq_set_option, include/lipvq.h) for one test; every option is back at its default afterwards.
+    Usage: lipvq_option("screen_mode", "coarse")."""
+    import lipvq_vae_amd  # noqa: F401
+    from lipvq_vae_amd import _capi
+    touched = []
+
+    def set_(name, value):
+        touched.append(name)
+        _capi.set_option(name, value)
+
+    yield set_
+    for n in touched:
+        _capi.set_option(n, None)
+
+
+@pytest.fixture
+def no_screen_monitor():
+    """The host-side screen monitor off for one test (the screen runs even where it certifies little)."""
+    from lipvq_vae_amd.tokenizer import _ScreenMonitor
+    old = _ScreenMonitor.ENABLED
+    _ScreenMonitor.ENABLED = False
+    yield
+    _ScreenMonitor.ENABLED = old

@@ -14,14 +14,13 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("screen", ["default", "fine", "coarse"])
 @pytest.mark.parametrize("name", BIG)
-def test_tokenize_reproduces_reference_indices_full_size(name, screen, oracle, monkeypatch):
-    """screen: the library's own choice for the shape, or one of the two screens forced (LIPVQ_SCREEN_MODE, read per launch):
+def test_tokenize_reproduces_reference_indices_full_size(name, screen, oracle, lipvq_option, no_screen_monitor):
+    """screen: the library's own choice for the shape, or one of the two screens forced (lipvq_set_option("screen_mode"), read per launch):
     the three-product and the one-product screen must both reproduce the REFERENCE's indices -- whichever a shape defaults to,
     the other stays covered."""
     from lipvq_vae_amd.tokenizer import LLFQVAE_V4
     if screen != "default":
-        monkeypatch.setenv("LIPVQ_SCREEN_MODE", screen)
-    monkeypatch.setenv("LIPVQ_SCREEN_MONITOR", "0")
+        lipvq_option("screen_mode", screen)
     p, x, ref, gap = big_fixture(name, oracle)
     K, D = p["quantizer.codebook"].shape
     A = x.shape[1]

@@ -19,7 +19,7 @@ def _setup(seed, A, D, K, oracle):
 
 @pytest.mark.parametrize("N,A,D,K", [(5000, 7, 64, 1024), (1024, 7, 32, 256), (777, 12, 128, 1000), (33, 7, 64, 37),
                                      (1, 7, 32, 256), (256 * 300 + 5, 7, 64, 1024), (600, 3, 64, 512)])
-def test_fused_equals_oracle_and_unfused(oracle, monkeypatch, N, A, D, K):
+def test_fused_equals_oracle_and_unfused(oracle, lipvq_option, N, A, D, K):
     from lipvq_vae_amd import ops
     p, model = _setup(N + D, A, D, K, oracle)
     assert ops.tokenize_supported(A, 64, 128, D, K)
@@ -39,13 +39,13 @@ def test_fused_equals_oracle_and_unfused(oracle, monkeypatch, N, A, D, K):
     idx_b, zq_b, ze_b, _ = ops.tokenize(xt, packed, raw, cb, prep, usage=usage_b)
     assert ze_b is None and torch.equal(idx_b, idx) and torch.equal(zq_b, zq) and torch.equal(usage_b, usage)
     # ... and with z_e never stored: uncertified rows are re-encoded from x by the exact kernel (nearest_rows_encode_kernel: what
-    # large fast-mode batches run; LIPVQ_TOK_ZE_ROWS is read per launch; the one-product screen always stores)
-    monkeypatch.setenv("LIPVQ_TOK_ZE_ROWS", "0")
-    monkeypatch.setenv("LIPVQ_SCREEN_MODE", "fine")
+    # large fast-mode batches run; the tok_ze_rows option is read per launch; the one-product screen always stores)
+    lipvq_option("tok_ze_rows", "0")
+    lipvq_option("screen_mode", "fine")
     usage_c = torch.zeros(K, dtype=torch.int64, device="cuda")
     idx_c, zq_c, _, _ = ops.tokenize(xt, packed, raw, cb, prep, usage=usage_c)
-    monkeypatch.delenv("LIPVQ_TOK_ZE_ROWS")
-    monkeypatch.delenv("LIPVQ_SCREEN_MODE")
+    lipvq_option("tok_ze_rows", None)
+    lipvq_option("screen_mode", None)
     assert torch.equal(idx_c, idx) and torch.equal(zq_c, zq) and torch.equal(usage_c, usage)
     assert np.array_equal(ze.cpu().numpy(), ze_ref)
     assert np.array_equal(idx.cpu().numpy(), idx_ref)
@@ -157,14 +157,13 @@ def test_no_grad_forward_takes_the_fused_launch_and_agrees(oracle):
 
 @pytest.mark.parametrize("screen", ["fine", "coarse"])
 @pytest.mark.parametrize("N,A,D,K", [(5000, 7, 64, 1024), (2100, 12, 208, 1024), (3000, 7, 32, 256), (2500, 12, 128, 1000)])
-def test_training_forward_launch_equals_unfused(oracle, monkeypatch, N, A, D, K, screen):
+def test_training_forward_launch_equals_unfused(oracle, lipvq_option, no_screen_monitor, N, A, D, K, screen):
     """lipvq_tokenize_train_f32 (encoder + quantizer + everything autograd saves, one launch) against lipvq_mlp3_f32 with saved
     pre-activations + the stand-alone quantizer: z_e, the three pre-activations, indices and z_q bit for bit; and the module's
     gradients at a batch that takes this route equal the ones the unfused route gives."""
     from lipvq_vae_amd import ops
     from lipvq_vae_amd.autograd import _ENC_ACTS
-    monkeypatch.setenv("LIPVQ_SCREEN_MODE", screen)          # both screens exist for the training instance too
-    monkeypatch.setenv("LIPVQ_SCREEN_MONITOR", "0")
+    lipvq_option("screen_mode", screen)          # both screens exist for the training instance too
     p, model = _setup(N + D, A, D, K, oracle)
     x = O.make_inputs(N + 1, N, A)
     xt = torch.from_numpy(x).cuda()
@@ -227,15 +226,14 @@ def test_decoder_launch_with_folded_loss_equals_separate_launches(oracle, N, A, 
 
 @pytest.mark.parametrize("screen", ["fine", "coarse"])
 @pytest.mark.parametrize("N,A,D,K", [(5000, 7, 64, 128), (2100, 12, 208, 1024), (3000, 7, 32, 256), (2500, 12, 128, 1000)])
-def test_vq_training_forward_launch_equals_unfused(monkeypatch, N, A, D, K, screen):
+def test_vq_training_forward_launch_equals_unfused(monkeypatch, lipvq_option, no_screen_monitor, N, A, D, K, screen):
     """lipvq_vq_tokenize_train_f32 (the plain VQVAE's encoder + quantizer + saved pre-activations, one launch) against
     lipvq_mlp3_f32(relu x 3, saved pre-activations) + the stand-alone quantizer, bit for bit; and the module's gradients at a batch
     that takes this route equal the ones the unfused route gives."""
     from lipvq_vae_amd import ops
     from lipvq_vae_amd.autograd import _RELU3
     from lipvq_vae_amd.tokenizer import VQVAE
-    monkeypatch.setenv("LIPVQ_SCREEN_MODE", screen)
-    monkeypatch.setenv("LIPVQ_SCREEN_MONITOR", "0")
+    lipvq_option("screen_mode", screen)
     torch.manual_seed(N + D)
     model = VQVAE(A, D, num_embeddings=K).cuda()
     with torch.no_grad():
@@ -395,15 +393,15 @@ def test_backward_with_folded_loss_terms_equals_separate_launches(oracle, monkey
 
 @pytest.mark.parametrize("shape", ["w8rg2", "w4rg2", "w4rg1"])
 @pytest.mark.parametrize("N,A,D,K", [(256 * 300 + 5, 7, 64, 1024), (9000, 7, 32, 256), (4100, 7, 128, 2048), (3000, 12, 208, 1024)])
-def test_other_kernel_shapes_give_the_same_results(oracle, monkeypatch, shape, N, A, D, K):
+def test_other_kernel_shapes_give_the_same_results(oracle, lipvq_option, shape, N, A, D, K):
     """tokenize_kernel exists in four (waves per workgroup, 32-row groups per wave) shapes (lipvq_fused.hip: tok_shape); only one
     is the default, the others stay in the library as measured alternatives -- every one of them must return the oracle's
-    indices / z_q / usage (the shape only changes which wave owns which rows).  LIPVQ_TOK_SHAPE is read per launch."""
+    indices / z_q / usage (the shape only changes which wave owns which rows).  The tok_shape option is read per launch."""
     p, model = _setup(N + D + 7, A, D, K, oracle)
     x = O.make_inputs(N + 3, N, A)
     xt = torch.from_numpy(x).cuda()
     idx_ref, zq_ref, usage_ref = oracle.nearest(oracle.llfq_encode(p, x), p["quantizer.codebook"])
-    monkeypatch.setenv("LIPVQ_TOK_SHAPE", shape)
+    lipvq_option("tok_shape", shape)
     model.code_usage.zero_()
     idx, zq = model.tokenize(xt)
     assert np.array_equal(idx.cpu().numpy(), idx_ref) and np.array_equal(zq.cpu().numpy(), zq_ref)

@@ -154,13 +154,12 @@ def test_vq_forward_backward(name, oracle, golden_dir):
 
 @pytest.mark.parametrize("screen", ["fine", "coarse"])
 @pytest.mark.parametrize("A,D,K,N", [(7, 64, 1024, 70000), (12, 208, 512, 9000), (7, 32, 256, 5000), (9, 128, 2048, 6000)])
-def test_vq_fused_tokenize_equals_oracle(oracle, monkeypatch, A, D, K, N, screen):
+def test_vq_fused_tokenize_equals_oracle(oracle, lipvq_option, no_screen_monitor, A, D, K, N, screen):
     """The plain VQVAE's encode + quantize in ONE launch (lipvq_vq_tokenize_f32: the fused kernel's ReLU instance with per-row fp16
     scales, either screen): indices, z_e (through the straight-through value), usage -- the oracle's, bit for bit; and it equals
     the unfused route (mlp3 + screened quantizer)."""
     from lipvq_vae_amd.tokenizer import VQVAE
-    monkeypatch.setenv("LIPVQ_SCREEN_MODE", screen)
-    monkeypatch.setenv("LIPVQ_SCREEN_MONITOR", "0")
+    lipvq_option("screen_mode", screen)
     p = O.make_params(900 + D + K, A, D, K, variant="vq", oracle=oracle)
     x = O.make_inputs(901 + N, N, A)
     model = _model(VQVAE, p, A, D, num_embeddings=K)

@@ -146,12 +146,12 @@ def test_near_ties_go_to_exact_kernel(ops, oracle):
 @pytest.mark.parametrize("screen", ["fine", "coarse"])
 @pytest.mark.parametrize("name", ["llfq_nearties_d128_k8192", "llfq_nearties_d208_k1024", "llfq_nearties_d64_k1024",
                                   "llfq_neartri_d128_k8192", "llfq_neartri_d208_k1024"])
-def test_adversarial_near_ties_match_the_reference(ops, oracle, name, screen, golden_dir, monkeypatch):
+def test_adversarial_near_ties_match_the_reference(ops, oracle, name, screen, golden_dir, lipvq_option):
     """Bisector rows (+- k * 1e-8) at D = 128 / K = 8192, D = 208 / K = 1024 and D = 64 / K = 1024 against indices the
     REFERENCE quantizer produced (oracle/gen_golden.py::run_nearties): the certified screen must hand (nearly) all of them
     to the exact kernel and the answers must be the reference's, bit for bit -- through both quantizer routes, with the
     three-product and with the one-product screen."""
-    monkeypatch.setenv("LIPVQ_SCREEN_MODE", screen)
+    lipvq_option("screen_mode", screen)
     g = np.load(golden_dir / f"{name}.npz")
     N, K, D = int(g["N"]), int(g["K"]), int(g["D"])
     # llfq_neartri_* (round 4): bisector rows with a THIRD code moved to within 1e-5 ... 2e-3 (relative) of the same distance:
