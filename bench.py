@@ -325,6 +325,13 @@ def main():
     backend = os.environ.get("LIPVQ_BENCH_BACKEND", "nccl")
     if args.rehearse_launcher:
         return rehearse(args, rank, world, backend)
+    # stdout carries ONE JSON line.  RCCL (and gloo) print banners to the C stdout when a communicator is created ("RCCL version :
+    # ...", "[Gloo] Rank 0 is connected ..."): with more than one rank, file descriptor 1 points at stderr until the line is printed.
+    saved_stdout = None
+    if world > 1:
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
     if backend != "nccl":
         local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
@@ -658,9 +665,15 @@ def main():
             out["value"] = None
             out["error"] = (f"parity gate failed: {gate['index_mismatches']} index mismatches vs the reference CPU path, "
                             f"largest relative distance gap {gate['max_rel_distance_gap_of_mismatches']:.3g} >= {PARITY_GAP:g}")
+    if saved_stdout is not None:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
+        sys.stdout.flush()
+        os.dup2(2, 1)                       # (whatever the teardown prints is not part of the result)
         dist.destroy_process_group()
     if failed:
         raise SystemExit(3)

@@ -549,9 +549,19 @@ __global__ __launch_bounds__(64 * MLPL_WAVES) void mlp3_lds_kernel(Mlp3Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
     {   // the packed stack -> LDS (total is a multiple of 32 floats; the host checked the 16-byte alignment)
+        // four loads in flight per thread and round (round 4: `dst[i] = src[i]` compiles to one load, one s_waitcnt vmcnt(0), one
+        // ds_write per iteration -- eight dependent L2 round trips per thread for the cfg2 decoder's 64 KB, in front of every launch)
         const float4* __restrict__ src = reinterpret_cast<const float4*>(a.packed);
         float4* dst = reinterpret_cast<float4*>(mlpl_w);
-        for (int i = tid; i < (int)(L.total / 4); i += 64 * MLPL_WAVES) dst[i] = src[i];
+        const int nv = (int)(L.total / 4);
+        constexpr int NT = 64 * MLPL_WAVES;
+        for (int i0 = tid; i0 < nv; i0 += 4 * NT) {
+            float4 r[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int i = i0 + q * NT; r[q] = src[i < nv ? i : nv - 1]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int i = i0 + q * NT; if (i < nv) dst[i] = r[q]; }
+        }
     }
     __syncthreads();
     const float* P0 = mlpl_w + L.oP0 + lane;

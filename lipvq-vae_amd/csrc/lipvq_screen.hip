@@ -156,7 +156,10 @@ __global__ void prep_e2_kernel(const float* __restrict__ cb, const float* __rest
     }
     const float e2 = (float)s;
     *e2p = e2;
-    *enp = (float)(sqrt(s) * (1.0 + 1e-6));
+    // |-2 e'| (rounded up): what the one-product bound multiplies by.  prep_res_kernel overwrites it with the value of the
+    // REPRESENTED (scaled, then unscaled) operand once the scale is known; until then this already is an upper-bound-grade
+    // value, so the certification never depends on the order of the preparation launches
+    *enp = (float)(2.0 * sqrt(s) * (1.0 + 1e-6));
     atomicMax(&hdr[0], __float_as_uint(e2));          // non-negative floats order like their bit patterns
     atomicMax(&hdr[1], __float_as_uint(e2));          // Emax^2 (same quantity; kept separate for clarity)
     atomicMax(&hdr[2], __float_as_uint(mx));
@@ -1361,7 +1364,7 @@ extern "C" int lipvq_nearest_screened_f32(const float* z, const float* codebook,
     if (N == 0) return LIPVQ_OK;
     if (!z || !codebook || !prep || !idx || !workspace) return fail(LIPVQ_EINVAL, "nearest_screened: null pointer");
     if (N > 2147483647LL) return fail(LIPVQ_EUNSUPPORTED, "nearest_screened: N too large");
-    if (!(D & 7) && (((uintptr_t)z | (uintptr_t)codebook | (uintptr_t)zq) & 15) != 0)
+    if (!(D & 3) && (((uintptr_t)z | (uintptr_t)codebook | (uintptr_t)zq) & 15) != 0)       // (the kernels take float4 paths iff D % 4 == 0)
         return fail(LIPVQ_EINVAL, "nearest_screened: z, codebook and zq must be 16-byte aligned");
     return screened_impl(z, codebook, prep, idx, zq, usage, workspace, nullptr, N, K, D, LIPVQ_SCREEN_GAMMA,
                          (hipStream_t)stream);
@@ -1375,7 +1378,7 @@ extern "C" int lipvq_vq_nearest_screened_f32(const float* z, const float* codebo
     if (N == 0) return LIPVQ_OK;
     if (!z || !codebook || !prep || !idx || !workspace) return fail(LIPVQ_EINVAL, "vq_nearest_screened: null pointer");
     if (N > 2147483647LL) return fail(LIPVQ_EUNSUPPORTED, "vq_nearest_screened: N too large");
-    if (!(D & 7) && (((uintptr_t)z | (uintptr_t)codebook | (uintptr_t)zq) & 15) != 0)
+    if (!(D & 3) && (((uintptr_t)z | (uintptr_t)codebook | (uintptr_t)zq) & 15) != 0)
         return fail(LIPVQ_EINVAL, "vq_nearest_screened: z, codebook and zq must be 16-byte aligned");
     return screened_impl(z, codebook, prep, idx, zq, usage, workspace, nullptr, N, K, D, LIPVQ_SCREEN_GAMMA,
                          (hipStream_t)stream, LIPVQ_DIST_SQSUM);

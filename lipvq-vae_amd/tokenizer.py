@@ -112,7 +112,9 @@ class _ScreenMonitor:
         if not _ScreenMonitor.ENABLED:
             return True
         if torch.cuda.is_current_stream_capturing():
-            return True                                  # a graph capture records one route; no host decisions inside it
+            # a graph capture records ONE route and no host decision can run at replay: take the route the last eager reading
+            # chose (a codebook that was sending every row to the exact stage keeps the all-pairs kernel in the graph too)
+            return self.bypass_calls <= 0
         if self._pending is not None:
             ev, host, n, coarse = self._pending
             if ev.query():
