@@ -61,6 +61,12 @@ constexpr int fused_ring_tc(int S) { return (S <= 2) ? 4 : (S <= 4) ? 2 : (S == 
 #endif
 constexpr int fused_ring_nb(int S) { return (S <= 4) ? 4 : (S == 8) ? LQ_RING8_NB : LQ_RING13_NB; }
 #endif
+#ifndef LQ_COARSE_TC_WIDE
+#define LQ_COARSE_TC_WIDE 2       /* tiles per stage of the one-product S = 8 instance (1 = as the three-product ring) */
+#endif
+// S = 8 (cfg3): 1.610 -> 1.555 ms, same box.  Not S = 13: with two tiles per stage that instance runs 10 ms instead of 0.9 (its
+// 26-k-step stage body no longer fits the registers it has left beside 104 of row fragments) -- profiles/r04_f_coarse_ring_ab.txt
+constexpr int fused_ring_tc_coarse(int S) { return S == 8 ? LQ_COARSE_TC_WIDE * fused_ring_tc(S) : fused_ring_tc(S); }
 #ifndef LQ_EXP_WGS_PER_CU
 #define LQ_EXP_WGS_PER_CU 1
 #endif
@@ -108,6 +114,30 @@ struct ActStage<true> {
     __device__ __forceinline__ void stage3(float& o0, float& o1) { o0 = a_ > 0.0f ? a_ : 0.0f; o1 = b_ > 0.0f ? b_ : 0.0f; }
 };
 
+template <int S, bool FAST>
+__host__ __device__ static size_t fused_lds_bytes_nohist(int A) {
+    constexpr int T0 = 2, T1 = 4, T2 = (S + 1) / 2;
+    const int S0q = ((A + 1) / 2 + 3) / 4;
+    const int S0h = (A + 15) / 16;
+    size_t fl = FAST ? (size_t)T0 * S0h * 256 + (size_t)T1 * (2 * T0) * 256 + (size_t)T2 * (2 * T1) * 256
+                     : (size_t)T0 * S0q * 256 + (size_t)T1 * 8 * 256 + (S >= LQ_STREAM2_MIN_S ? (size_t)0 : (size_t)T2 * 16 * 256);
+    fl += 32 * T0 + 32 * T1 + 32 * T2 + 16 * S;
+    // (one size for both screens' instances: the larger ring)
+    constexpr size_t ring_fine = (size_t)fused_ring_nb(S) * ScreenCfg<S, fused_ring_tc(S), false>::STAGE_BYTES + 1024;
+    constexpr size_t ring_coarse = (size_t)fused_ring_nb(S) * ScreenCfg<S, fused_ring_tc_coarse(S), true>::STAGE_BYTES + 1024;
+    const size_t ring = ((ring_fine > ring_coarse ? ring_fine : ring_coarse) + 63) & ~(size_t)63;
+    return fl * sizeof(float) + ring;
+}
+// the per-workgroup usage histogram: codebooks of up to FUSED_HIST_MAX codes, where the LDS has room for it
+template <int S, bool FAST>
+__host__ __device__ static bool fused_hist_fits(int A, int K) {
+    return K <= FUSED_HIST_MAX && fused_lds_bytes_nohist<S, FAST>(A) + (size_t)K * 4 <= (size_t)160 * 1024;
+}
+template <int S, bool FAST>
+static size_t fused_lds_bytes(int A, int K) {
+    return fused_lds_bytes_nohist<S, FAST>(A) + (fused_hist_fits<S, FAST>(A, K) ? (size_t)K * 4 : 0);
+}
+
 struct TokArgs {
     const float* x;              // [N][A]
     const float* packed;         // lipvq_mlp3_pack_f32 of (A -> 64 -> 128 -> D)
@@ -153,7 +183,11 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
     static_assert(!VQ || (RG == 1 && !FAST), "the ReLU instance: one row group, parity arithmetic");
     static_assert(RG == 1 || RG == 2, "one or two row groups per wave");
     constexpr int THREADS = WAVES * 64;
-    constexpr int TCF = fused_ring_tc(S), NBF = fused_ring_nb(S);
+    // the one-product screen stages hi-only tiles (half the bytes): twice the tiles per stage in the same LDS, i.e. half the
+    // stage hand-overs (vmcnt wait + workgroup barrier + DMA issue) per tile where a stage was ONE tile (S = 8)
+    constexpr int TCF = COARSE ? fused_ring_tc_coarse(S) : fused_ring_tc(S), NBF = fused_ring_nb(S);
+    using RingCfg = ScreenCfg<S, TCF, COARSE>;
+    constexpr size_t SLAB_STRIDE = ScreenCfg<S, fused_ring_tc(S), false>::STAGE_BYTES;   // the streamed layer-2 slabs' three buffers (either screen)
     constexpr int T0 = 2, T1 = 4, T2 = (S + 1) / 2;         // S odd (D = 208): the last 32-feature tile is half used
     constexpr int S1 = 16 * T0, S2 = 16 * T1;               // k-steps (pairs) of layers 1 and 2
     // STREAM2: the Lipschitz layer's weights (T2 x 16 KB of fp32 MFMA A operands: 112 KB at D = 208) do not fit beside the stage
@@ -186,10 +220,11 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
     // per-workgroup usage histogram (K <= FUSED_HIST_MAX): LDS atomics per row, ONE global atomic per non-empty
     // bin at the end of this persistent workgroup -- skewed code distributions would otherwise serialise on a
     // few global addresses (see lq_usage_add)
-    constexpr size_t STAGES_BYTES = lq_ring_bytes<S, TCF, NBF>();        // the ring + its dummy KiB
+    constexpr size_t RING_OWN = (size_t)NBF * RingCfg::STAGE_BYTES + 1024, RING_FINE = lq_ring_bytes<S, fused_ring_tc(S), NBF>();
+    constexpr size_t STAGES_BYTES = RING_OWN > RING_FINE ? RING_OWN : RING_FINE;      // the ring + its dummy KiB (one LDS carve for both screens)
     static_assert(STAGES_BYTES >= (size_t)WAVES * LQ_DECIDE_BYTES, "the decision's per-wave transposes live in the stage ring");
     unsigned* hist = reinterpret_cast<unsigned*>(stage0 + ((STAGES_BYTES + 63) & ~(size_t)63));
-    const bool use_hist = a.usage && a.K <= FUSED_HIST_MAX;
+    const bool use_hist = a.usage && fused_hist_fits<S, FAST>(a.A, a.K);         // (the same rule sizes the launch's LDS)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform (scalar row/address arithmetic)
@@ -619,7 +654,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                 typedef const __attribute__((address_space(1))) void* glb_ptr_e;
 #endif
                 const unsigned char* src = reinterpret_cast<const unsigned char*>(a.w2q) + (size_t)t_ * (G2 * 1024);
-                unsigned char* dst = stage0 + (size_t)buf_ * ScreenCfg<S, TCF>::STAGE_BYTES;
+                unsigned char* dst = stage0 + (size_t)buf_ * SLAB_STRIDE;
                 // the lane offset is made opaque HERE: the 14 source addresses of a row block's slabs do not change from block to
                 // block, hipcc hoisted them out of the block loop as 64-bit VGPR pairs and (S = 13: 190 spilled registers) spilled
                 // eleven of them -- each DMA then sat behind `scratch_load; s_waitcnt vmcnt(0)`, and vmcnt(0) also waits for every
@@ -705,7 +740,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
             // the last tile's GELU runs inside the first layer-2 chain: steps 0 .. 47 of that chain only read h1[0..2]
             constexpr int SLAB_BYTES = G2 * 1024;                          // one output tile's A operands: 16 KB
             constexpr int SLAB_CPW = SLAB_BYTES / 1024 / WAVES;
-            static_assert(!STREAM2 || (SLAB_BYTES % (1024 * WAVES) == 0 && SLAB_BYTES <= ScreenCfg<S, TCF>::STAGE_BYTES && NBF >= 3),
+            static_assert(!STREAM2 || (SLAB_BYTES % (1024 * WAVES) == 0 && SLAB_BYTES <= SLAB_STRIDE && 3 * SLAB_STRIDE <= STAGES_BYTES),
                           "slabs ride in the stage ring");
 #pragma unroll
             for (int t = 0; t < T2; ++t) {
@@ -721,7 +756,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                     // vector-memory load, and waiting for it (`vmcnt(0)`) waits for the slab copy just issued as well
                     unsigned lane4 = (unsigned)lane * 4u;
                     asm volatile("" : "+v"(lane4));
-                    wslab = reinterpret_cast<const float*>(stage0 + (size_t)(t % 3) * ScreenCfg<S, TCF>::STAGE_BYTES) + lane4;
+                    wslab = reinterpret_cast<const float*>(stage0 + (size_t)(t % 3) * SLAB_STRIDE) + lane4;
                     wn = *reinterpret_cast<const float4*>(wslab);                     // the tile's first group (read after the barrier)
                     bnext = bias16(w_B2, t);                                            // (no bias prefetch here: registers)
                 }
@@ -946,18 +981,6 @@ __global__ __launch_bounds__(FUSED_THREADS) void tokenize_kernel(TokArgs a) {
 template <int S, bool FAST, bool TRAIN, int RG, bool COARSE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void tokenize_kernel_w4(TokArgs a) {
     tokenize_body<S, FAST, TRAIN, RG, 4, COARSE>(a);
-}
-
-template <int S, bool FAST>
-static size_t fused_lds_bytes(int A, int K) {
-    constexpr int T0 = 2, T1 = 4, T2 = (S + 1) / 2;
-    const int S0q = ((A + 1) / 2 + 3) / 4;
-    const int S0h = (A + 15) / 16;
-    size_t fl = FAST ? (size_t)T0 * S0h * 256 + (size_t)T1 * (2 * T0) * 256 + (size_t)T2 * (2 * T1) * 256
-                     : (size_t)T0 * S0q * 256 + (size_t)T1 * 8 * 256 + (S >= LQ_STREAM2_MIN_S ? (size_t)0 : (size_t)T2 * 16 * 256);
-    fl += 32 * T0 + 32 * T1 + 32 * T2 + 16 * S;
-    const size_t ring = (lq_ring_bytes<S, fused_ring_tc(S), fused_ring_nb(S)>() + 63) & ~(size_t)63;
-    return fl * sizeof(float) + ring + (K <= FUSED_HIST_MAX ? (size_t)K * 4 : 0);
 }
 
 // Which (waves per workgroup, row groups per wave) instance runs.  Measured on one box (profiles/r03_d_tokenize_shapes_ab.txt):
