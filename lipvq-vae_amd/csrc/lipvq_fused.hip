@@ -396,11 +396,49 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
     bool have_pend = false;
 #pragma unroll
     for (int g_ = 0; g_ < RG; ++g_) { pend_kg[g_] = 0; pend_okg[g_] = false; pend_row0g[g_] = 0; }
+    // z_e row store of one finished 32-feature tile.  Lane (n, h) holds features 32t + 2r + h (r = 0..15) of row n: the even ones in
+    // the low half-wave, the odd ones in the high half.  One v_permlane32_swap per register pair (low half's r >= 8 <-> high
+    // half's r < 8) leaves the low lane with features 32t .. 32t+15 and the high lane with 32t+16 .. 32t+31, i.e. four 16-byte
+    // stores of consecutive floats per lane (64 contiguous bytes per lane) instead of sixteen 4-byte stores scattered over the row.
+    auto store_ze_tile = [&](const int64_t row, const int t, const f32x16& acc) {
+            {
+                float lo8[8], hi8[8];                 // after the swaps: lo8[j] = feature base + 2j, hi8[j] = base + 2j + 1
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    // vdst = low half's register r = 8 + j (goes up), src = high half's register r = j (comes down)
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[j]), __float_as_uint(acc[8 + j]), false, false);
+                    // sw[0]: lanes 0-31 keep acc[j] (own even features 2j), lanes 32-63 receive low half's acc[8+j]
+                    // sw[1]: lanes 0-31 receive high half's acc[j] (odd features 2j+1), lanes 32-63 keep acc[8+j]
+                    lo8[j] = __uint_as_float(sw[0]);
+                    hi8[j] = __uint_as_float(sw[1]);
+                }
+                // low lanes : lo8[j] = feat 2j (own, even), hi8[j] = feat 2j+1 (from the high lane)        -> base 32t
+                // high lanes: lo8[j] = feat 16+2j (from the low lane, even), hi8[j] = feat 16+2j+1 (own) -> base 32t+16
+                if (row < a.N && 2 * t + h < S) {                // (the high lanes' 16 features of a half-used last tile do not exist)
+                    float4* dst = reinterpret_cast<float4*>(a.ze_out + (size_t)row * a.D + 32 * t + 16 * h);
+                    // nontemporal (round 4): written once, read back for a fraction of a percent of the rows -- the stream should not
+                    // displace the codebook tiles and weights every workgroup re-reads from L2 (with the z_q rows the same way:
+                    // cfg2 -2.4 %, icrt -2.9 %, same box, profiles/r04_e_nt_stores_ab.txt)
+                    typedef float lq_f4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        __builtin_nontemporal_store((lq_f4v){lo8[2 * q], hi8[2 * q], lo8[2 * q + 1], hi8[2 * q + 1]}, reinterpret_cast<lq_f4v*>(dst) + q);
+                }
+            }
+    };
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
 #ifdef LQ_STAMPS
         st_prev = __builtin_amdgcn_s_memtime();
 #endif
         f16x8 ahg[RG][S], alg[RG][S];
+        // z_e of each group's LAST layer-2 tile, stored behind the screen's first copies -- in the instances with registers to spare
+        // (S <= 4: cfg2 0.4006 -> 0.3944 ms; at S = 13 the sixteen registers held across the end of layer 2 cost more than the
+        // wait they remove: icrt 0.8945 -> 0.9149, profiles/r04_g_ze_store_placement.txt)
+#ifndef LQ_DEFER_ZE_MAX_S
+#define LQ_DEFER_ZE_MAX_S 4
+#endif
+        constexpr bool DEFER_ZE = S <= LQ_DEFER_ZE_MAX_S;
+        f32x16 zdefg[RG];
         float n2g[RG], a2g[RG], fzg[RG], fowng[RG];
       // ---- phase A of row group GC: the round-2 block body, on this group's rows / fragments / pending z_q copy ----
       auto encode_group = [&](auto GC) {
@@ -480,35 +518,13 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                 if constexpr (COARSE) a2lo = lq_fma(rs, rs, a2lo);
             }
           }
-            // z_e row store.  Lane (n, h) holds features 32t + 2r + h (r = 0..15) of row n: the even ones in
-            // the low half-wave, the odd ones in the high half.  One v_permlane32_swap per register pair
-            // (low half's r >= 8 <-> high half's r < 8) leaves the low lane with features 32t .. 32t+15 and
-            // the high lane with 32t+16 .. 32t+31, i.e. four 16-byte stores of consecutive floats per lane
-            // (64 contiguous bytes per lane) instead of sixteen 4-byte stores scattered over the row.
+            // z_e rows for the exact stage (store_ze_tile).  The LAST tile's are not stored here: its sixteen values wait in zdefg and
+            // are stored behind the screen's first stage copies (lq_screen_core_rg, DEFER) -- in front of them their write
+            // acknowledgements stood between every wave and "stage 0 has landed" (vmcnt retires in order)
 #ifndef LQ_ABL_NOZESTORE
             if (a.ze_out) {
-                float lo8[8], hi8[8];                 // after the swaps: lo8[j] = feature base + 2j, hi8[j] = base + 2j + 1
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    // vdst = low half's register r = 8 + j (goes up), src = high half's register r = j (comes down)
-                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[j]), __float_as_uint(acc[8 + j]), false, false);
-                    // sw[0]: lanes 0-31 keep acc[j] (own even features 2j), lanes 32-63 receive low half's acc[8+j]
-                    // sw[1]: lanes 0-31 receive high half's acc[j] (odd features 2j+1), lanes 32-63 keep acc[8+j]
-                    lo8[j] = __uint_as_float(sw[0]);
-                    hi8[j] = __uint_as_float(sw[1]);
-                }
-                // low lanes : lo8[j] = feat 2j (own, even), hi8[j] = feat 2j+1 (from the high lane)        -> base 32t
-                // high lanes: lo8[j] = feat 16+2j (from the low lane, even), hi8[j] = feat 16+2j+1 (own) -> base 32t+16
-                if (row < a.N && 2 * t + h < S) {                // (the high lanes' 16 features of a half-used last tile do not exist)
-                    float4* dst = reinterpret_cast<float4*>(a.ze_out + (size_t)row * a.D + 32 * t + 16 * h);
-                    // nontemporal (round 4): written once, read back for a fraction of a percent of the rows -- the stream should not
-                    // displace the codebook tiles and weights every workgroup re-reads from L2 (with the z_q rows the same way:
-                    // cfg2 -2.4 %, icrt -2.9 %, same box, profiles/r04_e_nt_stores_ab.txt)
-                    typedef float lq_f4v __attribute__((ext_vector_type(4)));
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        __builtin_nontemporal_store((lq_f4v){lo8[2 * q], hi8[2 * q], lo8[2 * q + 1], hi8[2 * q + 1]}, reinterpret_cast<lq_f4v*>(dst) + q);
-                }
+                if (DEFER_ZE && t == T2 - 1) zdefg[g] = acc;
+                else store_ze_tile(row, t, acc);
             }
 #endif
         };
@@ -748,6 +764,8 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                 if constexpr (STREAM2) {
                     // slab t has landed in every wave's part (slab t+1 may still fly); everyone has left tile t-1, whose buffer
                     // slab t+2 goes to.  (Slabs 0 and 1 were issued in front of layer 1.)
+                    // (round 4, not kept: counting the previous tile's four z_e stores out of this wait -- they are younger than slab t --
+                    // made icrt slower, 0.886 -> 0.908 ms: profiles/r04_g_ze_store_placement.txt)
                     if (t + 1 < T2) lq_wait_vmcnt<SLAB_CPW>(); else lq_wait_vmcnt<0>();
                     lq_wg_barrier();
                     if (t + 2 < T2) slab_dma(t + 2, (t + 2) % 3);
@@ -917,7 +935,15 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                 for (int r = 0; r < 16; ++r) znrg[g_][r] = 0.0f;
             }
         }
-        lq_screen_core_rg<S, THREADS, TCF, NBF, PACKF, RG, COARSE>(ahg, alg, tiles, L.ntiles, stage0, tid, frow, znrg, m1g, m2g, k1g);
+#ifdef LQ_ABL_NOZESTORE
+        const bool have_def = false;
+#else
+        const bool have_def = DEFER_ZE && a.ze_out != nullptr;
+#endif
+        lq_screen_core_rg<S, THREADS, TCF, NBF, PACKF, RG, COARSE, 4 * RG>(ahg, alg, tiles, L.ntiles, stage0, tid, frow, znrg, m1g, m2g, k1g, have_def, [&]() {
+#pragma unroll
+            for (int g_ = 0; g_ < RG; ++g_) store_ze_tile(((blk * WAVES + wave) * RG + g_) * 32 + ln, T2 - 1, zdefg[g_]);
+        });
         LQ_STAMP(4);
         const unsigned keep_mask = PACKF ? ~((1u << lq_pack_bits(L.ntiles)) - 1u) : 0xffffffffu;
         unsigned char* scratch = stage0 + (size_t)wave * LQ_DECIDE_BYTES;

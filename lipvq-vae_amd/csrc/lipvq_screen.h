@@ -218,12 +218,20 @@ __host__ __device__ static inline int lq_pack_bits(int ntiles) { int b = 1; whil
 // RG row groups per wave (round 3): the wave multiplies RG x 32 rows against every tile, so that one pair of B-fragment reads,
 // one |e'|^2 read, one stage hand-over (wait, barrier, DMA issue) serve RG x 3 MFMAs per k-step instead of 3, and consecutive
 // MFMAs go to different accumulators.  ah/al/m1/m2/k1 carry the group as their leading dimension.
-template <int S, int NT, int TC_ = screen_default_tc(S), int NB = 4, bool PACK = false, int RG = 1, bool COARSE = false>
+// DEFER (round 4): the caller's last vector-memory stores before the screen (the fused launch's z_e rows of its last layer-2 tile:
+// NDEF store instructions per wave when `have_def`) are issued by `deferred()` BEHIND the prologue's stage copies instead of in
+// front of them.  vmcnt retires in order: issued in front, their write acknowledgements (microseconds) stood between every wave
+// and "stage 0 has landed" -- 3.5 % of the cfg2 launch (profiles/r04_g_ze_store_placement.txt).  Behind the copies, the prologue's
+// wait and the first hand-over simply leave NDEF more operations outstanding.
+struct LqNoDeferred { __device__ __forceinline__ void operator()() const {} };
+template <int S, int NT, int TC_ = screen_default_tc(S), int NB = 4, bool PACK = false, int RG = 1, bool COARSE = false, int NDEF = 0,
+          typename DEFERRED = LqNoDeferred>
 __device__ __forceinline__ void lq_screen_core_rg(const f16x8 (&ah)[RG][S], const f16x8 (&al)[RG][S],
                                                   const unsigned char* __restrict__ tiles, int ntiles,
                                                   unsigned char* stage0, int tid, const float (&frow)[16],
                                                   const float (&znr)[RG][16],
-                                                  float (&m1)[RG][16], float (&m2)[RG][16], int (&k1)[RG][16]) {
+                                                  float (&m1)[RG][16], float (&m2)[RG][16], int (&k1)[RG][16],
+                                                  bool have_def = false, DEFERRED deferred = DEFERRED()) {
     using C = ScreenCfg<S, TC_, COARSE>;
     // NB = 2 is NOT a ring this loop can run: with one stage in flight (PD = 1) stage st+1 is only ISSUED at the hand-over in the
     // middle of stage st, and nothing waits for it before the read-ahead crosses into it.  (An experiment build with 2 x 4 tiles
@@ -290,9 +298,17 @@ __device__ __forceinline__ void lq_screen_core_rg(const f16x8 (&ah)[RG][S], cons
     // prologue: stages 0 .. PD-1 in flight, stage 0 landed
 #pragma unroll
     for (int p = 0; p < PD; ++p) stage_dma(p, p);
+    static_assert((PD - 1) * CPW + NDEF < 64, "vmcnt immediate");
+    if (NDEF > 0 && have_def) {                   // (launch-uniform)
+        deferred();
 #ifndef LQ_ABL_NOSTAGE
-    lq_wait_vmcnt<(PD - 1) * CPW>();
+        lq_wait_vmcnt<(PD - 1) * CPW + NDEF>();
 #endif
+    } else {
+#ifndef LQ_ABL_NOSTAGE
+        lq_wait_vmcnt<(PD - 1) * CPW>();
+#endif
+    }
     lq_wg_barrier();
 
     // two named accumulators (per row group): the chain of tile i runs into one while the other (tile i-1) is booked
@@ -334,7 +350,9 @@ __device__ __forceinline__ void lq_screen_core_rg(const f16x8 (&ah)[RG][S], cons
                 // ---- mid-stage hand-over: stage st+1 has landed everywhere (the PD-2 younger stages may still fly); everyone has
                 // left stage st-1, whose buffer is the one stage st+PD goes to
 #ifndef LQ_ABL_NOSTAGE
-                lq_wait_vmcnt<(PD >= 2 ? (PD - 2) * CPW : 0)>();
+                // (the first hand-over of a pass with deferred stores: they are younger than stage 1's copy and need not be done)
+                if (NDEF > 0 && have_def && st == 0) lq_wait_vmcnt<(PD >= 2 ? (PD - 2) * CPW : 0) + (PD >= 2 ? NDEF : 0)>();
+                else lq_wait_vmcnt<(PD >= 2 ? (PD - 2) * CPW : 0)>();
 #endif
 #ifndef LQ_ABL_NOBARRIER
                 lq_wg_barrier();

@@ -44,7 +44,7 @@ while time.time() - t0 < budget:
         ze = ze.clone(); ze[:m] = cb[ia] * t + cb[ib] * (1 - t); ze[m:m + max(1, m // 4)] = cb[ia[:max(1, m // 4)]]
     for dist in (0, 1):                                     # the norm rule (LLFQ) and the sum rule (plain VQVAE)
         ref, _, _ = ops.nearest(ze, cb, dist=dist)
-        tag = (N, A, D, K, dist, os.environ["LIPVQ_SCREEN_MODE"])
+        tag = (N, A, D, K, dist, ops.get_option("screen_mode"))
         if ops.nearest_screen_supported(K, D):
             idx_s, zq_s, ws = ops.nearest_screened(ze, cb, ops.nearest_prepare(cb), return_workspace=True, dist=dist)
             assert torch.equal(idx_s, ref), ("screened",) + tag
@@ -56,7 +56,7 @@ while time.time() - t0 < budget:
     if ops.tokenize_supported(A, 64, 128, D, K):
         idx_f, zq_f = model.tokenize(x, count_usage=False)
         ref_f, _, _ = ops.nearest(model.encode(x), cb)
-        assert torch.equal(idx_f, ref_f), ("fused", N, A, D, K, os.environ["LIPVQ_SCREEN_MODE"], os.environ["LIPVQ_TOK_SHAPE"])
+        assert torch.equal(idx_f, ref_f), ("fused", N, A, D, K, ops.get_option("screen_mode"), ops.get_option("tok_shape"))
         assert torch.equal(zq_f, cb[ref_f])
     if ops.tokenize_supported(A, 64, 128, D, K) and N > 2048 and K >= 64:
         # the plain VQVAE's fused launch (ReLU instance, per-row scales) against its own encoder + the all-pairs kernel
@@ -67,7 +67,7 @@ while time.time() - t0 < budget:
         idx_v, zst_v = vq.tokenize(x, count_usage=False)
         ze_v = vq.encode(x)
         ref_v, zq_v, _ = ops.nearest(ze_v, vq.embedding.weight.detach(), dist=1)
-        assert torch.equal(idx_v, ref_v), ("vq fused", N, A, D, K, os.environ["LIPVQ_SCREEN_MODE"])
+        assert torch.equal(idx_v, ref_v), ("vq fused", N, A, D, K, ops.get_option("screen_mode"))
         assert torch.equal(zst_v, ops.ste(ze_v, zq_v))
     cases += 1; rows += N
     if time.time() - last_note > 60:                          # (a silent GPU run is taken to be hung after 7 minutes)
