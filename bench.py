@@ -414,8 +414,8 @@ def main():
         step_no[0] += 1
         if m == 0:
             wait_pending(b)                 # the stream waits for that set's reduction before its rows are reused
+            ubuf[b].zero_()                 # ONE fill per set of M steps (a fill per step is a 2-3 us launch: 4 % of a 65 536-row shard's step)
         row = ubuf[b][m]
-        row.zero_()
         model.code_usage = row
         last_row[0] = row
         # == LLFQVAE_V4.tokenize: ONE fused launch (encoder + Lipschitz layer + MFMA screen, csrc/lipvq_fused.hip)
@@ -649,8 +649,8 @@ def main():
     out["roofline"].update({"traffic": traffic, "traffic_source": traffic_src, "traffic_detail": traffic_detail,
                             "traffic_note": "includes N x D x 4 bytes of z_e STORES beyond the algorithmic bytes (134 MB at cfg2): the launch keeps "
                                             "z_e for its exact stage -- deciding the uncertified rows from stored rows beats re-encoding them from "
-                                            "x by 2.4 % of the whole call (profiles/r03_z_ze_store_ab.txt); the launch is matrix-pipe bound, these "
-                                            "stores are not re-reads and do not bind"})
+                                            "x (profiles/r03_z_ze_store_ab.txt); per kernel and per cause: profiles/r04_e_traffic_accounting.md "
+                                            "(z_e / z_q rows are nontemporal stores, for which WRITE_SIZE reads 5-15 % above the bytes stored)"})
     failed = False
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], gate = cpu_baseline(model, x, idx_timed)
