@@ -328,7 +328,7 @@ def main():
     # stdout carries ONE JSON line.  RCCL (and gloo) print banners to the C stdout when a communicator is created ("RCCL version :
     # ...", "[Gloo] Rank 0 is connected ..."): with more than one rank, file descriptor 1 points at stderr until the line is printed.
     saved_stdout = None
-    if world > 1:
+    if world > 1 or os.environ.get("LIPVQ_BENCH_FORCE_DIST") == "1":
         sys.stdout.flush()
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
@@ -337,7 +337,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # LIPVQ_BENCH_FORCE_DIST=1: initialise the process group even with ONE rank (a one-GPU box can then exercise the whole
+    # collective path of the N > 1 run -- RCCL communicator, asynchronous bucket all-reduce, barriers -- with a world of one)
+    if world > 1 or os.environ.get("LIPVQ_BENCH_FORCE_DIST") == "1":
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29577")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
         # "nccl" is RCCL on ROCm.  LIPVQ_BENCH_BACKEND=gloo exists only to rehearse the multi-process
         # flow on a box with fewer GPUs than ranks (ranks then share cuda:0).
