@@ -56,6 +56,15 @@ def test_world2_worker_rehearsal_over_gloo_on_one_gpu():
     assert rcs == [0, 0], "\n".join(o[-1500:] for o in outs)
 
 
+def test_world1_worker_over_nccl():
+    """The same worker with ONE rank over nccl (= RCCL): every leg -- ShardedTokenizer's delta all-reduce, lipvq_allreduce_counts /
+    lipvq_allreduce_f32 on the library's own communicator, and bench.py's bucket pattern (an asynchronous [M][K] all-reduce issued
+    while the next tokenize launches are in flight) through torch.distributed AND the C ABI -- runs on a real RCCL communicator."""
+    rcs, outs = _run_world(1, "nccl")
+    assert rcs == [0], "\n".join(o[-1500:] for o in outs)
+    assert "ok" in outs[0]
+
+
 def test_world1_communicator_allreduce_counts_and_f32():
     import lipvq_vae_amd  # noqa: F401
     from lipvq_vae_amd.sharded import RcclCounts
