@@ -223,6 +223,9 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
     constexpr size_t RING_OWN = (size_t)NBF * RingCfg::STAGE_BYTES + 1024, RING_FINE = lq_ring_bytes<S, fused_ring_tc(S), NBF>();
     constexpr size_t STAGES_BYTES = RING_OWN > RING_FINE ? RING_OWN : RING_FINE;      // the ring + its dummy KiB (one LDS carve for both screens)
     static_assert(STAGES_BYTES >= (size_t)WAVES * LQ_DECIDE_BYTES, "the decision's per-wave transposes live in the stage ring");
+    // per-wave private slice of the (idle) ring: the decision's transposes (LQ_DECIDE_BYTES) and the z_q copy's staging (GP KiB)
+    constexpr size_t WSLICE = (STAGES_BYTES >= (size_t)WAVES * 8192) ? 8192 : LQ_DECIDE_BYTES;
+    static_assert(LQ_DECIDE_BYTES >= 4096 && WSLICE >= LQ_DECIDE_BYTES, "a slice holds the transposes and four staged KiB");
     unsigned* hist = reinterpret_cast<unsigned*>(stage0 + ((STAGES_BYTES + 63) & ~(size_t)63));
     const bool use_hist = a.usage && fused_hist_fits<S, FAST>(a.A, a.K);         // (the same rule sizes the launch's LDS)
 
@@ -560,10 +563,15 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
             constexpr int NTRIP = (16 * S + 63) / 64;                    // 64 floats of every row per gather trip
             constexpr int GP = (STAGES_BYTES >= (size_t)WAVES * 8192) ? 8 : 4;      // passes (KiB per wave) per round
             constexpr int NROUND = NTRIP * (8 / GP);
-            unsigned char* gstage = stage0 + (size_t)wave * GP * 1024;
+            // every wave's staging area and its decision scratch are ONE private slice of the ring (stride WSLICE): a wave may start
+            // the copy while the others are still deciding the previous block -- no workgroup barrier in front of it (round 4; the
+            // staging areas used to overlap other waves' scratch: every block began by waiting for its slowest wave)
+            unsigned char* gstage = stage0 + (size_t)wave * WSLICE;
             const bool gnow = DEFER_GATHER && have_pend && a.zq;         // wave-uniform
             if (gnow) {
-                lq_wg_barrier();                                         // every wave has left the previous block's decision scratch (same ring)
+#ifdef LQ_GATHER_BARRIER         /* measurement knob: the barrier as it was */
+                lq_wg_barrier();
+#endif
                 lq_gather_dma<GP>(gstage, a.cb, pend_k, pend_ok, pend_row0, a.N, a.D, lane, 0, 0);
             }
             {
@@ -946,7 +954,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
         });
         LQ_STAMP(4);
         const unsigned keep_mask = PACKF ? ~((1u << lq_pack_bits(L.ntiles)) - 1u) : 0xffffffffu;
-        unsigned char* scratch = stage0 + (size_t)wave * LQ_DECIDE_BYTES;
+        unsigned char* scratch = stage0 + (size_t)wave * WSLICE;
 #pragma unroll
         for (int g_ = 0; g_ < RG; ++g_) {
             const int64_t row0 = ((blk * WAVES + wave) * RG + g_) * 32;
