@@ -54,6 +54,9 @@ const char* lipvq_last_error(void);
  *   tok_shape         "w8rg1" | "w8rg2" | "w4rg2" | "w4rg1": (waves per workgroup, row groups per wave) of the fused launch
  *   tok_ze_rows       batch size up to which a fused launch stores z_e for its exact stage when nothing else asks for it
  *   tok_grid          workgroups of the fused launch's persistent grid (default 256 = one per CU)
+ *   tok_inplace       "0" | "1": the fused launch never / whenever possible lets its waves decide their uncertified rows in place
+ *                     instead of listing them for a second kernel (default: K <= 2048 under the three-product screen, launches
+ *                     of <= 262 144 rows)
  *   rows_grid, wgrad_chunk, wgrad_per_tile, wgrad_no_wg5, wgrad_rows, embed_bwd_grid, mlp3_small_tiles, mlp3_sub, mlp3_lds_rows
  *                     grid / route choices of the exact-rows, weight-gradient, embedding-backward and MLP kernels (read ONCE, at the
  *                     first launch of that kind: set them before it) */

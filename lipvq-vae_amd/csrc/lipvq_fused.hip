@@ -158,6 +158,7 @@ struct TokArgs {
     int A, D, K;
     float gamma;
     int coarse;                  // host side only: the one-product screen instance runs (ze_out is then never NULL)
+    int inplace;                 // uncertified rows are decided by the wave that screened them (needs ze_out; lipvq_screen.h)
 };
 
 // T0 = 2 (64 features), T1 = 4 (128 features): the reference's encoder widths (v5:54-59).
@@ -425,7 +426,11 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                     typedef float lq_f4v __attribute__((ext_vector_type(4)));
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
+#ifdef LQ_PLAIN_ZE_STORES        /* measurement knob */
+                        reinterpret_cast<lq_f4v*>(dst)[q] = (lq_f4v){lo8[2 * q], hi8[2 * q], lo8[2 * q + 1], hi8[2 * q + 1]};
+#else
                         __builtin_nontemporal_store((lq_f4v){lo8[2 * q], hi8[2 * q], lo8[2 * q + 1], hi8[2 * q + 1]}, reinterpret_cast<lq_f4v*>(dst) + q);
+#endif
                 }
             }
     };
@@ -665,7 +670,11 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
             // the interleaved stream loses another 9 % to issue arbitration between the two waves (5 843).  Same values either way:
             // cfg2 0.4095 -> 0.3997 ms per launch, same box (profiles/r04_b_lumped_gelu_ab.txt).  Not where every output tile of
             // layer 2 waits at a workgroup barrier for its streamed weights (S = 13: 0.934 -> 1.00 ms lumped) -- there the staging stays.
+#ifdef LQ_NO_LUMPED              /* measurement knob: the staged arrangement everywhere */
+            constexpr bool LUMPED = false;
+#else
             constexpr bool LUMPED = !VQ && !STREAM2;
+#endif
             constexpr int G1 = S1 / 4, G2 = S2 / 4;             // groups per tile
             auto wread = [&](int gidx) {                        // group gidx of the stream (compile-time after unrolling)
                 if (STREAM2 && gidx >= T1 * G1) gidx = T1 * G1 - 1;             // streamed layer 2: its groups are read from the slab ring
@@ -966,7 +975,13 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                                                              zng[g_], tiles, tile_bytes, ScreenCfg<S, TCF, COARSE>::FRAG_BYTES);
             const bool row_sane = VQ || n2g[g_] >= tiny2;             // (see fz above; such a row's screen values bound nothing)
             certified = certified && row_sane;
-            lq_screen_emit<PACKF>(dec, certified, row_sane, my_k, row, row < a.N, a.amb_count, a.amb_list, a.N, a.K, lane, keep_mask, scratch);
+            // in place (round 4; small codebooks under the three-product screen): this wave decides its uncertified rows itself
+            // (lq_screen_decide_inplace) and they go on as certified ones -- no list kernel behind the launch
+            if (!COARSE && a.inplace)
+                certified = lq_screen_decide_inplace<PACKF, 2 * S, VQ ? LIPVQ_DIST_SQSUM : LIPVQ_DIST_NORM>(
+                    dec, certified, row_sane, my_k, row0, row < a.N, a.amb_count, a.ze_out, a.cb, a.K, lane, keep_mask, scratch);
+            else
+                lq_screen_emit<PACKF>(dec, certified, row_sane, my_k, row, row < a.N, a.amb_count, a.amb_list, a.N, a.K, lane, keep_mask, scratch);
             if (h == 0 && row < a.N && certified) {
                 a.idx[row] = (int64_t)my_k;
                 if (use_hist) atomicAdd(&hist[my_k], 1u);              // LDS atomic
@@ -1023,6 +1038,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 //   icrt (S = 13): w8rg1 1.19 ms, w4rg1 1.27
 // so the round-2 shape stays the default everywhere; the others remain as instances the parity tests run
 // (LIPVQ_TOK_SHAPE=w8rg1|w8rg2|w4rg2|w4rg1: measurement knob; results identical).
+// In-place decisions (lq_screen_decide_inplace): three-product screen, codebooks the list kernel would finish alone, z_e rows stored --
+// and launches of at most LQ_INPLACE_MAX_ROWS rows.  Same box, cfg2, in place against the list kernel behind the launch
+// (profiles/r04_j_inplace_ab.txt): 65 536 rows 0.0637 -> 0.0585 ms, 131 072 rows 0.1096 -> 0.1054, 262 144 rows 0.2021 -> 0.1988,
+// 524 288 rows 0.3929 -> 0.3936: a wave that stops for a row (about 2 us: the row's z_e comes back from HBM) holds its workgroup
+// at the next block's first hand-over, and at eight blocks per wave that eats the 6 us the second kernel cost.
+// (LIPVQ_TOK_INPLACE=0 / 1: measurement knob -- never / whenever possible; results identical)
+#ifndef LQ_INPLACE_MAX_ROWS
+#define LQ_INPLACE_MAX_ROWS 262144
+#endif
+static int lq_inplace(bool have_ze, int coarse, int K, int64_t N) {
+    const bool can = have_ze && !coarse && K <= LQ_LISTS_ALL_K;
+    if (const char* e = lq_knob("LIPVQ_TOK_INPLACE")) {
+        if (e[0] == '0') return 0;
+        if (e[0] == '1') return can ? 1 : 0;
+    }
+    return (can && N <= LQ_INPLACE_MAX_ROWS) ? 1 : 0;
+}
 struct TokShape { int waves, rg; };
 static TokShape tok_shape_env() {              // read per launch (a getenv: nanoseconds), so that a test can switch shapes in-process
     const char* e = lq_knob("LIPVQ_TOK_SHAPE");
@@ -1225,7 +1257,8 @@ static int tokenize_impl(const float* x, const float* packed, const void* packed
         hipLaunchKernelGGL(w2q_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, packed + PL.oP2, w2q, PL.T2, PL.S2);
     }
     TokArgs a{x, packed, (const unsigned char*)packed16, (const unsigned char*)prep, codebook, idx, zq,
-              (unsigned long long*)usage, ze_buf, amb_count, amb_list, w2q, pre0, pre1, pre2, N, A, D, K, LIPVQ_SCREEN_GAMMA, coarse};
+              (unsigned long long*)usage, ze_buf, amb_count, amb_list, w2q, pre0, pre1, pre2, N, A, D, K, LIPVQ_SCREEN_GAMMA, coarse,
+              lq_inplace(ze_buf != nullptr, coarse, K, N)};
     int rc;
     if (pre0) {
         if ((((uintptr_t)pre0 | (uintptr_t)pre1 | (uintptr_t)pre2) & 15) != 0)
@@ -1251,7 +1284,7 @@ static int tokenize_impl(const float* x, const float* packed, const void* packed
             default: rc = launch_tokenize<13, false>(a, st); break;
         }
     }
-    if (!rc) {
+    if (!rc && !a.inplace) {
         // uncertified rows (count on the device): exact decision, from the stored z_e rows or from x
         if (ze_buf) rc = lipvq_launch_rows(ze_buf, 0, codebook, idx, zq, usage, amb_list, amb_count, N, K, D, st);
         else rc = lipvq_launch_rows_encode(x, raw6, A, codebook, idx, zq, usage, amb_list, amb_count, N, K, D, st);
@@ -1306,7 +1339,7 @@ static int vq_tokenize_impl(const float* x, const float* packed, const float* co
     }
     const int coarse = lq_screen_coarse(lq_screen_S(D), K);
     TokArgs a{x, packed, nullptr, (const unsigned char*)prep, codebook, idx, zq, (unsigned long long*)usage, ze_out, amb_count,
-              amb_list, w2q, pre0, pre1, pre2, N, A, D, K, LIPVQ_SCREEN_GAMMA, coarse};
+              amb_list, w2q, pre0, pre1, pre2, N, A, D, K, LIPVQ_SCREEN_GAMMA, coarse, lq_inplace(true, coarse, K, N)};
     int rc;
     switch (D) {
         case 32: rc = launch_tokenize_vq<2>(a, st); break;
@@ -1314,7 +1347,7 @@ static int vq_tokenize_impl(const float* x, const float* packed, const float* co
         case 128: rc = launch_tokenize_vq<8>(a, st); break;
         default: rc = launch_tokenize_vq<13>(a, st); break;
     }
-    if (!rc) rc = lipvq_launch_rows(ze_out, 0, codebook, idx, zq, usage, amb_list, amb_count, N, K, D, st, LIPVQ_DIST_SQSUM);
+    if (!rc && !a.inplace) rc = lipvq_launch_rows(ze_out, 0, codebook, idx, zq, usage, amb_list, amb_count, N, K, D, st, LIPVQ_DIST_SQSUM);
     if (rc) (void)hipMemsetAsync(ws, 0, 64, st);     // a failed call must not leave counters behind for the next one
     return rc;
 }

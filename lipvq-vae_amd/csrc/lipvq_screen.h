@@ -761,6 +761,150 @@ __device__ __forceinline__ void lq_screen_emit(const LqDecision& dec, bool certi
     lq_emit_store(need, slot, head, mask, codes, my_k, row, amb_list, N, lane);
 }
 
+#ifndef LQ_LISTS_ALL_K
+#define LQ_LISTS_ALL_K 2048       /* codebooks up to this size: the list kernel decides every listed row (no scanning-kernel launch) */
+#endif
+// One listed row decided by ONE WAVE (round 3; the body of nearest_lists_kernel, lipvq_screen.hip -- and, round 4, of the fused
+// launch's in-place decisions, lq_screen_decide_inplace below): its eight 8-lane groups score eight candidates at once; lane j of a
+// group keeps torch's accumulator j (features j, j + 8, ...: the k-ordered fma chain of lq_sqdist8; for the sum rule the four
+// accumulators of lane column j, lq_sqdist32), the eight partials are added in lane order, roots compared, lower code among equal
+// values.  cl = the row's 16 ints {n0, mask0, c0..c5, n1, mask1, c0..c5} as lq_emit_store lays them out (global memory or LDS), or
+// nullptr (no list at all).  zload(f) = feature f of the row.  Returns the code in every lane, or -1: a long scan left to the
+// scanning kernel (never with all_here).
+template <int DCH, int DIST, typename ZLOAD>
+__device__ __forceinline__ int lq_lists_row(ZLOAD zload, const float* __restrict__ cb, int K, const int* cl, int lane, bool all_here) {
+    constexpr int D = DCH * 8;
+    const int g = lane >> 3, j = lane & 7;
+    int n0 = -1, n1 = -1;
+    if (cl) { n0 = cl[0]; n1 = cl[8]; }
+    const bool shortlist = n0 >= 0 && n1 >= 0 && n0 + n1 >= 1 && n0 <= LQ_CAND_MAX && n1 <= LQ_CAND_MAX;   // wave-uniform
+    // lane masks (some lane's second minimum may be within the margin, or a part listed more than LQ_CAND_MAX codes): every
+    // code congruent to a flagged lane mod 32 is a candidate -- popcount(mask) x K/32 of them, eight at a time like a short list
+    const bool lanescan = !shortlist && n0 != -1 && n1 != -1 && (n0 == -2 || n1 == -2 || n0 > LQ_CAND_MAX || n1 > LQ_CAND_MAX);
+    const unsigned lmask = lanescan ? (((unsigned)cl[1] & 0xffffu) | (((unsigned)cl[9] & 0xffffu) << 16)) : 0u;
+    // ... as long as that is a few rounds of eight: a long scan would hold this wave for hundreds of dependent rounds while
+    // the scanning kernel spreads a row over 64 slices (measured at K = 8192: 4.6 k such rows, 256 codes per flagged lane:
+    // 290 us here against 101 us there)
+    bool scan_here = lanescan && lmask != 0u && __builtin_popcount(lmask) * ((K + 31) / 32) <= 128;
+    // all_here (round 4; codebooks of <= LQ_LISTS_ALL_K codes): the caller is the call's last word on the row -- whatever it came
+    // with (a long lane scan, no list at all: every lane flagged) is scanned by this wave, eight codes a round.  Such rows are a
+    // few per ten thousand, and a launch of the scanning kernel for them (usually for nothing: the count lives on the device)
+    // cost every call 4.5 us.
+    unsigned lm_eff = lmask;
+    if (!shortlist && !scan_here) {
+        if (!all_here) return -1;
+        scan_here = true;
+        lm_eff = (lanescan && lmask != 0u) ? lmask : 0xffffffffu;
+    }
+    const bool scanning = !shortlist;                                    // (wave-uniform; shortlist rows read their list)
+    const int P = scanning ? __builtin_popcount(lm_eff) : 0;
+    const int nc = scanning ? P * ((K + 31) / 32) : n0 + n1;
+    float zv[DCH];
+#pragma unroll
+    for (int i = 0; i < DCH; ++i) zv[i] = zload(8 * i + j);
+    float best_v = INFINITY;
+    int best_k = 0x7fffffff;
+    for (int c0 = 0; c0 < nc; c0 += 8) {
+        const int ci = c0 + g;
+        bool live = ci < nc;
+        int code;
+        if (scanning) {
+            const int t = ci / P, w = ci - t * P;                          // the w-th flagged lane of tile t
+            unsigned m = lm_eff;
+            for (int q = 0; q < w; ++q) m &= m - 1;
+            code = 32 * t + __builtin_ctz(m | 0x80000000u);
+            live = live && code < K;
+        } else {
+            code = live ? (ci < n0 ? cl[2 + ci] : cl[10 + (ci - n0)]) : cl[n0 > 0 ? 2 : 10];
+        }
+        code = (code >= 0 && code < K) ? code : 0;                       // (lq_screen_emit lists valid codes only)
+        const float* c = cb + (size_t)code * D;
+        float s;
+        if constexpr (DIST == LIPVQ_DIST_NORM) {
+            float a = 0.0f;
+#pragma unroll
+            for (int i = 0; i < DCH; ++i) { const float d = zv[i] - c[8 * i + j]; a = lq_fma(d, d, a); }
+            s = __shfl(a, 8 * g, 64);
+#pragma unroll
+            for (int l = 1; l < 8; ++l) s = s + __shfl(a, 8 * g + l, 64);
+            s = lq_sqrt(s);
+        } else {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < DCH; ++i) {
+                const int q = (i < (DCH / 4) * 4) ? (i & 3) : 0;
+                const float d = zv[i] - c[8 * i + j];
+                acc[q] = acc[q] + d * d;
+            }
+            const float vl = ((acc[0] + acc[1]) + acc[2]) + acc[3];
+            s = __shfl(vl, 8 * g, 64);
+#pragma unroll
+            for (int l = 1; l < 8; ++l) s = s + __shfl(vl, 8 * g + l, 64);
+        }
+        const float v = (live && s == s) ? s : INFINITY;                 // a NaN never wins
+        const int kk = live ? code : 0x7fffffff;
+        if (v < best_v || (v == best_v && kk < best_k)) { best_v = v; best_k = kk; }
+    }
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1) {
+        const float ov = __shfl_xor(best_v, off, 64);
+        const int ok = __shfl_xor(best_k, off, 64);
+        if (ov < best_v || (ov == best_v && ok < best_k)) { best_v = ov; best_k = ok; }
+    }
+    if (best_k < 0 || best_k >= K) {                                     // every value NaN: any valid code of the list
+        const int fb = scanning ? __builtin_ctz(lm_eff) : cl[n0 > 0 ? 2 : 10];
+        best_k = (fb >= 0 && fb < K) ? fb : 0;
+    }
+    return best_k;
+}
+
+// Round 4: the rows the screen does not certify are decided IN PLACE by the wave that screened them (codebooks of at most
+// LQ_LISTS_ALL_K codes under the three-product screen: a few rows per thousand, mostly two candidates).  The parts lq_emit_candidates
+// works out go to the wave's scratch in the list kernel's slot format instead of the workspace, and lq_lists_row -- the list
+// kernel's own body: same candidates, same accumulator order, same tie rule -- reads them there; the row's z_e comes back from the
+// rows this wave stored in phase A (those stores have retired: every hand-over of the screen loop waited behind them; agent-scope
+// loads, since this CU's vector cache may hold nothing older of these lines but need not be asked).  The row then continues as a
+// certified one (index, usage, z_q gather), so the call has no list kernel behind it: one launch less per call (6 us of a 65 us
+// launch at 65 536 rows).  The number of rows decided this way is still counted into the live word and published as before
+// (LLFQVAE_V4.last_exact_rows, the screen monitor).
+template <bool PACK, int DCH, int DIST>
+__device__ __forceinline__ bool lq_screen_decide_inplace(const LqDecision& dec, bool certified, bool lists_ok, int& my_k, int64_t row0,
+                                                         bool row_valid, int* __restrict__ amb_count, const float* __restrict__ z,
+                                                         const float* __restrict__ cb, int K, int lane, unsigned keep_mask,
+                                                         unsigned char* wave_lds) {
+    const bool need = row_valid && !certified;                          // the same in both halves of the row
+    if (__builtin_amdgcn_ballot_w64(need) == 0ull) return certified;    // wave-uniform: most waves have nothing to decide
+    const int ln = lane & 31, h = lane >> 5;
+    unsigned long long lm = __builtin_amdgcn_ballot_w64(h == 0 && need);                  // (bits 0 .. 31 only)
+    if (lane == __builtin_ctzll(lm)) (void)lq_ws_reserve(amb_count, __builtin_popcountll(lm));   // counted, nothing reserved
+    int head;
+    unsigned mask;
+    int codes[LQ_CAND_MAX];
+    lq_emit_candidates<PACK>(dec, lists_ok, K, lane, keep_mask, wave_lds, head, mask, codes);
+    __builtin_amdgcn_wave_barrier();                                    // the decide image has been read (unpacked codes)
+    int* parts = reinterpret_cast<int*>(wave_lds);                      // [32 rows][16 ints]: 2 KiB of the wave's LQ_DECIDE_BYTES
+    static_assert(LQ_CAND_MAX == 6 && 32 * 16 * 4 <= LQ_DECIDE_BYTES, "a part is {n, mask, six codes}");
+    if (need) {
+        typedef int lq_i4 __attribute__((ext_vector_type(4)));
+        lq_i4* out4 = reinterpret_cast<lq_i4*>(parts + ln * 16 + 8 * h);
+        out4[0] = lq_i4{head, (int)mask, codes[0], codes[1]};
+        out4[1] = lq_i4{codes[2], codes[3], codes[4], codes[5]};
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                 // lgkmcnt(0): this wave's LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+    constexpr int D = DCH * 8;
+    while (lm) {                                                        // wave-uniform
+        const int r = __builtin_ctzll(lm);
+        lm &= lm - 1ull;
+        const float* zr = z + (size_t)(row0 + r) * D;
+        const int bk = lq_lists_row<DCH, DIST>([&](int f) { return __hip_atomic_load(zr + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
+                                               cb, K, parts + r * 16, lane, true);
+        if (ln == r) { my_k = bk; certified = true; }
+    }
+    __builtin_amdgcn_wave_barrier();                                    // the parts have been read before the scratch's next use
+    return certified;
+}
+
 // z_q rows of certified rows: 16 lanes copy one codebook row (16 B each), 4 rows per pass
 // z_q rows of certified rows: 16 lanes copy 64 floats of one codebook row (16 B each per pass), 4 rows per pass of the wave, 8
 // passes = the wave's 32 rows; a "trip" covers floats [64 trip, 64 trip + 64) of the rows.

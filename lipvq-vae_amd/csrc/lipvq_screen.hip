@@ -602,9 +602,6 @@ __global__ __launch_bounds__(256) void nearest_rows_kernel(
 // screen's rows; popcount(mask) x K/32 candidates) take the same loop while that is at most 128 candidates; longer scans and rows
 // with no list at all (n = -1: a meaningless screen) are appended to slot2_list for the scanning kernel.
 // ------------------------------------------------------------------------------------------
-#ifndef LQ_LISTS_ALL_K
-#define LQ_LISTS_ALL_K 2048       /* codebooks up to this size: the list kernel decides every listed row (no scanning-kernel launch) */
-#endif
 template <int DCH, int DIST>
 __global__ __launch_bounds__(256) void nearest_lists_kernel(
     const float* __restrict__ z, const float* __restrict__ cb, int64_t* __restrict__ idx, float* __restrict__ zq,
@@ -612,92 +609,17 @@ __global__ __launch_bounds__(256) void nearest_lists_kernel(
     int K, int z_by_slot, const int* __restrict__ cand_list, size_t cand_cap, int* __restrict__ slot2_list,
     int* __restrict__ slot2_count, int all_here) {
     constexpr int D = DCH * 8;
-    const int lane = threadIdx.x & 63, g = lane >> 3, j = lane & 7;
+    const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
     const int count = *row_count;
     for (int slot = wid; slot < count; slot += nw) {
-        int n0 = -1, n1 = -1;
-        const int* cl = cand_list + (size_t)((size_t)slot < cand_cap ? slot : 0) * 16;
-        if ((size_t)slot < cand_cap) { n0 = cl[0]; n1 = cl[8]; }
-        const bool shortlist = n0 >= 0 && n1 >= 0 && n0 + n1 >= 1 && n0 <= LQ_CAND_MAX && n1 <= LQ_CAND_MAX;   // wave-uniform
-        // lane masks (some lane's second minimum may be within the margin, or a part listed more than LQ_CAND_MAX codes): every
-        // code congruent to a flagged lane mod 32 is a candidate -- popcount(mask) x K/32 of them, eight at a time like a short list
-        const bool lanescan = !shortlist && n0 != -1 && n1 != -1 && (n0 == -2 || n1 == -2 || n0 > LQ_CAND_MAX || n1 > LQ_CAND_MAX);
-        const unsigned lmask = lanescan ? (((unsigned)cl[1] & 0xffffu) | (((unsigned)cl[9] & 0xffffu) << 16)) : 0u;
-        // ... as long as that is a few rounds of eight: a long scan would hold this wave for hundreds of dependent rounds while
-        // the scanning kernel spreads a row over 64 slices (measured at K = 8192: 4.6 k such rows, 256 codes per flagged lane:
-        // 290 us here against 101 us there)
-        bool scan_here = lanescan && lmask != 0u && __builtin_popcount(lmask) * ((K + 31) / 32) <= 128;
-        // all_here (round 4; codebooks of <= LQ_LISTS_ALL_K codes): this kernel is the call's last -- whatever the row came with
-        // (a long lane scan, no list at all: every lane flagged) is scanned by this wave, eight codes a round.  Such rows are a
-        // few per ten thousand, and a launch of the scanning kernel for them (usually for nothing: the count lives on the device)
-        // cost every call 4.5 us.
-        unsigned lm_eff = lmask;
-        if (!shortlist && !scan_here) {
-            if (!all_here) {
-                if (lane == 0) slot2_list[atomicAdd(slot2_count, 1)] = slot;      // long lane scans, no list at all: the scanning kernel
-                continue;
-            }
-            scan_here = true;
-            lm_eff = (lanescan && lmask != 0u) ? lmask : 0xffffffffu;
-        }
-        const bool scanning = !shortlist;                                    // (wave-uniform; shortlist rows read their list)
+        const int* cl = (size_t)slot < cand_cap ? cand_list + (size_t)slot * 16 : nullptr;
         const int64_t row = row_list[slot];
         const float* zr = z + (size_t)(z_by_slot ? (int64_t)slot : row) * D;
-        const int P = scanning ? __builtin_popcount(lm_eff) : 0;
-        const int nc = scanning ? P * ((K + 31) / 32) : n0 + n1;
-        float best_v = INFINITY;
-        int best_k = 0x7fffffff;
-        for (int c0 = 0; c0 < nc; c0 += 8) {
-            const int ci = c0 + g;
-            bool live = ci < nc;
-            int code;
-            if (scanning) {
-                const int t = ci / P, w = ci - t * P;                          // the w-th flagged lane of tile t
-                unsigned m = lm_eff;
-                for (int q = 0; q < w; ++q) m &= m - 1;
-                code = 32 * t + __builtin_ctz(m | 0x80000000u);
-                live = live && code < K;
-            } else {
-                code = live ? (ci < n0 ? cl[2 + ci] : cl[10 + (ci - n0)]) : cl[n0 > 0 ? 2 : 10];
-            }
-            code = (code >= 0 && code < K) ? code : 0;                       // (lq_screen_emit lists valid codes only)
-            const float* c = cb + (size_t)code * D;
-            float s;
-            if constexpr (DIST == LIPVQ_DIST_NORM) {
-                float a = 0.0f;
-#pragma unroll
-                for (int i = 0; i < DCH; ++i) { const float d = zr[8 * i + j] - c[8 * i + j]; a = lq_fma(d, d, a); }
-                s = __shfl(a, 8 * g, 64);
-#pragma unroll
-                for (int l = 1; l < 8; ++l) s = s + __shfl(a, 8 * g + l, 64);
-                s = lq_sqrt(s);
-            } else {
-                float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int i = 0; i < DCH; ++i) {
-                    const int q = (i < (DCH / 4) * 4) ? (i & 3) : 0;
-                    const float d = zr[8 * i + j] - c[8 * i + j];
-                    acc[q] = acc[q] + d * d;
-                }
-                const float vl = ((acc[0] + acc[1]) + acc[2]) + acc[3];
-                s = __shfl(vl, 8 * g, 64);
-#pragma unroll
-                for (int l = 1; l < 8; ++l) s = s + __shfl(vl, 8 * g + l, 64);
-            }
-            const float v = (live && s == s) ? s : INFINITY;                 // a NaN never wins
-            const int kk = live ? code : 0x7fffffff;
-            if (v < best_v || (v == best_v && kk < best_k)) { best_v = v; best_k = kk; }
-        }
-#pragma unroll
-        for (int off = 8; off < 64; off <<= 1) {
-            const float ov = __shfl_xor(best_v, off, 64);
-            const int ok = __shfl_xor(best_k, off, 64);
-            if (ov < best_v || (ov == best_v && ok < best_k)) { best_v = ov; best_k = ok; }
-        }
-        if (best_k < 0 || best_k >= K) {                                     // every value NaN: any valid code of the list
-            const int fb = scanning ? __builtin_ctz(lm_eff) : cl[n0 > 0 ? 2 : 10];
-            best_k = (fb >= 0 && fb < K) ? fb : 0;
+        const int best_k = lq_lists_row<DCH, DIST>([&](int f) { return zr[f]; }, cb, K, cl, lane, all_here != 0);
+        if (best_k < 0) {                                                    // a long scan: the scanning kernel's
+            if (lane == 0) slot2_list[atomicAdd(slot2_count, 1)] = slot;
+            continue;
         }
         if (lane == 0) {
             idx[row] = (int64_t)best_k;

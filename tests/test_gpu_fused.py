@@ -441,3 +441,36 @@ def test_workspace_header_is_kept_clean_by_the_launch_itself(oracle, N, A, D, K)
     assert len(set(counts)) == 1 and 0 <= counts[0] <= N, counts              # the same rows are left to an exact decision
     if K >= 256:
         assert counts[0] > 0, "meant to exercise uncertified rows"
+
+
+@pytest.mark.parametrize("N,A,D,K", [(300000, 7, 64, 1024), (20011, 7, 32, 256), (9000, 12, 64, 2048), (24000, 7, 128, 1024),
+                                     (12345, 12, 208, 1024)])
+def test_in_place_decisions_equal_the_list_kernel(oracle, lipvq_option, N, A, D, K):
+    """Round 4: under the three-product screen with K <= 2048 the wave that screened a row decides it itself when the screen does not
+    certify it (lq_screen_decide_inplace: the list kernel's own body on the row's stored z_e) -- by default for launches of at most
+    262 144 rows.  Forced on and forced off (option tok_inplace): same indices, z_q, usage and the same published count of rows
+    decided exactly; both equal the all-pairs exact kernel."""
+    from lipvq_vae_amd import ops
+    p, model = _setup(N % 1000 + D + 1, A, D, K, oracle)
+    xt = torch.from_numpy(O.make_inputs(N % 971, N, A)).cuda()
+    packed, _, Wn = model._packed_encoder()
+    w0, b0, w1, b1, _, b2, _ = (t.detach() for t in model._enc_params())
+    raw = (w0, b0, w1, b1, Wn, b2)
+    cb = model.quantizer.codebook.detach()
+    prep = ops.nearest_prepare(cb)
+    lipvq_option("screen_mode", "fine")
+    ref_i, ref_q, _ = ops.nearest(model.encode(xt), cb)
+    ref_u = torch.bincount(ref_i, minlength=K)
+    seen = {}
+    for setting in ("0", "1", None):
+        lipvq_option("tok_inplace", setting)
+        ws = ops.tokenize_workspace(N, D, xt.device)
+        for call in range(2):
+            usage = torch.zeros(K, dtype=torch.int64, device="cuda")
+            idx, zq, _, _ = ops.tokenize(xt, packed, raw, cb, prep, usage=usage, workspace=ws)
+            assert torch.equal(idx, ref_i) and torch.equal(zq, ref_q) and torch.equal(usage, ref_u), (setting, call)
+            hdr = ws[:16].cpu()
+            assert int(hdr[8]) == 0 and int(hdr[9]) == 0 and int(hdr[0]) == int(hdr[1]), (setting, hdr.tolist())
+            seen.setdefault(setting, int(hdr[0]))
+            assert seen[setting] == int(hdr[0])
+    assert seen["0"] == seen["1"] == seen[None] and seen["0"] > 0, seen
