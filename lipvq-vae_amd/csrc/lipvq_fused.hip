@@ -1070,9 +1070,12 @@ static TokShape tok_shape(int64_t N) {
     constexpr bool HAS_RG2 = !FAST && !TRAIN && S <= 8;      // the instances that exist (launch_tokenize)
     constexpr bool HAS_W4 = !FAST && !TRAIN;
     TokShape t = tok_shape_env();
-    if (t.waves == 0) t = {8, 1};
+    // Size rule (round 4): a launch of at most 32 768 rows is at most one 32-row block per SIMD of the chip -- as 4-wave workgroups
+    // (one wave per SIMD, 256 CUs) instead of 8-wave ones (two per SIMD on half the CUs): same box, 32 768 rows, w8rg1 -> w4rg1:
+    // icrt 0.137 -> 0.099 ms, cfg3 0.205 -> 0.184, cfg2 0.0528 -> 0.0509 (profiles/r04_k_small_launch_shape_ab.txt).  An explicit
+    // tok_shape is honoured at any batch size.
+    if (t.waves == 0) t = (HAS_W4 && N <= 4 * 32 * 256) ? TokShape{4, 1} : TokShape{8, 1};
     if ((t.rg == 2 && !HAS_RG2) || (t.waves == 4 && !HAS_W4)) t = {8, 1};
-    (void)N;        // (no size rule: the default is one shape; an explicit LIPVQ_TOK_SHAPE is honoured at any batch size)
     return t;
 }
 

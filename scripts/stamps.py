@@ -23,7 +23,8 @@ e0.record(); model.tokenize(x); e1.record(); torch.cuda.synchronize()
 ws = model._tok_ws.cpu().numpy()
 off = 16 + ((N // 2) & ~1)
 import os
-NW = 4 if (lipvq_vae_amd._capi.get_option("tok_shape") or "").startswith("w4") else 8      # waves per workgroup of the instance that ran
+_shape = lipvq_vae_amd._capi.get_option("tok_shape") or ("w4rg1" if N <= 32768 else "w8rg1")   # (the library's size rule, lipvq_fused.hip::tok_shape)
+NW = 4 if _shape.startswith("w4") else 8      # waves per workgroup of the instance that ran
 # (options come from the environment only with LIPVQ_DEV_KNOBS=1: lipvq-vae_amd/_capi.py)
 NWG = min(256, -(-N // (NW * 32)))                              # workgroups of the launch
 st = ws[off:off + NWG * NW * 32].view(np.int64).reshape(NWG * NW, 16)
