@@ -136,6 +136,9 @@ def cpu_baseline(model, x_dev, idx_dev, budget_s=10.0):
     return base, gate
 
 
+CHILD_SCHEDULE = []          # the counter children run the schedule THIS process tuned (main sets it): ["--schedule", "d,n"]
+
+
 def pmc_child_runs(workload, passes, child_steps=5, sustained=200, timeout_s=150):
     """Counter passes of the metric's kernels, measured NOW: one child run of this file under `rocprofv3 --pmc <counters>` per pass
     (counters only -- no trace domain -- and the program directly behind `--`), after the timed region so that the profiler never
@@ -157,7 +160,7 @@ def pmc_child_runs(workload, passes, child_steps=5, sustained=200, timeout_s=150
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     child = [sys.executable, str(ROOT / "bench.py"), "--workload", workload, "--steps", str(child_steps), "--warmup", "2",
-             "--no-cpu-baseline", "--sustained", str(sustained), "--metric-only", "--traffic", "off"]
+             "--no-cpu-baseline", "--sustained", str(sustained), "--metric-only", "--traffic", "off"] + CHILD_SCHEDULE
     result = {}
     try:
         for name, counters in passes:
@@ -237,6 +240,51 @@ def measure_traffic_live(workload, kernels, timeout_s=150):
                    "kernels; reads x2 (gfx950 FETCH_SIZE correction)"), detail, sq
 
 
+def sample_power(run_some, seconds=2.5):
+    """Socket power / shader clock / junction temperature as rocm-smi reports them WHILE the metric's launch loops (after the timed
+    region; rank 0, one GPU).  The launch runs at or near the package power limit on most boxes of the pool and the clock is what
+    that leaves (profiles/r04_i_clock_ab.txt): the reading says which kind of box a line came from.  Returns a dict or None."""
+    import threading
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            try:
+                r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp", "--json"], capture_output=True, text=True,
+                                   timeout=10)
+                card = json.loads(r.stdout)
+                card = card[sorted(card)[0]]
+                rec = {}
+                for k, v in card.items():
+                    kl = k.lower()
+                    if kl.startswith("sclk clock speed"):
+                        rec["sclk"] = float(str(v).strip("()Mhz "))
+                    elif "power" in kl and "(w)" in kl:
+                        rec["power"] = float(v)
+                    elif "temperature" in kl and "junction" in kl:
+                        rec["temp"] = float(v)
+                samples.append(rec)
+            except Exception:  # noqa: BLE001 -- optional equipment
+                pass
+            stop.wait(0.15)
+    th = threading.Thread(target=sampler, daemon=True)
+    t_end = time.time() + seconds
+    th.start()
+    while time.time() < t_end:
+        run_some()
+    stop.set()
+    th.join(timeout=15)
+    samples = samples[1:] if len(samples) > 2 else samples           # (the first sample may predate the loop)
+
+    def mean(key):
+        v = [s_[key] for s_ in samples if key in s_]
+        return sum(v) / len(v) if v else None
+    if not samples or mean("power") is None:
+        return None
+    return {"socket_power_w": mean("power"), "sclk_mhz": mean("sclk"), "junction_temp_c": mean("temp"), "samples": len(samples),
+            "how": f"rocm-smi sampled every ~0.3 s while the metric's launch looped for {seconds} s after the timed region"}
+
+
 def self_launch(args):
     """Plain `python bench.py --gpus N`: start N fresh ranks.  This process has made no GPU call (importing torch does
     not initialise HIP) and makes none; the ranks are children of torch.distributed.run, never an exec of this process."""
@@ -309,6 +357,9 @@ def main():
     ap.add_argument("--sustained", type=int, default=1000, help="back-to-back launches of the sustained reading (0 = skip)")
     ap.add_argument("--traffic", default="live", choices=("live", "file", "off"),
                     help="roofline.traffic: measured now under rocprofv3 --pmc (N=1 only), read from profiles/hbm_traffic.json, or null")
+    ap.add_argument("--schedule", default=None, help="defer_ze,nt_ze (e.g. 0,1): fix the fused launch's schedule choices instead of tuning")
+    ap.add_argument("--no-tune", action="store_true",
+                    help="skip LLFQVAE_V4.tune (set-up, untimed): the fused launch's device-dependent schedule choices stay at their defaults")
     ap.add_argument("--metric-only", action="store_true",
                     help="skip the fast-mode / full-forward / training-step side readings (profiling runs: every dispatch is then the metric's)")
     ap.add_argument("--rehearse-launcher", action="store_true", help=argparse.SUPPRESS)
@@ -459,6 +510,21 @@ def main():
         for b in (0, 1):
             wait_pending(b)
 
+    # Set-up, untimed: every rank lets the library measure the fused launch's device-dependent schedule choices on ITS device with
+    # ITS shard (lipvq_tokenize_tune_f32, ~0.3 s: identical results under every choice; MI355X devices hold different clocks under
+    # the same kernel and what wins on one loses on another, profiles/r04_i_clock_ab.txt).  The line reports what was chosen.
+    tuned = None
+    if args.schedule:
+        d_, n_ = (v.strip() for v in args.schedule.split(","))
+        ops.set_option("tok_defer_ze", d_)
+        ops.set_option("tok_nt_ze", n_)
+        tuned = {"choice": {"defer_ze": int(d_), "nt_ze": int(n_)}, "fixed": "--schedule"}
+    elif not args.no_tune:
+        tuned = model.tune(x)
+        fence()
+    if tuned is not None:
+        CHILD_SCHEDULE[:] = ["--schedule", f"{tuned['choice']['defer_ze']},{tuned['choice']['nt_ze']}"]
+
     # Sustained reading FIRST: the same step, >= 0.4 s of back-to-back launches (same barriers, MAX over ranks).  It is a
     # number of its own (`sustained`), and it leaves the chip in the clock / power state of a job that has been running for a
     # while -- which is what the W warm-up + K timed steps below are then measured in.  (Round 1 timed K = 20 steps straight
@@ -561,6 +627,10 @@ def main():
     }
     if sustained is not None:
         out["sustained"] = sustained
+    out["tuned"] = tuned if tuned is not None else "not tuned (--no-tune or no fused launch for this shape): library defaults"
+    if tuned is not None and "fixed" not in tuned:
+        tuned["what"] = ("set-up, untimed, rank 0's device: LLFQVAE_V4.tune timed the fused launch's four (defer_ze, nt_ze) schedule "
+                         "combinations (identical results) and the process keeps the fastest")
     if world == 1 and not args.metric_only and ops.tokenize_fast_supported(A, 64, model.hidden_dim, D, K):
         # reported beside the metric, never as `value`: the opt-in fast mode (fp16 encoder GEMMs, fp32 accumulation and
         # quantizer) on the same batch, with the fraction of indices that differ from the parity run above
@@ -647,6 +717,15 @@ def main():
         t = json.loads(tfile.read_text())
         if t.get("workload") == args.workload:
             traffic, traffic_src = t.get("bytes_per_launch"), (traffic_src or "") + "committed: " + str(t.get("source"))
+    if world == 1 and rank == 0 and not args.metric_only and args.traffic != "off":
+        def _some():
+            for _ in range(200):
+                step(False)
+            drain()
+            fence()
+        pw = sample_power(_some)
+        if pw is not None:
+            out["roofline"]["power"] = pw
     if sq is not None:
         # the same fraction against peaks scaled to the clock the launch held (the datasheet peaks are 2.4 GHz figures)
         out["roofline"].update({"mfma_busy_frac": sq["mfma_busy_frac"], "shader_clock_mhz": sq["shader_clock_mhz"],

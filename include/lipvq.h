@@ -57,6 +57,9 @@ const char* lipvq_last_error(void);
  *   tok_inplace       "0" | "1": the fused launch never / whenever possible lets its waves decide their uncertified rows in place
  *                     instead of listing them for a second kernel (default: K <= 2048 under the three-product screen, launches
  *                     of <= 262 144 rows)
+ *   tok_defer_ze, tok_nt_ze   "0" | "1": the fused launch's two device-dependent schedule choices (the last z_e tile's stores issued
+ *                     behind the screen's first stage copies; z_e rows stored nontemporal) -- overrides the defaults (0, 1) and
+ *                     whatever lipvq_tokenize_tune_f32 found for the device
  *   rows_grid, wgrad_chunk, wgrad_per_tile, wgrad_no_wg5, wgrad_rows, embed_bwd_grid, mlp3_small_tiles, mlp3_sub, mlp3_lds_rows
  *                     grid / route choices of the exact-rows, weight-gradient, embedding-backward and MLP kernels (read ONCE, at the
  *                     first launch of that kind: set them before it) */
@@ -186,6 +189,15 @@ int lipvq_tokenize_workspace_init(void* workspace, void* stream);
 int lipvq_tokenize_f32(const float* x, const float* packed, const float* const* raw6, const float* codebook,
                        const void* prep, int64_t* idx, float* zq, int64_t* usage, float* ze_out, void* workspace,
                        int64_t N, int A, int J0, int J1, int D, int K, void* stream);
+/* MI355X devices hold different clocks under the same kernel, and two schedule choices of the fused launch (identical results) win
+ * on some devices and lose on others (profiles/r04_i_clock_ab.txt).  This call measures the four combinations with the caller's
+ * own arguments (those of lipvq_tokenize_f32) -- each warmed, then `launches` back-to-back calls between HIP events, two alternating
+ * rounds, minimum per combination -- and keeps the fastest as the current device's setting for every later lipvq_tokenize_* call of
+ * the process.  SYNCHRONOUS (waits for the stream), not capturable; every launch writes idx / zq / ze_out and accumulates into usage
+ * as lipvq_tokenize_f32 does.  choice (may be NULL): defer_ze | nt_ze << 1; ms4 (may be NULL): ms per launch of the four. */
+int lipvq_tokenize_tune_f32(const float* x, const float* packed, const float* const* raw6, const float* codebook,
+                            const void* prep, int64_t* idx, float* zq, int64_t* usage, float* ze_out, void* workspace,
+                            int64_t N, int A, int J0, int J1, int D, int K, void* stream, int launches, int* choice, float* ms4);
 /* The forward half of a training step in the same launch: lipvq_tokenize_f32 that also stores what autograd saves for
  * the backward of v5:71-74 -- z_e [N][D] and the pre-activations pre0 [N][J0], pre1 [N][J1], pre2 [N][D] (all required,
  * 16-byte aligned), bit-identical to lipvq_mlp3_f32(x, .., pre0, pre1, pre2). */

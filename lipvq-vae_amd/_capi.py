@@ -58,6 +58,7 @@ SIGNATURES = {
     "lipvq_tokenize_workspace_bytes": (_sz, [_i64, _i]),
     "lipvq_tokenize_workspace_init": (_i, [_vp, _vp]),
     "lipvq_tokenize_f32": (_i, [_vp] * 10 + [_i64] + [_i] * 5 + [_vp]),
+    "lipvq_tokenize_tune_f32": (_i, [_vp] * 10 + [_i64] + [_i] * 5 + [_vp, _i, _vp, _vp]),
     "lipvq_nearest_small_supported": (_i, [_i64, _i, _i]),
     "lipvq_nearest_small_workspace_bytes": (_sz, [_i64, _i]),
     "lipvq_nearest_small_f32": (_i, [_vp] * 6 + [_i64, _i, _i, _i, _vp]),
@@ -138,7 +139,7 @@ lib = _load()
 
 
 OPTIONS = ("screen_mode", "tok_shape", "tok_ze_rows", "tok_grid", "rows_grid", "wgrad_chunk", "wgrad_per_tile", "wgrad_no_wg5",
-           "wgrad_rows", "embed_bwd_grid", "mlp3_small_tiles", "mlp3_sub", "mlp3_lds_rows", "tok_inplace")
+           "wgrad_rows", "embed_bwd_grid", "mlp3_small_tiles", "mlp3_sub", "mlp3_lds_rows", "tok_inplace", "tok_defer_ze", "tok_nt_ze")
 
 
 def set_option(name: str, value=None) -> None:

@@ -14,6 +14,7 @@
 // four MFMAs), two waves share each SIMD so one wave's GELU/bookkeeping VALU work runs beside the other's
 // MFMAs, and a workgroup persists over row blocks so the weights are loaded once.
 #include <string.h>
+#include <atomic>
 
 #include "lipvq_mlp.h"
 #include "lipvq_screen.h"
@@ -159,7 +160,17 @@ struct TokArgs {
     float gamma;
     int coarse;                  // host side only: the one-product screen instance runs (ze_out is then never NULL)
     int inplace;                 // uncertified rows are decided by the wave that screened them (needs ze_out; lipvq_screen.h)
+    int defer_ze;                // S <= 4: the last tile's z_e stores go behind the screen's first stage copies   } launch-uniform schedule choices,
+    int nt_ze;                   // z_e rows are stored nontemporal                                                } same results: lq_schedule()
 };
+
+#ifdef LQ_CT_SCHEDULE             /* measurement builds: the two schedule choices as compile-time constants (defer_ze | nt_ze << 1) */
+#define LQ_DEFER_FLAG(a) ((LQ_CT_SCHEDULE & 1) != 0)
+#define LQ_NT_FLAG(a) ((LQ_CT_SCHEDULE & 2) != 0)
+#else
+#define LQ_DEFER_FLAG(a) ((a).defer_ze != 0)
+#define LQ_NT_FLAG(a) ((a).nt_ze != 0)
+#endif
 
 // T0 = 2 (64 features), T1 = 4 (128 features): the reference's encoder widths (v5:54-59).
 // FAST: the encoder's three GEMMs as fp16 MFMAs (v_mfma_f32_32x32x16_f16, fp32 accumulation) -- the "fast" mode
@@ -426,11 +437,8 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                     typedef float lq_f4v __attribute__((ext_vector_type(4)));
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-#ifdef LQ_PLAIN_ZE_STORES        /* measurement knob */
-                        reinterpret_cast<lq_f4v*>(dst)[q] = (lq_f4v){lo8[2 * q], hi8[2 * q], lo8[2 * q + 1], hi8[2 * q + 1]};
-#else
-                        __builtin_nontemporal_store((lq_f4v){lo8[2 * q], hi8[2 * q], lo8[2 * q + 1], hi8[2 * q + 1]}, reinterpret_cast<lq_f4v*>(dst) + q);
-#endif
+                        if (LQ_NT_FLAG(a)) __builtin_nontemporal_store((lq_f4v){lo8[2 * q], hi8[2 * q], lo8[2 * q + 1], hi8[2 * q + 1]}, reinterpret_cast<lq_f4v*>(dst) + q);
+                        else reinterpret_cast<lq_f4v*>(dst)[q] = (lq_f4v){lo8[2 * q], hi8[2 * q], lo8[2 * q + 1], hi8[2 * q + 1]};   // (launch-uniform: TokArgs)
                 }
             }
     };
@@ -531,7 +539,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
             // acknowledgements stood between every wave and "stage 0 has landed" (vmcnt retires in order)
 #ifndef LQ_ABL_NOZESTORE
             if (a.ze_out) {
-                if (DEFER_ZE && t == T2 - 1) zdefg[g] = acc;
+                if (DEFER_ZE && LQ_DEFER_FLAG(a) && t == T2 - 1) zdefg[g] = acc;
                 else store_ze_tile(row, t, acc);
             }
 #endif
@@ -955,7 +963,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
 #ifdef LQ_ABL_NOZESTORE
         const bool have_def = false;
 #else
-        const bool have_def = DEFER_ZE && a.ze_out != nullptr;
+        const bool have_def = DEFER_ZE && LQ_DEFER_FLAG(a) && a.ze_out != nullptr;
 #endif
         lq_screen_core_rg<S, THREADS, TCF, NBF, PACKF, RG, COARSE, 4 * RG>(ahg, alg, tiles, L.ntiles, stage0, tid, frow, znrg, m1g, m2g, k1g, have_def, [&]() {
 #pragma unroll
@@ -1038,6 +1046,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 //   icrt (S = 13): w8rg1 1.19 ms, w4rg1 1.27
 // so the round-2 shape stays the default everywhere; the others remain as instances the parity tests run
 // (LIPVQ_TOK_SHAPE=w8rg1|w8rg2|w4rg2|w4rg1: measurement knob; results identical).
+// Schedule choices of the fused launch with IDENTICAL results whose better setting depends on the DEVICE (round 4,
+// profiles/r04_i_clock_ab.txt): MI355X devices hold different clocks under the same kernel (MI355X_MICROARCH.md, DVFS give-back items
+// 3-5).  With the last tile's z_e stores deferred and nontemporal, cfg2's launch takes 0.387 ms on a device that keeps 2.22 GHz under
+// it (0.404 without the deferral) -- and 0.437 ms on a device that answers the denser issue stream with 1.97 GHz (0.403 without:
+// 2.12 GHz).  Defaults: the settings that are never bad (no deferral, nontemporal); lipvq_tokenize_tune_f32 measures the four
+// combinations on the caller's device and shape and keeps the winner for that device; the options tok_defer_ze / tok_nt_ze override.
+#ifndef LQ_DEFAULT_DEFER_ZE
+#define LQ_DEFAULT_DEFER_ZE 0
+#endif
+struct LqSchedule { int defer_ze, nt_ze; };
+static std::atomic<int> g_tuned[64];                 // per device: 0 = not tuned, else 1 + (defer_ze | nt_ze << 1)
+static LqSchedule lq_schedule() {
+    LqSchedule sc{LQ_DEFAULT_DEFER_ZE, 1};
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        const int t = g_tuned[dev].load(std::memory_order_relaxed);
+        if (t) { sc.defer_ze = (t - 1) & 1; sc.nt_ze = ((t - 1) >> 1) & 1; }
+    }
+    if (const char* e = lq_knob("LIPVQ_TOK_DEFER_ZE")) sc.defer_ze = e[0] != '0';
+    if (const char* e = lq_knob("LIPVQ_TOK_NT_ZE")) sc.nt_ze = e[0] != '0';
+    return sc;
+}
+
 // In-place decisions (lq_screen_decide_inplace): three-product screen, codebooks the list kernel would finish alone, z_e rows stored --
 // and launches of at most LQ_INPLACE_MAX_ROWS rows.  Same box, cfg2, in place against the list kernel behind the launch
 // (profiles/r04_j_inplace_ab.txt): 65 536 rows 0.0637 -> 0.0585 ms, 131 072 rows 0.1096 -> 0.1054, 262 144 rows 0.2021 -> 0.1988,
@@ -1261,7 +1292,7 @@ static int tokenize_impl(const float* x, const float* packed, const void* packed
     }
     TokArgs a{x, packed, (const unsigned char*)packed16, (const unsigned char*)prep, codebook, idx, zq,
               (unsigned long long*)usage, ze_buf, amb_count, amb_list, w2q, pre0, pre1, pre2, N, A, D, K, LIPVQ_SCREEN_GAMMA, coarse,
-              lq_inplace(ze_buf != nullptr, coarse, K, N)};
+              lq_inplace(ze_buf != nullptr, coarse, K, N), lq_schedule().defer_ze, lq_schedule().nt_ze};
     int rc;
     if (pre0) {
         if ((((uintptr_t)pre0 | (uintptr_t)pre1 | (uintptr_t)pre2) & 15) != 0)
@@ -1300,6 +1331,54 @@ extern "C" int lipvq_tokenize_f32(const float* x, const float* packed, const flo
                                   const void* prep, int64_t* idx, float* zq, int64_t* usage, float* ze_out,
                                   void* workspace, int64_t N, int A, int J0, int J1, int D, int K, void* stream) {
     return tokenize_impl(x, packed, nullptr, raw6, codebook, prep, idx, zq, usage, ze_out, workspace, N, A, J0, J1, D, K, stream);
+}
+
+// lipvq_tokenize_f32's schedule tuned on the caller's device, shape and data: the four (defer_ze, nt_ze) combinations, each warmed
+// and then timed over `launches` back-to-back calls between HIP events, two alternating rounds, the minimum per combination; the
+// fastest becomes this device's setting for every later lipvq_tokenize_* call of the process.  SYNCHRONOUS (it waits for the
+// stream) and not capturable.  Every launch writes idx / zq / ze_out and accumulates into usage like lipvq_tokenize_f32 -- all four
+// combinations write the same values.  choice (may be NULL): defer_ze | nt_ze << 1;  ms4 (may be NULL): the four times per launch.
+extern "C" int lipvq_tokenize_tune_f32(const float* x, const float* packed, const float* const* raw6, const float* codebook,
+                                       const void* prep, int64_t* idx, float* zq, int64_t* usage, float* ze_out, void* workspace,
+                                       int64_t N, int A, int J0, int J1, int D, int K, void* stream, int launches, int* choice,
+                                       float* ms4) {
+    hipStream_t st = (hipStream_t)stream;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+        return fail(LIPVQ_EINVAL, "tokenize_tune: the stream is capturing (the tuner synchronises)");
+    if (launches < 1) return fail(LIPVQ_EINVAL, "tokenize_tune: launches < 1");
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(LIPVQ_EINVAL, "tokenize_tune: device index");
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(LIPVQ_EHIP, "tokenize_tune: hipEventCreate");
+    const int before = g_tuned[dev].load(std::memory_order_relaxed);
+    float best[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    int rc = LIPVQ_OK;
+    auto run = [&](int n) {
+        for (int i = 0; i < n && !rc; ++i)
+            rc = tokenize_impl(x, packed, nullptr, raw6, codebook, prep, idx, zq, usage, ze_out, workspace, N, A, J0, J1, D, K, stream);
+    };
+    run(launches);                                                       // the chip's clock and power state of a running job
+    for (int round = 0; round < 2 && !rc; ++round)
+        for (int c = 0; c < 4 && !rc; ++c) {
+            g_tuned[dev].store(1 + c, std::memory_order_relaxed);
+            run((launches + 1) / 2);
+            (void)hipEventRecord(e0, st);
+            run(launches);
+            (void)hipEventRecord(e1, st);
+            if (hipEventSynchronize(e1) != hipSuccess) rc = fail(LIPVQ_EHIP, "tokenize_tune: hipEventSynchronize");
+            float ms = 0.0f;
+            if (!rc && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms / launches < best[c]) best[c] = ms / launches;
+        }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) { g_tuned[dev].store(before, std::memory_order_relaxed); return rc; }
+    int win = 0;
+    for (int c = 1; c < 4; ++c) if (best[c] < best[win]) win = c;
+    g_tuned[dev].store(1 + win, std::memory_order_relaxed);
+    if (choice) *choice = win;
+    if (ms4) for (int c = 0; c < 4; ++c) ms4[c] = best[c];
+    return LIPVQ_OK;
 }
 
 // The forward half of a training step (v5:71-74 with everything autograd saves): lipvq_tokenize_f32 that also writes the three
@@ -1342,7 +1421,8 @@ static int vq_tokenize_impl(const float* x, const float* packed, const float* co
     }
     const int coarse = lq_screen_coarse(lq_screen_S(D), K);
     TokArgs a{x, packed, nullptr, (const unsigned char*)prep, codebook, idx, zq, (unsigned long long*)usage, ze_out, amb_count,
-              amb_list, w2q, pre0, pre1, pre2, N, A, D, K, LIPVQ_SCREEN_GAMMA, coarse, lq_inplace(true, coarse, K, N)};
+              amb_list, w2q, pre0, pre1, pre2, N, A, D, K, LIPVQ_SCREEN_GAMMA, coarse, lq_inplace(true, coarse, K, N),
+              lq_schedule().defer_ze, lq_schedule().nt_ze};
     int rc;
     switch (D) {
         case 32: rc = launch_tokenize_vq<2>(a, st); break;

@@ -617,6 +617,31 @@ def tokenize(x, packed: PackedMlp3, raw, codebook, prep: PreparedCodebook, usage
     return idx, zq, ze, ws
 
 
+def tokenize_tune(x, packed: PackedMlp3, raw, codebook, prep: PreparedCodebook, workspace=None, launches=150):
+    """lipvq_tokenize_tune_f32: time the fused launch's four device-dependent schedule combinations (identical results) on this
+    device, shape and data and keep the fastest for the process.  Synchronous.  Returns (choice, [ms per launch] * 4) with
+    choice = defer_ze | nt_ze << 1."""
+    raw = tuple(_chk(t, f"raw[{i}]") for i, t in enumerate(raw))
+    raw_arr = (_C.c_void_p * 6)(*[t.data_ptr() for t in raw])
+    x, codebook = _chk(x, "x"), _chk(codebook, "codebook")
+    N, A = x.shape
+    K, D = codebook.shape
+    if (packed.K0, packed.J2) != (A, D) or (prep.K, prep.D) != (K, D):
+        raise ValueError("tokenize_tune: packed encoder / prepared codebook do not match the inputs")
+    dev = x.device
+    idx = torch.empty(N, device=dev, dtype=torch.int64)
+    zq = torch.empty((N, D), device=dev, dtype=torch.float32)
+    usage = torch.zeros(K, device=dev, dtype=torch.int64)           # scratch: every timed launch accumulates into it
+    ws = workspace if workspace is not None else tokenize_workspace(N, D, dev)
+    choice = _C.c_int(-1)
+    ms4 = (_C.c_float * 4)()
+    with _on(dev):
+        check(lib.lipvq_tokenize_tune_f32(_ptr(x), _ptr(packed.buf), raw_arr, _ptr(codebook), _ptr(prep.buf), _ptr(idx), _ptr(zq),
+                                          _ptr(usage), None, _ptr(ws), N, A, packed.J0, packed.J1, D, K, _stream(), int(launches),
+                                          _C.byref(choice), ms4), "lipvq_tokenize_tune_f32")
+    return int(choice.value), [float(v) for v in ms4]
+
+
 def vq_tokenize(x, packed: PackedMlp3, codebook, prep: PreparedCodebook, usage=None, workspace=None, want_pre=False):
     """(idx, zq, ze, workspace) of the plain VQVAE's fused encode + quantize launch (lipvq_vq_tokenize_f32: ReLU encoder,
     `pow(2).sum(-1)` argmin): the same results as mlp3(relu x 3) + nearest(DIST_SQSUM).  z_e is always returned (the

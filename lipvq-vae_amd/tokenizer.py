@@ -295,6 +295,23 @@ class LLFQVAE_V4(_TokenizerBase):
         return ops.tokenize_supported(self.feature_dim, 64, self.hidden_dim, self.latent_dim, self.num_codes)
 
     @torch.no_grad()
+    def tune(self, x, launches=150):
+        """Measure the fused launch's device-dependent schedule choices on THIS device with this batch and keep the fastest for the
+        process (lipvq_tokenize_tune_f32; MI355X devices hold different clocks under the same kernel, and what wins on one loses on
+        another: profiles/r04_i_clock_ab.txt).  Results are identical under every choice.  Synchronous: call it once, outside any
+        timed or captured region.  Returns {"choice": {"defer_ze", "nt_ze"}, "ms_per_launch": {...}} or None (no fused launch here)."""
+        x = self._as_rows(x)
+        if x.shape[0] == 0 or not self.fused_shape():
+            return None
+        cb = self.quantizer.codebook.detach()
+        packed, _, Wn = self._packed_encoder()
+        w0, b0, w1, b1, _, b2, _ = (t.detach() for t in self._enc_params())
+        prep = self._cb_cache.get((self.quantizer.codebook,), lambda: ops.nearest_prepare(cb))
+        choice, ms = ops.tokenize_tune(x, packed, (w0, b0, w1, b1, Wn, b2), cb, prep, launches=launches)
+        return {"choice": {"defer_ze": choice & 1, "nt_ze": (choice >> 1) & 1},
+                "ms_per_launch": {f"defer_ze={c & 1},nt_ze={(c >> 1) & 1}": ms[c] for c in range(4)}}
+
+    @torch.no_grad()
     def tokenize(self, x, count_usage=True, mode="parity"):
         """encode + quantize: (indices[N] int64, z_latent[N,D])   (v5:71-74).
 

@@ -12,10 +12,13 @@ import time
 from pathlib import Path
 
 
-def child(tree, wl, seconds):
+def child(tree, wl, seconds, opts=""):
     sys.path.insert(0, str(Path(tree).resolve()))
     import torch
     import lipvq_vae_amd  # noqa: F401
+    for kv in filter(None, opts.split(",")):
+        from lipvq_vae_amd import ops
+        ops.set_option(*kv.split("="))
     from lipvq_vae_amd.tokenizer import LLFQVAE_V4
     from bench import WORKLOADS, trained_like_
     B, T, A, D, K = WORKLOADS[wl]
@@ -62,14 +65,15 @@ def main():
     wl, passes, trees = sys.argv[1], int(sys.argv[2]), sys.argv[3:]
     r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp", "--json"], capture_output=True, text=True)
     print("# rocm-smi idle sample:", r.stdout.strip()[:1500], r.stderr.strip()[:300])
-    print(f"{'pass':>4} {'tree':24s} {'ms/launch (median of windows)':>30} {'min':>8} {'sclk MHz':>9} {'power W':>8} {'temp C':>7}")
+    print(f"{'pass':>4} {'tree':60s} {'ms/launch (median of windows)':>30} {'min':>8} {'sclk MHz':>9} {'power W':>8} {'temp C':>7}")
     for p in range(passes):
         for tree in trees:
-            root, _, lib = tree.partition("::")                     # "<tree>::<library>" runs that tree's host code on another build
+            parts = tree.split("::")                                # "<tree>[::<library>[::opt=val,opt=val]]": that tree's host code on
+            root, lib, opts = parts[0], (parts[1] if len(parts) > 1 else ""), (parts[2] if len(parts) > 2 else "")   # another build / options
             env = dict(os.environ)
             if lib:
                 env["LIPVQ_HIP_LIBRARY"] = lib
-            proc = subprocess.Popen([sys.executable, __file__, "--child", root, wl, "4"], stdout=subprocess.PIPE, text=True, env=env)
+            proc = subprocess.Popen([sys.executable, __file__, "--child", root, wl, "4", opts], stdout=subprocess.PIPE, text=True, env=env)
             samples, stop = [], threading.Event()
             line = proc.stdout.readline()
             assert line.startswith("READY"), line
@@ -89,11 +93,11 @@ def main():
             def mean(i):
                 v = [s[i] for s in samples if s[i] is not None]
                 return sum(v) / len(v) if v else float("nan")
-            print(f"{p:4d} {tree:24s} {ms[len(ms) // 2]:30.4f} {ms[0]:8.4f} {mean(0):9.0f} {mean(1):8.0f} {mean(2):7.0f}", flush=True)
+            print(f"{p:4d} {tree:60s} {ms[len(ms) // 2]:30.4f} {ms[0]:8.4f} {mean(0):9.0f} {mean(1):8.0f} {mean(2):7.0f}", flush=True)
 
 
 if __name__ == "__main__":
     if sys.argv[1] == "--child":
-        child(sys.argv[2], sys.argv[3], float(sys.argv[4]))
+        child(sys.argv[2], sys.argv[3], float(sys.argv[4]), sys.argv[5] if len(sys.argv) > 5 else "")
     else:
         main()

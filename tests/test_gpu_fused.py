@@ -474,3 +474,45 @@ def test_in_place_decisions_equal_the_list_kernel(oracle, lipvq_option, N, A, D,
             seen.setdefault(setting, int(hdr[0]))
             assert seen[setting] == int(hdr[0])
     assert seen["0"] == seen["1"] == seen[None] and seen["0"] > 0, seen
+
+
+def test_schedule_choices_give_the_same_results_and_tune_keeps_one(oracle, lipvq_option):
+    """Round 4: the fused launch's two device-dependent schedule choices (options tok_defer_ze / tok_nt_ze; which combination is
+    fastest depends on the MI355X device: profiles/r04_i_clock_ab.txt) change nothing but speed -- indices, z_q, z_e and usage are
+    bit-identical under all four, and LLFQVAE_V4.tune (lipvq_tokenize_tune_f32) times them and keeps one."""
+    N, A, D, K = 70000, 7, 64, 1024
+    p, model = _setup(77, A, D, K, oracle)
+    xt = torch.from_numpy(O.make_inputs(78, N, A)).cuda()
+    ref = None
+    for d in ("0", "1"):
+        for n in ("0", "1"):
+            lipvq_option("tok_defer_ze", d)
+            lipvq_option("tok_nt_ze", n)
+            model.code_usage.zero_()
+            idx, zq, ze = model._tokenize_fused(xt, model.code_usage, want_ze=True)
+            got = (idx.clone(), zq.clone(), ze.clone(), model.code_usage.clone())
+            if ref is None:
+                ref = got
+                assert torch.equal(ze, model.encode(xt))
+            assert all(torch.equal(a, b) for a, b in zip(got, ref)), (d, n)
+    lipvq_option("tok_defer_ze", None)
+    lipvq_option("tok_nt_ze", None)
+    usage_before = model.code_usage.clone()
+    t = model.tune(xt, launches=20)
+    assert set(t["choice"]) == {"defer_ze", "nt_ze"} and all(v in (0, 1) for v in t["choice"].values())
+    assert len(t["ms_per_launch"]) == 4 and all(0.0 < v < 50.0 for v in t["ms_per_launch"].values()), t
+    assert torch.equal(model.code_usage, usage_before)                      # the tuner counts into a scratch of its own
+    idx, _ = model.tokenize(xt, count_usage=False)
+    assert torch.equal(idx, ref[0])
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        from lipvq_vae_amd import ops
+        cb = model.quantizer.codebook.detach()
+        packed, _, Wn = model._packed_encoder()
+        w0, b0, w1, b1, _, b2, _ = (t_.detach() for t_ in model._enc_params())
+        prep = ops.nearest_prepare(cb)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            with pytest.raises(RuntimeError, match="capturing"):
+                ops.tokenize_tune(xt, packed, (w0, b0, w1, b1, Wn, b2), cb, prep, launches=2)
