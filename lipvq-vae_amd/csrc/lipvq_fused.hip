@@ -437,8 +437,8 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                     typedef float lq_f4v __attribute__((ext_vector_type(4)));
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        if (LQ_NT_FLAG(a)) __builtin_nontemporal_store((lq_f4v){lo8[2 * q], hi8[2 * q], lo8[2 * q + 1], hi8[2 * q + 1]}, reinterpret_cast<lq_f4v*>(dst) + q);
-                        else reinterpret_cast<lq_f4v*>(dst)[q] = (lq_f4v){lo8[2 * q], hi8[2 * q], lo8[2 * q + 1], hi8[2 * q + 1]};   // (launch-uniform: TokArgs)
+                        if (S > 4 || TRAIN || LQ_NT_FLAG(a)) __builtin_nontemporal_store((lq_f4v){lo8[2 * q], hi8[2 * q], lo8[2 * q + 1], hi8[2 * q + 1]}, reinterpret_cast<lq_f4v*>(dst) + q);
+                        else reinterpret_cast<lq_f4v*>(dst)[q] = (lq_f4v){lo8[2 * q], hi8[2 * q], lo8[2 * q + 1], hi8[2 * q + 1]};   // (launch-uniform: TokArgs; S > 4 and the training instances: always nontemporal -- nothing to choose there, and the second copy of the stores cost icrt 1.4 %)
                 }
             }
     };
@@ -453,7 +453,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
 #ifndef LQ_DEFER_ZE_MAX_S
 #define LQ_DEFER_ZE_MAX_S 4
 #endif
-        constexpr bool DEFER_ZE = S <= LQ_DEFER_ZE_MAX_S;
+        constexpr bool DEFER_ZE = S <= LQ_DEFER_ZE_MAX_S && !TRAIN;
         f32x16 zdefg[RG];
         float n2g[RG], a2g[RG], fzg[RG], fowng[RG];
       // ---- phase A of row group GC: the round-2 block body, on this group's rows / fragments / pending z_q copy ----
