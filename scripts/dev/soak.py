@@ -20,10 +20,15 @@ while time.time() - t0 < budget:
     D = int(rng.choice([32, 64, 128, 208])) if rng.random() < 0.6 else int(rng.integers(1, 209))
     K = int(rng.choice([37, 256, 1000, 1024, 2048, 8192])) if D <= 128 else int(rng.choice([128, 1024, 4096]))
     ops.set_option("screen_mode", str(rng.choice(["fine", "coarse"])))              # read per launch by the library
-    ops.set_option("tok_shape", str(rng.choice(["w8rg1", "w8rg1", "w8rg2", "w4rg2", "w4rg1"])))
+    shape = rng.choice(["default", "default", "w8rg1", "w8rg2", "w4rg2", "w4rg1"])          # default: the library's size rule
+    ops.set_option("tok_shape", None if shape == "default" else str(shape))
+    inpl = rng.choice(["default", "0", "1"])                                                 # uncertified rows in place / listed
+    ops.set_option("tok_inplace", None if inpl == "default" else str(inpl))
+    ops.set_option("tok_defer_ze", str(rng.integers(2)))
+    ops.set_option("tok_nt_ze", str(rng.integers(2)))
     _ScreenMonitor.ENABLED = False
     A = int(rng.choice([3, 7, 12]))
-    N = int(rng.choice([1, 33, 257, 2049, 4100, 30000, 100001]))
+    N = int(rng.choice([1, 33, 257, 2049, 4100, 30000, 70001, 100001, 300000]))
     torch.manual_seed(int(rng.integers(1 << 30)))
     model = LLFQVAE_V4(A, D, num_codes=K).cuda()
     trained_like_(model, A, seed=int(rng.integers(1 << 30)))
@@ -56,7 +61,7 @@ while time.time() - t0 < budget:
     if ops.tokenize_supported(A, 64, 128, D, K):
         idx_f, zq_f = model.tokenize(x, count_usage=False)
         ref_f, _, _ = ops.nearest(model.encode(x), cb)
-        assert torch.equal(idx_f, ref_f), ("fused", N, A, D, K, ops.get_option("screen_mode"), ops.get_option("tok_shape"))
+        assert torch.equal(idx_f, ref_f), ("fused", N, A, D, K, ops.get_option("screen_mode"), ops.get_option("tok_shape"), ops.get_option("tok_inplace"))
         assert torch.equal(zq_f, cb[ref_f])
     if ops.tokenize_supported(A, 64, 128, D, K) and N > 2048 and K >= 64:
         # the plain VQVAE's fused launch (ReLU instance, per-row scales) against its own encoder + the all-pairs kernel
