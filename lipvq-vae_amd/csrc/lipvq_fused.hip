@@ -164,6 +164,9 @@ struct TokArgs {
     int nt_ze;                   // z_e rows are stored nontemporal                                                } same results: lq_schedule()
 };
 
+#ifndef LQ_PROLOGUE_DMA_MIN_S
+#define LQ_PROLOGUE_DMA_MIN_S 99  /* measurement knob: instances whose layer-1/2 weights travel by LDS-DMA under the first layer 0 (none: see the prologue) */
+#endif
 #ifdef LQ_CT_SCHEDULE             /* measurement builds: the two schedule choices as compile-time constants (defer_ze | nt_ze << 1) */
 #define LQ_DEFER_FLAG(a) ((LQ_CT_SCHEDULE & 1) != 0)
 #define LQ_NT_FLAG(a) ((LQ_CT_SCHEDULE & 2) != 0)
@@ -206,6 +209,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
     // ring, so they are streamed, one 16 KB output-tile slab at a time, through that ring -- which is idle during the encoder
     // phase -- by the same LDS-DMA + counted-vmcnt mechanism as the codebook (all eight waves work on the same tile).
     constexpr bool STREAM2 = !FAST && S >= LQ_STREAM2_MIN_S;
+    constexpr bool PROLOGUE_DMA = !FAST && S >= LQ_PROLOGUE_DMA_MIN_S;    // layers 1 / 2 copied by LDS-DMA under the first layer 0 (prologue)
     static_assert(!FAST || (S % 2 == 0 && S <= 8), "fast mode: D in {32, 64, 128}");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 #ifdef LQ_STAMPS
@@ -333,42 +337,74 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
             const float* P0 = a.packed + PL.oP0;
             const float* P1 = a.packed + PL.oP1;
             const float* P2 = a.packed + PL.oP2;
-            float4 r1[R1], r2[R2 > 0 ? R2 : 1];
+            // (round 4, measured, NOT the default: S >= LQ_PROLOGUE_DMA_MIN_S) layers 1 and 2 by LDS-DMA, issued BEHIND the loads of
+            // layer 0 / biases / mu / x (vmcnt retires in order: what layer 0 needs is older and is waited for alone) and waited for
+            // only where layer 1 first reads them -- the first row block's layer 0 runs under the copy.  One wave-instruction moves 16
+            // image entries: lane l brings component l & 3 of entry 16 c + (l >> 2).  Same box, against the register-staged copy in
+            // front of one barrier (profiles/r04_l_prologue_dma_ab.txt): cfg2 0.3884 -> 0.3922 ms (0.0592 -> 0.0607 at 65 536 rows: the
+            // dword-granular copy is slower than 16-byte register stores and layer 0 too short to hide it); icrt within the noise.
+            constexpr int RR1 = PROLOGUE_DMA ? 1 : R1, RR2 = PROLOGUE_DMA ? 1 : (R2 > 0 ? R2 : 1);
+            float4 r1[RR1], r2[RR2];
+            if constexpr (!PROLOGUE_DMA) {
 #pragma unroll
-            for (int it = 0; it < R1; ++it) {
-                int v = tid + it * THREADS;
-                v = v < NV1 ? v : NV1 - 1;
-                const float* src = P1 + ((size_t)(v >> 6) * 4) * 64 + (v & 63);
-                r1[it] = make_float4(src[0], src[64], src[128], src[192]);
-            }
+                for (int it = 0; it < R1; ++it) {
+                    int v = tid + it * THREADS;
+                    v = v < NV1 ? v : NV1 - 1;
+                    const float* src = P1 + ((size_t)(v >> 6) * 4) * 64 + (v & 63);
+                    r1[it] = make_float4(src[0], src[64], src[128], src[192]);
+                }
 #pragma unroll
-            for (int it = 0; it < R2; ++it) {
-                int v = tid + it * THREADS;
-                v = v < NV2 ? v : NV2 - 1;
-                const float* src = P2 + ((size_t)(v >> 6) * 4) * 64 + (v & 63);
-                r2[it] = make_float4(src[0], src[64], src[128], src[192]);
+                for (int it = 0; it < R2; ++it) {
+                    int v = tid + it * THREADS;
+                    v = v < NV2 ? v : NV2 - 1;
+                    const float* src = P2 + ((size_t)(v >> 6) * 4) * 64 + (v & 63);
+                    r2[it] = make_float4(src[0], src[64], src[128], src[192]);
+                }
             }
             // layer 0 (fan-in A: S0 k-steps, padded to whole groups of four with zeros), entry v = (t * S0q + sq) * 64 + l
             const int NV0 = T0 * S0q * 64;
-            for (int v0 = tid; v0 < NV0; v0 += THREADS) {
+            auto p0_entry = [&](int v0, float (&e)[4]) {
                 const int l = v0 & 63, sq = (v0 >> 6) % S0q, t = (v0 >> 6) / S0q;
-                float e[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int s = 4 * sq + q;
-                    e[q] = (s < S0) ? P0[((size_t)t * S0 + s) * 64 + l] : 0.0f;
+                    const float v = P0[((size_t)t * S0 + (s < S0 ? s : S0 - 1)) * 64 + l];          // (always a valid address)
+                    e[q] = (s < S0) ? v : 0.0f;
                 }
+            };
+            float e0[4];
+            p0_entry(tid < NV0 ? tid : NV0 - 1, e0);                      // (one entry per thread up to fan-in 16: loads first ...)
+            if constexpr (PROLOGUE_DMA) {
+                typedef __attribute__((address_space(3))) void* lds_ptr_t;
+                typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+                auto dma_image = [&](float* dstw, const float* P, int NV) {
+                    for (int c = wave; c < NV / 16; c += WAVES) {
+                        const int v = 16 * c + (lane >> 2);
+                        const float* src = P + ((size_t)(v >> 6) * 4 + (lane & 3)) * 64 + (v & 63);
+                        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(dstw + 64 * c), 4, 0, 0);
+                    }
+                };
+                static_assert(NV1 % 16 == 0 && NV2 % 16 == 0, "whole wave-instructions");
+                dma_image(w_P1, P1, NV1);                                 // ... then the copies (younger than every load above)
+                if (NV2 > 0) dma_image(w_P2, P2, NV2);
+            }
+            if (tid < NV0) *reinterpret_cast<float4*>(w_P0 + (size_t)tid * 4) = make_float4(e0[0], e0[1], e0[2], e0[3]);
+            for (int v0 = tid + THREADS; v0 < NV0; v0 += THREADS) {       // (fan-in > 16 only)
+                float e[4];
+                p0_entry(v0, e);
                 *reinterpret_cast<float4*>(w_P0 + (size_t)v0 * 4) = make_float4(e[0], e[1], e[2], e[3]);
             }
+            if constexpr (!PROLOGUE_DMA) {
 #pragma unroll
-            for (int it = 0; it < R1; ++it) {
-                const int v = tid + it * THREADS;
-                if (v < NV1) *reinterpret_cast<float4*>(w_P1 + (size_t)v * 4) = r1[it];
-            }
+                for (int it = 0; it < R1; ++it) {
+                    const int v = tid + it * THREADS;
+                    if (v < NV1) *reinterpret_cast<float4*>(w_P1 + (size_t)v * 4) = r1[it];
+                }
 #pragma unroll
-            for (int it = 0; it < R2; ++it) {
-                const int v = tid + it * THREADS;
-                if (v < NV2) *reinterpret_cast<float4*>(w_P2 + (size_t)v * 4) = r2[it];
+                for (int it = 0; it < R2; ++it) {
+                    const int v = tid + it * THREADS;
+                    if (v < NV2) *reinterpret_cast<float4*>(w_P2 + (size_t)v * 4) = r2[it];
+                }
             }
         }
         // biases re-laid out [t][h][r] = b[32 t + 2 r + h]: the 16 values of a lane's accumulator tile are 64 contiguous bytes
@@ -380,7 +416,8 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
         if (use_hist)
             for (int i = tid; i < a.K; i += THREADS) hist[i] = 0u;
     }
-    __syncthreads();
+    if constexpr (PROLOGUE_DMA) lq_wg_barrier();      // (LDS stores only: the layer-1/2 copies stay in flight -- waited for behind the first layer 0)
+    else __syncthreads();
 
 #ifdef LQ_EXP_STAGGER             /* experiment: the workgroup in the SIMDs' odd wave slots starts LQ_EXP_STAGGER cycles late */
     if (__builtin_amdgcn_s_getreg(6148) & 1) {
@@ -664,6 +701,10 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                                           GP * ((rd + 1) % (8 / GP)));
                     }
                 }
+            }
+            if (PROLOGUE_DMA && g == 0 && blk == (int64_t)blockIdx.x) {   // the workgroup's first row block: layers 1 / 2 have landed
+                lq_wait_vmcnt<0>();
+                lq_wg_barrier();
             }
             LQ_STAMP(0);
             // ---- layers 1 and 2: one stream of 16-byte weight reads (T1 S1/4 of layer 1, then T2 S2/4 of layer 2), each read
