@@ -38,6 +38,9 @@ class _LLFQFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, module, x, *params):
+        # (the engine would otherwise hand backward() a materialised [N, D] zero tensor for the non-differentiable z_latent: a 134 MB
+        # fill per step at the metric's batch)
+        ctx.set_materialize_grads(False)
         enc_packed, scale, Wn = module._packed_encoder()
         dec_packed = module._packed_decoder()
         codebook = module.quantizer.codebook.detach()
@@ -84,6 +87,8 @@ class _LLFQFn(torch.autograd.Function):
         from .backward import llfq_backward
         m = ctx.module
         _check_versions(ctx, (*m._enc_params(), m.quantizer.codebook, *m._dec_params()))
+        if g_loss is None:                               # the loss took no part in what is being differentiated
+            return (None,) * len(ctx.needs_input_grad)
         grads = llfq_backward(m, ctx.saved_tensors, g_loss)
         return (None, None) + tuple(grads)
 
@@ -110,12 +115,16 @@ class _NoCtx:
     def mark_non_differentiable(self, *a):
         pass
 
+    def set_materialize_grads(self, flag):
+        pass
+
 
 class _VQFn(torch.autograd.Function):
     """(z_latent, loss) of the plain VQVAE (reference backbone.py:38-76)."""
 
     @staticmethod
     def forward(ctx, module, x, *params):
+        ctx.set_materialize_grads(False)                 # (see _LLFQFn.forward)
         enc_packed = module._packed_encoder()
         dec_packed = module._packed_decoder()
         E = module.embedding.weight.detach()
@@ -162,6 +171,8 @@ class _VQFn(torch.autograd.Function):
         from .backward import vq_backward
         m = ctx.module
         _check_versions(ctx, (*m._enc_params(), *m._dec_params(), m.embedding.weight))
+        if g_loss is None:
+            return (None,) * len(ctx.needs_input_grad)
         grads = vq_backward(m, ctx.saved_tensors, g_loss)
         return (None, None) + tuple(grads)
 
@@ -190,6 +201,9 @@ class _ManualCtx:
         self.saved_tensors = tensors
 
     def mark_non_differentiable(self, *a):
+        pass
+
+    def set_materialize_grads(self, flag):
         pass
 
 

@@ -850,7 +850,9 @@ static int launch_mlp3_lds(const Mlp3Args& a, hipStream_t st, const char* what, 
     if (blocks > cus) blocks = cus;                  // one persistent workgroup per CU
     if (FUSE == 3) {                                 // one slot per wave in the partial sums; unused slots must read 0
         if (blocks * MLPL_WAVES > MLPL_LOSS_SLOTS) blocks = MLPL_LOSS_SLOTS / MLPL_WAVES;
-        if (hipMemsetAsync(a.loss_part, 0, 2 * MLPL_LOSS_SLOTS * sizeof(double), st) != hipSuccess) return fail(LIPVQ_EHIP, "%s: memset", what);
+        // (every wave of the grid writes its slot: with 256 workgroups x 8 waves none is left over and nothing needs zeroing)
+        if (blocks * MLPL_WAVES < MLPL_LOSS_SLOTS &&
+            hipMemsetAsync(a.loss_part, 0, 2 * MLPL_LOSS_SLOTS * sizeof(double), st) != hipSuccess) return fail(LIPVQ_EHIP, "%s: memset", what);
     }
     hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(64 * MLPL_WAVES), lds, st, a);
     *done = true;
