@@ -17,7 +17,8 @@ environment, as the driver's `python -m torch.distributed.run ... bench.py --gpu
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline      the fused tokenize launch: algorithmic flops per launch (164 736 flop
-                per row at config 2) / mean duration from HIP events on its stream, against two floors:
+                per row at config 2) / mean launch duration (one pair of HIP events over the K timed steps, on the
+                launches' stream: first launch's start to last launch's end, / K), against two floors:
                 `frac` = the matrix-pipe floor of its instruction mix (encoder on the fp32 MFMA pipe,
                 distance screen on the fp16 MFMA pipe with 3 split products per algorithmic product);
                 `frac_algorithmic_floor` = the stricter reading, algorithmic 2NKD distance flops at the
@@ -477,15 +478,8 @@ def main():
         model.code_usage = row
         last_row[0] = row
         # == LLFQVAE_V4.tokenize: ONE fused launch (encoder + Lipschitz layer + MFMA screen, csrc/lipvq_fused.hip)
-        # followed by the exact kernel for the rows the screen could not certify.  HIP events bracket it
-        # on the stream it is launched on (torch's current stream is handed to the C ABI).
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+        # followed by the exact kernel for the rows the screen could not certify (none where the launch decides them in place).
         idx, zq = model.tokenize(x)
-        if timed:
-            e1.record()
-            ev_pairs.append((e0, e1))
         if m == M - 1:
             reduce_set(b)
         return idx, zq
@@ -553,9 +547,16 @@ def main():
         step(False)
     drain()
     fence()
+    # ONE pair of HIP events over the timed region, on the stream the launches go to (torch's current stream is handed to the C ABI):
+    # mean launch duration = their distance / K.  (Until round 4 every step carried its own pair: forty event packets in a
+    # twenty-step region, 12 us of queue gaps per step that the sustained loop does not have -- the instrument slowed the measurement.)
+    e_first, e_last = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    e_first.record()
     for _ in range(args.steps):
         idx, zq = step(True)
+    e_last.record()
+    ev_pairs.append((e_first, e_last))
     drain()                                 # every histogram reduction is inside the timed region
     fence()
     elapsed = time.perf_counter() - t0
@@ -569,7 +570,7 @@ def main():
         usage_rows = int(last_row[0].sum().item())
     idx_timed = idx.clone()
 
-    tok_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / max(1, len(ev_pairs))
+    tok_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / max(1, args.steps)      # (first launch's start -> last launch's end) / K
     value = N_global * args.steps / elapsed
 
     # algorithmic work per launch: encoder 2*(A*64+64*128+128*D) + distance 2*K*D flop per row
