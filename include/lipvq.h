@@ -55,8 +55,8 @@ const char* lipvq_last_error(void);
  *   tok_ze_rows       batch size up to which a fused launch stores z_e for its exact stage when nothing else asks for it
  *   tok_grid          workgroups of the fused launch's persistent grid (default 256 = one per CU)
  *   tok_inplace       "0" | "1": the fused launch never / whenever possible lets its waves decide their uncertified rows in place
- *                     instead of listing them for a second kernel (default: K <= 2048 under the three-product screen, launches
- *                     of <= 262 144 rows)
+ *                     instead of listing them for a second kernel (default: whenever possible = K <= 2048 under the three-product
+ *                     screen with z_e rows stored)
  *   tok_defer_ze, tok_nt_ze   "0" | "1": the fused launch's two device-dependent schedule choices (the last z_e tile's stores issued
  *                     behind the screen's first stage copies; z_e rows stored nontemporal) -- overrides the defaults (0, 1) and
  *                     whatever lipvq_tokenize_tune_f32 found for the device

@@ -1110,14 +1110,14 @@ static LqSchedule lq_schedule() {
     return sc;
 }
 
-// In-place decisions (lq_screen_decide_inplace): three-product screen, codebooks the list kernel would finish alone, z_e rows stored --
-// and launches of at most LQ_INPLACE_MAX_ROWS rows.  Same box, cfg2, in place against the list kernel behind the launch
-// (profiles/r04_j_inplace_ab.txt): 65 536 rows 0.0637 -> 0.0585 ms, 131 072 rows 0.1096 -> 0.1054, 262 144 rows 0.2021 -> 0.1988,
-// 524 288 rows 0.3929 -> 0.3936: a wave that stops for a row (about 2 us: the row's z_e comes back from HBM) holds its workgroup
-// at the next block's first hand-over, and at eight blocks per wave that eats the 6 us the second kernel cost.
-// (LIPVQ_TOK_INPLACE=0 / 1: measurement knob -- never / whenever possible; results identical)
+// In-place decisions (lq_screen_decide_inplace): three-product screen, codebooks the list kernel would finish alone, z_e rows stored.
+// Same box, cfg2, in place against the list kernel behind the launch (profiles/r04_j_inplace_ab.txt): 65 536 rows 0.0637 -> 0.0585 ms,
+// 131 072 rows 0.1096 -> 0.1054, 262 144 rows 0.2069 -> 0.1993, 524 288 rows 0.3910 -> 0.3863.  (With the last z_e tile's stores
+// deferred -- the schedule of the round's first builds -- the full batch measured level, 0.3929 -> 0.3936, and a size rule kept
+// it on the list kernel; without the deferral the wave that stops ~2 us for a row no longer costs its workgroup the 6 us saved.)
+// (LIPVQ_TOK_INPLACE=0 / 1: measurement knob -- never / whenever possible; LQ_INPLACE_MAX_ROWS: compile-time size limit; results identical)
 #ifndef LQ_INPLACE_MAX_ROWS
-#define LQ_INPLACE_MAX_ROWS 262144
+#define LQ_INPLACE_MAX_ROWS 2147483647
 #endif
 static int lq_inplace(bool have_ze, int coarse, int K, int64_t N) {
     const bool can = have_ze && !coarse && K <= LQ_LISTS_ALL_K;

@@ -447,8 +447,8 @@ def test_workspace_header_is_kept_clean_by_the_launch_itself(oracle, N, A, D, K)
                                      (12345, 12, 208, 1024)])
 def test_in_place_decisions_equal_the_list_kernel(oracle, lipvq_option, N, A, D, K):
     """Round 4: under the three-product screen with K <= 2048 the wave that screened a row decides it itself when the screen does not
-    certify it (lq_screen_decide_inplace: the list kernel's own body on the row's stored z_e) -- by default for launches of at most
-    262 144 rows.  Forced on and forced off (option tok_inplace): same indices, z_q, usage and the same published count of rows
+    certify it (lq_screen_decide_inplace: the list kernel's own body on the row's stored z_e) -- the default at every batch size.
+    Forced on, forced off (option tok_inplace) and default: same indices, z_q, usage and the same published count of rows
     decided exactly; both equal the all-pairs exact kernel."""
     from lipvq_vae_amd import ops
     p, model = _setup(N % 1000 + D + 1, A, D, K, oracle)
