@@ -1006,10 +1006,16 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
 #else
         const bool have_def = DEFER_ZE && LQ_DEFER_FLAG(a) && a.ze_out != nullptr;
 #endif
-        lq_screen_core_rg<S, THREADS, TCF, NBF, PACKF, RG, COARSE, 4 * RG>(ahg, alg, tiles, L.ntiles, stage0, tid, frow, znrg, m1g, m2g, k1g, have_def, [&]() {
+        auto deferred_ze = [&]() {
 #pragma unroll
             for (int g_ = 0; g_ < RG; ++g_) store_ze_tile(((blk * WAVES + wave) * RG + g_) * 32 + ln, T2 - 1, zdefg[g_]);
-        });
+        };
+#ifndef LQ_SEED_E2
+#define LQ_SEED_E2 0              /* 1: measurement knob, the three-product chain seeded with |e'|^2 f (lq_screen_core_rg, SEED): 7 vector
+                                     instructions less per tile and 0.8 % SLOWER (profiles/r04_m_seed_e2_ab.txt) -- not the default */
+#endif
+        constexpr bool SEED_E2 = LQ_SEED_E2 && !COARSE && !VQ;                // (VQ: every row its own scale -- sixteen products either way)
+        lq_screen_core_rg<S, THREADS, TCF, NBF, PACKF, RG, COARSE, 4 * RG, decltype(deferred_ze), SEED_E2>(ahg, alg, tiles, L.ntiles, stage0, tid, frow, znrg, m1g, m2g, k1g, have_def, deferred_ze);
         LQ_STAMP(4);
         const unsigned keep_mask = PACKF ? ~((1u << lq_pack_bits(L.ntiles)) - 1u) : 0xffffffffu;
         unsigned char* scratch = stage0 + (size_t)wave * WSLICE;

@@ -148,7 +148,7 @@ __device__ __forceinline__ float lq_coarse_zn(float a2lo, float n2, float fz, fl
     const float t = lq_fma(rho, lq_fma(3.0f, A, B), A);
     return t * (fown / fz) * 1.0009765625f;                 // (1 + 2^-10): the norms' own fp32 rounding (D + 2 roundings each), generously
 }
-template <int LO, int HI, bool PACK = false, bool COARSE = false>
+template <int LO, int HI, bool PACK = false, bool COARSE = false, bool SEEDED = COARSE>
 __device__ __forceinline__ void lq_track_part(const f32x16& acc, float e2, float en, const float (&frow)[16], const float (&znr)[16],
                                               int id, unsigned keep_mask, float (&m1)[16], float (&m2)[16], int (&k1)[16]) {
 #ifdef LQ_ABL_NOTRACK
@@ -157,15 +157,15 @@ __device__ __forceinline__ void lq_track_part(const f32x16& acc, float e2, float
 #endif
 #pragma unroll
     for (int r = LO; r < HI; ++r) {
-        // COARSE: the chain started from |e'|^2 f - w (lq_screen_core_rg seeds it), the accumulator IS the booked value
-        const float v = COARSE ? acc[r] : LQ_E2_TERM(e2, frow[r], acc[r]);
+        // COARSE / SEEDED: the chain started from |e'|^2 f (- w) (lq_screen_core_rg seeds it), the accumulator IS the booked value
+        const float v = SEEDED ? acc[r] : LQ_E2_TERM(e2, frow[r], acc[r]);
         lq_track_one<PACK>(v, id, keep_mask, m1[r], m2[r], k1[r]);
     }
 }
 
 // the pending tile's registers that are booked behind MFMA j of the NM MFMAs of the running tile (NM = 3 S, or S for the
 // one-product chain): [16 j / NM, 16 (j + 1) / NM)   (j a compile-time constant after unrolling)
-template <int S, bool PACK, bool COARSE = false>
+template <int S, bool PACK, bool COARSE = false, bool SEEDED = COARSE>
 __device__ __forceinline__ void lq_track_after_mfma(int j, const f32x16& acc, float e2, float en, const float (&frow)[16],
                                                     const float (&znr)[16], int id, unsigned keep_mask, float (&m1)[16],
                                                     float (&m2)[16], int (&k1)[16]) {
@@ -178,7 +178,7 @@ __device__ __forceinline__ void lq_track_after_mfma(int j, const f32x16& acc, fl
 #pragma unroll
     for (int r = 0; r < 16; ++r)
         if (r >= lo && r < hi) {
-            const float v = COARSE ? acc[r] : LQ_E2_TERM(e2, frow[r], acc[r]);
+            const float v = SEEDED ? acc[r] : LQ_E2_TERM(e2, frow[r], acc[r]);
             lq_track_one<PACK>(v, id, keep_mask, m1[r], m2[r], k1[r]);
         }
 }
@@ -224,8 +224,14 @@ __host__ __device__ static inline int lq_pack_bits(int ntiles) { int b = 1; whil
 // and "stage 0 has landed" -- 3.5 % of the cfg2 launch (profiles/r04_g_ze_store_placement.txt).  Behind the copies, the prologue's
 // wait and the first hand-over simply leave NDEF more operations outstanding.
 struct LqNoDeferred { __device__ __forceinline__ void operator()() const {} };
+// SEED (round 4; three-product chains whose rows share ONE scale -- the fused launch's sigmoid latents): the chain of a tile starts
+// from |e'|^2 f, the same value in all sixteen registers (eight v_pk_mov_b32), instead of from zero with the term added per element
+// when the tile is booked (sixteen fmas): the accumulator is the booked value, as in the one-product chain.  MEASURED SLOWER (cfg2
+// 0.3832 -> 0.3861 ms, same box: the chain's first MFMA now waits for its C operand where it took an inline zero, and the fmas it
+// saves sat off the critical path) -- kept behind LQ_SEED_E2 as a record, off by default.  Screening values move
+// by roundings of the partial sums (covered by gamma: lipvq_screen.hip, "Error bound"); indices are whatever the exact arithmetic says.
 template <int S, int NT, int TC_ = screen_default_tc(S), int NB = 4, bool PACK = false, int RG = 1, bool COARSE = false, int NDEF = 0,
-          typename DEFERRED = LqNoDeferred>
+          typename DEFERRED = LqNoDeferred, bool SEED = false>
 __device__ __forceinline__ void lq_screen_core_rg(const f16x8 (&ah)[RG][S], const f16x8 (&al)[RG][S],
                                                   const unsigned char* __restrict__ tiles, int ntiles,
                                                   unsigned char* stage0, int tid, const float (&frow)[16],
@@ -368,10 +374,32 @@ __device__ __forceinline__ void lq_screen_core_rg(const f16x8 (&ah)[RG][S], cons
             if (s == 0) {
                 const float e2c = e2q[(c + par) & 1];
                 const float enc = enq[(c + par) & 1];
+                if constexpr (SEED && !COARSE) {
+                    // sixteen copies of one value as register PAIRS: v_pk_mov_b32 moves two dwords per instruction (hipcc writes
+                    // fifteen v_mov_b32 -- as many vector instructions as the fmas this arrangement removes)
+                    typedef float lq_f2 __attribute__((ext_vector_type(2)));
+                    const float e2f = e2c * frow[0];
+                    lq_f2 pr;
+                    pr.x = e2f;
+                    pr.y = e2f;
 #pragma unroll
-                for (int g_ = 0; g_ < RG; ++g_)
+                    for (int g_ = 0; g_ < RG; ++g_) {
+                        acc[g_][0] = pr.x;
+                        acc[g_][1] = pr.y;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[g_][r] = COARSE ? lq_fma(-znr[g_][r], enc, e2c * frow[r]) : 0.0f;
+                        for (int q = 1; q < 8; ++q) {
+                            lq_f2 d;
+                            asm volatile("v_pk_mov_b32 %0, %1, %1" : "=v"(d) : "v"(pr));
+                            acc[g_][2 * q] = d.x;
+                            acc[g_][2 * q + 1] = d.y;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int g_ = 0; g_ < RG; ++g_)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[g_][r] = COARSE ? lq_fma(-znr[g_][r], enc, e2c * frow[r]) : 0.0f;
+                }
                 int code = PACK ? (st * C::TC + c) : (st * C::TC + c) * 32 + ln;
                 if constexpr (PACK) asm volatile("" : "+v"(code));      // the tile index lives in a vector register (lq_track_one)
                 if (((c + par) & 1) == 0) { e2A = e2c; enA = enc; codeA = code; } else { e2B = e2c; enB = enc; codeB = code; }
@@ -411,7 +439,7 @@ __device__ __forceinline__ void lq_screen_core_rg(const f16x8 (&ah)[RG][S], cons
 #ifndef LQ_FRAG_BEFORE_MFMA
                 if (g_ == 0) { __builtin_amdgcn_sched_barrier(0); read_ahead(); __builtin_amdgcn_sched_barrier(0); }
 #endif
-                lq_track_after_mfma<S, PACK, COARSE>(COARSE ? s : 3 * s + 0, prev[g_], e2_prev, en_prev, frow, znr[g_], code_prev, keep_mask,
+                lq_track_after_mfma<S, PACK, COARSE, COARSE || SEED>(COARSE ? s : 3 * s + 0, prev[g_], e2_prev, en_prev, frow, znr[g_], code_prev, keep_mask,
                                                      m1[g_], m2[g_], k1[g_]);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -419,14 +447,14 @@ __device__ __forceinline__ void lq_screen_core_rg(const f16x8 (&ah)[RG][S], cons
 #pragma unroll
                 for (int g_ = 0; g_ < RG; ++g_) {
                     acc[g_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[g_][s], bh, acc[g_], 0, 0, 0);
-                    lq_track_after_mfma<S, PACK, false>(3 * s + 1, prev[g_], e2_prev, en_prev, frow, znr[g_], code_prev, keep_mask,
+                    lq_track_after_mfma<S, PACK, false, SEED>(3 * s + 1, prev[g_], e2_prev, en_prev, frow, znr[g_], code_prev, keep_mask,
                                                         m1[g_], m2[g_], k1[g_]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int g_ = 0; g_ < RG; ++g_) {
                     acc[g_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g_][s], bl, acc[g_], 0, 0, 0);
-                    lq_track_after_mfma<S, PACK, false>(3 * s + 2, prev[g_], e2_prev, en_prev, frow, znr[g_], code_prev, keep_mask,
+                    lq_track_after_mfma<S, PACK, false, SEED>(3 * s + 2, prev[g_], e2_prev, en_prev, frow, znr[g_], code_prev, keep_mask,
                                                         m1[g_], m2[g_], k1[g_]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -441,7 +469,7 @@ __device__ __forceinline__ void lq_screen_core_rg(const f16x8 (&ah)[RG][S], cons
     // the last tile's chain: ntiles is even, so it ran into accB
 #pragma unroll
     for (int g_ = 0; g_ < RG; ++g_)
-        lq_track_part<0, 16, PACK, COARSE>(accB[g_], e2B, enB, frow, znr[g_], codeB, keep_mask, m1[g_], m2[g_], k1[g_]);
+        lq_track_part<0, 16, PACK, COARSE, COARSE || SEED>(accB[g_], e2B, enB, frow, znr[g_], codeB, keep_mask, m1[g_], m2[g_], k1[g_]);
     // the copies issued for stages past the end go to the dummy KiB, but they count: drain them, then every wave has left
     // the stage buffers (the callers reuse them as per-wave scratch: lq_screen_decide)
 #ifndef LQ_ABL_NOSTAGE
