@@ -628,7 +628,7 @@ def main():
     }
     if sustained is not None:
         out["sustained"] = sustained
-    out["tuned"] = tuned if tuned is not None else "not tuned (--no-tune or no fused launch for this shape): library defaults"
+    out["tuned"] = tuned if tuned is not None else "not tuned (--no-tune, no fused launch for this shape, or a latent width above 64 whose instances have no device-dependent choice): library defaults"
     if tuned is not None and "fixed" not in tuned:
         tuned["what"] = ("set-up, untimed, rank 0's device: LLFQVAE_V4.tune timed the fused launch's four (defer_ze, nt_ze) schedule "
                          "combinations (identical results) and the process keeps the fastest")

@@ -194,7 +194,8 @@ int lipvq_tokenize_f32(const float* x, const float* packed, const float* const* 
  * own arguments (those of lipvq_tokenize_f32) -- each warmed, then `launches` back-to-back calls between HIP events, two alternating
  * rounds, minimum per combination -- and keeps the fastest as the current device's setting for every later lipvq_tokenize_* call of
  * the process.  SYNCHRONOUS (waits for the stream), not capturable; every launch writes idx / zq / ze_out and accumulates into usage
- * as lipvq_tokenize_f32 does.  choice (may be NULL): defer_ze | nt_ze << 1; ms4 (may be NULL): ms per launch of the four. */
+ * as lipvq_tokenize_f32 does.  choice (may be NULL): defer_ze | nt_ze << 1; ms4 (may be NULL): ms per launch of the four.
+ * Latent widths above 64 have no such choice (their instances fix both): the call returns at once with choice = -1. */
 int lipvq_tokenize_tune_f32(const float* x, const float* packed, const float* const* raw6, const float* codebook,
                             const void* prep, int64_t* idx, float* zq, int64_t* usage, float* ze_out, void* workspace,
                             int64_t N, int A, int J0, int J1, int D, int K, void* stream, int launches, int* choice, float* ms4);

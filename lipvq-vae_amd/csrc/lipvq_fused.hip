@@ -1394,6 +1394,11 @@ extern "C" int lipvq_tokenize_tune_f32(const float* x, const float* packed, cons
     if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
         return fail(LIPVQ_EINVAL, "tokenize_tune: the stream is capturing (the tuner synchronises)");
     if (launches < 1) return fail(LIPVQ_EINVAL, "tokenize_tune: launches < 1");
+    if (lq_screen_S(D) > 4) {                                                // (wider latents: their instances have no such choice)
+        if (choice) *choice = -1;
+        if (ms4) for (int c = 0; c < 4; ++c) ms4[c] = 0.0f;
+        return LIPVQ_OK;
+    }
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(LIPVQ_EINVAL, "tokenize_tune: device index");
     hipEvent_t e0, e1;

@@ -308,6 +308,8 @@ class LLFQVAE_V4(_TokenizerBase):
         w0, b0, w1, b1, _, b2, _ = (t.detach() for t in self._enc_params())
         prep = self._cb_cache.get((self.quantizer.codebook,), lambda: ops.nearest_prepare(cb))
         choice, ms = ops.tokenize_tune(x, packed, (w0, b0, w1, b1, Wn, b2), cb, prep, launches=launches)
+        if choice < 0:                                       # latent widths above 64: nothing device-dependent to choose
+            return None
         return {"choice": {"defer_ze": choice & 1, "nt_ze": (choice >> 1) & 1},
                 "ms_per_launch": {f"defer_ze={c & 1},nt_ze={(c >> 1) & 1}": ms[c] for c in range(4)}}
 

@@ -516,3 +516,10 @@ def test_schedule_choices_give_the_same_results_and_tune_keeps_one(oracle, lipvq
         with torch.cuda.graph(g, stream=s):
             with pytest.raises(RuntimeError, match="capturing"):
                 ops.tokenize_tune(xt, packed, (w0, b0, w1, b1, Wn, b2), cb, prep, launches=2)
+
+
+def test_tune_has_nothing_to_choose_for_wide_latents(oracle):
+    """lipvq_tokenize_tune_f32 returns at once (choice -1 -> None) where the instances fix both schedule flags (D > 64)."""
+    p, model = _setup(5, 12, 208, 1024, oracle)
+    xt = torch.from_numpy(O.make_inputs(6, 4096, 12)).cuda()
+    assert model.tune(xt, launches=5) is None
