@@ -60,6 +60,7 @@ const char* lipvq_last_error(void);
  *   tok_defer_ze, tok_nt_ze   "0" | "1": the fused launch's two device-dependent schedule choices (the last z_e tile's stores issued
  *                     behind the screen's first stage copies; z_e rows stored nontemporal) -- overrides the defaults (0, 1) and
  *                     whatever lipvq_tokenize_tune_f32 found for the device
+ *   tok_ze_ring       "0": the z_e scratch of an in-place launch is written in full (N x D floats) instead of as a 2 048-wave ring
  *   rows_grid, wgrad_chunk, wgrad_per_tile, wgrad_no_wg5, wgrad_rows, embed_bwd_grid, mlp3_small_tiles, mlp3_sub, mlp3_lds_rows
  *                     grid / route choices of the exact-rows, weight-gradient, embedding-backward and MLP kernels (read ONCE, at the
  *                     first launch of that kind: set them before it) */

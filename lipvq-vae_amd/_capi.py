@@ -139,7 +139,7 @@ lib = _load()
 
 
 OPTIONS = ("screen_mode", "tok_shape", "tok_ze_rows", "tok_grid", "rows_grid", "wgrad_chunk", "wgrad_per_tile", "wgrad_no_wg5",
-           "wgrad_rows", "embed_bwd_grid", "mlp3_small_tiles", "mlp3_sub", "mlp3_lds_rows", "tok_inplace", "tok_defer_ze", "tok_nt_ze")
+           "wgrad_rows", "embed_bwd_grid", "mlp3_small_tiles", "mlp3_sub", "mlp3_lds_rows", "tok_inplace", "tok_defer_ze", "tok_nt_ze", "tok_ze_ring")
 
 
 def set_option(name: str, value=None) -> None:

@@ -162,6 +162,8 @@ struct TokArgs {
     int inplace;                 // uncertified rows are decided by the wave that screened them (needs ze_out; lipvq_screen.h)
     int defer_ze;                // S <= 4: the last tile's z_e stores go behind the screen's first stage copies   } launch-uniform schedule choices,
     int nt_ze;                   // z_e rows are stored nontemporal                                                } same results: lq_schedule()
+    int ze_ring;                 // ze_out is a RING: a wave's 32 rows of every row block go to the same 32 rows (in-place launches whose
+                                 // caller wants no z_e: lq_ze_ring) -- the rows live in L2 until the wave has decided them
 };
 
 #ifndef LQ_PROLOGUE_DMA_MIN_S
@@ -452,6 +454,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
     // the low half-wave, the odd ones in the high half.  One v_permlane32_swap per register pair (low half's r >= 8 <-> high
     // half's r < 8) leaves the low lane with features 32t .. 32t+15 and the high lane with 32t+16 .. 32t+31, i.e. four 16-byte
     // stores of consecutive floats per lane (64 contiguous bytes per lane) instead of sixteen 4-byte stores scattered over the row.
+    int64_t ze_shift = 0;          // ring mode: rows of row block blk are stored ze_shift rows lower (set per block)
     auto store_ze_tile = [&](const int64_t row, const int t, const f32x16& acc) {
             {
                 float lo8[8], hi8[8];                 // after the swaps: lo8[j] = feature base + 2j, hi8[j] = base + 2j + 1
@@ -467,7 +470,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
                 // low lanes : lo8[j] = feat 2j (own, even), hi8[j] = feat 2j+1 (from the high lane)        -> base 32t
                 // high lanes: lo8[j] = feat 16+2j (from the low lane, even), hi8[j] = feat 16+2j+1 (own) -> base 32t+16
                 if (row < a.N && 2 * t + h < S) {                // (the high lanes' 16 features of a half-used last tile do not exist)
-                    float4* dst = reinterpret_cast<float4*>(a.ze_out + (size_t)row * a.D + 32 * t + 16 * h);
+                    float4* dst = reinterpret_cast<float4*>(a.ze_out + (size_t)(row - ze_shift) * a.D + 32 * t + 16 * h);
                     // nontemporal (round 4): written once, read back for a fraction of a percent of the rows -- the stream should not
                     // displace the codebook tiles and weights every workgroup re-reads from L2 (with the z_q rows the same way:
                     // cfg2 -2.4 %, icrt -2.9 %, same box, profiles/r04_e_nt_stores_ab.txt)
@@ -483,6 +486,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
 #ifdef LQ_STAMPS
         st_prev = __builtin_amdgcn_s_memtime();
 #endif
+        ze_shift = a.ze_ring ? (blk - (int64_t)blockIdx.x) * (WAVES * RG * 32) : 0;
         f16x8 ahg[RG][S], alg[RG][S];
         // z_e of each group's LAST layer-2 tile, stored behind the screen's first copies -- in the instances with registers to spare
         // (S <= 4: cfg2 0.4006 -> 0.3944 ms; at S = 13 the sixteen registers held across the end of layer 2 cost more than the
@@ -1034,7 +1038,7 @@ __device__ __forceinline__ void tokenize_body(const TokArgs& a) {
             // (lq_screen_decide_inplace) and they go on as certified ones -- no list kernel behind the launch
             if (!COARSE && a.inplace)
                 certified = lq_screen_decide_inplace<PACKF, 2 * S, VQ ? LIPVQ_DIST_SQSUM : LIPVQ_DIST_NORM>(
-                    dec, certified, row_sane, my_k, row0, row < a.N, a.amb_count, a.ze_out, a.cb, a.K, lane, keep_mask, scratch);
+                    dec, certified, row_sane, my_k, row0 - ze_shift, row < a.N, a.amb_count, a.ze_out, a.cb, a.K, lane, keep_mask, scratch);
             else
                 lq_screen_emit<PACKF>(dec, certified, row_sane, my_k, row, row < a.N, a.amb_count, a.amb_list, a.N, a.K, lane, keep_mask, scratch);
             if (h == 0 && row < a.N && certified) {
@@ -1104,8 +1108,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
 struct LqSchedule { int defer_ze, nt_ze; };
 static std::atomic<int> g_tuned[64];                 // per device: 0 = not tuned, else 1 + (defer_ze | nt_ze << 1)
-static LqSchedule lq_schedule() {
-    LqSchedule sc{LQ_DEFAULT_DEFER_ZE, 1};
+static LqSchedule lq_schedule(int ring = 0) {
+    LqSchedule sc{LQ_DEFAULT_DEFER_ZE, ring ? 0 : 1};      // (ring rows are meant to stay in L2: plain stores unless tuned / told otherwise)
     int dev = 0;
     if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
         const int t = g_tuned[dev].load(std::memory_order_relaxed);
@@ -1132,6 +1136,17 @@ static int lq_inplace(bool have_ze, int coarse, int K, int64_t N) {
         if (e[0] == '1') return can ? 1 : 0;
     }
     return (can && N <= LQ_INPLACE_MAX_ROWS) ? 1 : 0;
+}
+// Ring mode of the z_e scratch (round 4, late): where the launch decides its uncertified rows in place and the caller wants no z_e,
+// nothing reads a row's z_e after its wave has decided the row block -- so every block's 32 rows of a wave go to the SAME 32 rows of
+// the scratch (2 048 waves x 32 rows x D floats: 16 MB at D = 64) instead of streaming over N x D floats.  Measured, same box, three
+// alternating passes (profiles/r04_n_ze_ring_ab.txt): cfg2 0.3848 -> 0.3829 ms.  The stores still leave the L2 (WRITE_SIZE 275 -> 250
+// MB per launch, HBM traffic 298 -> 270 MB: this L2 writes the rows through whether or not they are overwritten 50 us later), so the
+// gain is the read side of the in-place decisions and 118 MB of address range less, not the 134 MB of stores hoped for.
+// (LIPVQ_TOK_ZE_RING=0: measurement knob, the full scratch.)
+static int lq_ze_ring(bool caller_wants_ze, int inplace) {
+    if (const char* e = lq_knob("LIPVQ_TOK_ZE_RING")) if (e[0] == '0') return 0;
+    return (!caller_wants_ze && inplace) ? 1 : 0;
 }
 struct TokShape { int waves, rg; };
 static TokShape tok_shape_env() {              // read per launch (a getenv: nanoseconds), so that a test can switch shapes in-process
@@ -1339,7 +1354,10 @@ static int tokenize_impl(const float* x, const float* packed, const void* packed
     }
     TokArgs a{x, packed, (const unsigned char*)packed16, (const unsigned char*)prep, codebook, idx, zq,
               (unsigned long long*)usage, ze_buf, amb_count, amb_list, w2q, pre0, pre1, pre2, N, A, D, K, LIPVQ_SCREEN_GAMMA, coarse,
-              lq_inplace(ze_buf != nullptr, coarse, K, N), lq_schedule().defer_ze, lq_schedule().nt_ze};
+              lq_inplace(ze_buf != nullptr, coarse, K, N), 0, 0, 0};
+    a.ze_ring = lq_ze_ring(ze_out != nullptr, a.inplace);
+    a.defer_ze = lq_schedule(a.ze_ring).defer_ze;
+    a.nt_ze = lq_schedule(a.ze_ring).nt_ze;
     int rc;
     if (pre0) {
         if ((((uintptr_t)pre0 | (uintptr_t)pre1 | (uintptr_t)pre2) & 15) != 0)
@@ -1425,8 +1443,12 @@ extern "C" int lipvq_tokenize_tune_f32(const float* x, const float* packed, cons
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (rc) { g_tuned[dev].store(before, std::memory_order_relaxed); return rc; }
-    int win = 0;
-    for (int c = 1; c < 4; ++c) if (best[c] < best[win]) win = c;
+    // the default of this launch's mode stays unless another combination is faster by more than half a percent (ties are common, and
+    // the ring's plain stores are what keeps its rows out of HBM)
+    const int ring = lq_ze_ring(ze_out != nullptr, lq_inplace(true, lq_screen_coarse(lq_screen_S(D), K), K, N));
+    const int dflt = LQ_DEFAULT_DEFER_ZE | ((ring ? 0 : 1) << 1);
+    int win = dflt;
+    for (int c = 0; c < 4; ++c) if (best[c] < 0.995f * best[dflt] && best[c] < best[win]) win = c;
     g_tuned[dev].store(1 + win, std::memory_order_relaxed);
     if (choice) *choice = win;
     if (ms4) for (int c = 0; c < 4; ++c) ms4[c] = best[c];
@@ -1474,7 +1496,7 @@ static int vq_tokenize_impl(const float* x, const float* packed, const float* co
     const int coarse = lq_screen_coarse(lq_screen_S(D), K);
     TokArgs a{x, packed, nullptr, (const unsigned char*)prep, codebook, idx, zq, (unsigned long long*)usage, ze_out, amb_count,
               amb_list, w2q, pre0, pre1, pre2, N, A, D, K, LIPVQ_SCREEN_GAMMA, coarse, lq_inplace(true, coarse, K, N),
-              lq_schedule().defer_ze, lq_schedule().nt_ze};
+              lq_schedule().defer_ze, lq_schedule().nt_ze, 0};
     int rc;
     switch (D) {
         case 32: rc = launch_tokenize_vq<2>(a, st); break;

@@ -32,7 +32,7 @@ int lipvq_check_launch(const char* what) {
 // ------------------------------------------------------------------------------------------
 static const char* const g_opt_names[] = {"screen_mode", "tok_shape", "tok_ze_rows", "tok_grid", "rows_grid", "wgrad_chunk",
                                           "wgrad_per_tile", "wgrad_no_wg5", "wgrad_rows", "embed_bwd_grid", "mlp3_small_tiles",
-                                          "mlp3_sub", "mlp3_lds_rows", "tok_inplace", "tok_defer_ze", "tok_nt_ze"};
+                                          "mlp3_sub", "mlp3_lds_rows", "tok_inplace", "tok_defer_ze", "tok_nt_ze", "tok_ze_ring"};
 constexpr int kNumOpts = (int)(sizeof(g_opt_names) / sizeof(g_opt_names[0]));
 static char g_opt_vals[kNumOpts][32];
 static bool g_opt_set[kNumOpts];
