@@ -736,7 +736,9 @@ def main():
     out["roofline"].update({"traffic": traffic, "traffic_source": traffic_src, "traffic_detail": traffic_detail,
                             "traffic_note": "includes N x D x 4 bytes of z_e STORES beyond the algorithmic bytes (134 MB at cfg2): the launch keeps "
                                             "z_e for its exact stage -- deciding the uncertified rows from stored rows beats re-encoding them from "
-                                            "x (profiles/r03_z_ze_store_ab.txt); per kernel and per cause: profiles/r04_e_traffic_accounting.md "
+                                            "x (profiles/r03_z_ze_store_ab.txt); where the rows are decided in place the stores go to a 16 MB ring, "
+                                            "but the L2 still writes them through (profiles/r04_n_ze_ring_ab.txt); per kernel and per cause: "
+                                            "profiles/r04_e_traffic_accounting.md "
                                             "(z_e / z_q rows are nontemporal stores, for which WRITE_SIZE reads 5-15 % above the bytes stored)"})
     failed = False
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
