@@ -26,6 +26,7 @@ while time.time() - t0 < budget:
     ops.set_option("tok_inplace", None if inpl == "default" else str(inpl))
     ops.set_option("tok_defer_ze", str(rng.integers(2)))
     ops.set_option("tok_nt_ze", str(rng.integers(2)))
+    ops.set_option("tok_ze_ring", None if rng.random() < 0.7 else "0")                       # the z_e scratch as a ring (default) / in full
     _ScreenMonitor.ENABLED = False
     A = int(rng.choice([3, 7, 12]))
     N = int(rng.choice([1, 33, 257, 2049, 4100, 30000, 70001, 100001, 300000]))
